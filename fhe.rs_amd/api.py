@@ -1,0 +1,549 @@
+"""Host-side mirror of the reference types that sit on the hot path, as thin ctypes wrappers
+over the C ABI (include/fhe_hip.h).  Names, argument meaning and error behaviour follow fhe.rs:
+
+    Context, Scaler, Switcher                  fhe_math::rq            (crates/fhe-math/src/rq/)
+    KeySwitchingKey, RelinearizationKey,
+    GaloisKey, EvaluationKey, Multiplicator,
+    BfvParameters                              fhe::bfv                (crates/fhe/src/bfv/)
+
+Every compute method accepts either
+  * a numpy uint64 array  -> host-pointer entry point (synchronous, returns a new array), or
+  * a torch CUDA tensor   -> `_dev` entry point on torch's current stream (device pointers;
+    torch is used purely as the device allocator / stream provider).
+Polynomials are `[..., L, N]` row-major exactly like `rq::Poly`; leading dims are the batch.
+Nothing in this module computes on the CPU: without the HIP library it cannot be imported.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, FheError  # noqa: F401  (re-exported)
+
+try:  # torch is only the device allocator / stream provider
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_dev(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _np(x):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_lib.u64p)
+
+
+def _dptr(t):
+    if not t.is_cuda or not t.is_contiguous() or t.element_size() != 8:
+        raise ValueError("device buffers must be contiguous 8-byte CUDA tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _limbs(x: int):
+    out = []
+    while True:
+        out.append(x & 0xFFFFFFFFFFFFFFFF)
+        x >>= 64
+        if x == 0:
+            break
+    return np.array(out, dtype=np.uint64)
+
+
+class Context:
+    """rq::Context (crates/fhe-math/src/rq/context.rs:9-92)."""
+
+    def __init__(self, moduli, degree, device=0, tables=None, _handle=None, _owner=None):
+        self._owner = _owner
+        if _handle is not None:
+            self._h = _handle
+        else:
+            m = _np(moduli)
+            h = C.c_void_p()
+            if tables is None:
+                args = [None] * 6
+                keep = []
+            else:
+                keep = [_np(tables[k]) for k in ("omegas", "omegas_shoup", "zetas_inv", "zetas_inv_shoup",
+                                                 "size_inv", "size_inv_shoup")]
+                args = [_ptr(a) for a in keep]
+            check(_lib.lib().fhe_ctx_create(device, degree, len(m), _ptr(m), *args, C.byref(h)))
+            self._h = h
+        L = _lib.lib()
+        self.degree = L.fhe_ctx_degree(self._h)
+        self.nmoduli = L.fhe_ctx_nmoduli(self._h)
+        self.device = L.fhe_ctx_device(self._h)
+        mm = np.zeros(self.nmoduli, dtype=np.uint64)
+        check(L.fhe_ctx_moduli(self._h, _ptr(mm)))
+        self.moduli = [int(x) for x in mm]
+
+    def __del__(self):
+        if self._owner is None and getattr(self, "_h", None) is not None and _lib._lib is not None:
+            _lib._lib.fhe_ctx_destroy(self._h)
+
+    def at_level(self, level):
+        """Context::context_at_level."""
+        h = C.c_void_p()
+        check(_lib.lib().fhe_ctx_at_level(self._h, level, C.byref(h)))
+        return Context(None, None, _handle=h, _owner=self._owner or self)
+
+    def niterations_to(self, other):
+        n = C.c_size_t()
+        check(_lib.lib().fhe_ctx_niterations_to(self._h, other._h, C.byref(n)))
+        return n.value
+
+    def table(self, which):
+        shape = (self.nmoduli, self.degree) if which < 4 else ((self.nmoduli,) if which < 6 else (max(self.nmoduli - 1, 0),))
+        out = np.zeros(max(int(np.prod(shape)), 1), dtype=np.uint64)
+        check(_lib.lib().fhe_ctx_get_table(self._h, which, _ptr(out)))
+        return out[: int(np.prod(shape))].reshape(shape)
+
+    # -- helpers ------------------------------------------------------------------
+    def _batch(self, x, rows=None):
+        rows = self.nmoduli if rows is None else rows
+        shp = tuple(x.shape)
+        if len(shp) < 2 or shp[-1] != self.degree or shp[-2] != rows:
+            raise ValueError(f"expected [..., {rows}, {self.degree}], got {shp}")
+        b = 1
+        for d in shp[:-2]:
+            b *= d
+        return b
+
+    def _unary_inplace(self, host_fn, dev_fn, x):
+        L = _lib.lib()
+        if _is_dev(x):
+            check(getattr(L, dev_fn)(self._h, _dptr(x), self._batch(x), _stream()))
+            return x
+        a = _np(x).copy()
+        check(getattr(L, host_fn)(self._h, _ptr(a), self._batch(a)))
+        return a
+
+    def _binary_inplace(self, host_fn, dev_fn, x, y):
+        L = _lib.lib()
+        if _is_dev(x):
+            check(getattr(L, dev_fn)(self._h, _dptr(x), _dptr(y), self._batch(x), _stream()))
+            return x
+        a, b = _np(x).copy(), _np(y)
+        if a.shape != b.shape:
+            raise ValueError("shape mismatch")
+        check(getattr(L, host_fn)(self._h, _ptr(a), _ptr(b), self._batch(a)))
+        return a
+
+    # -- NttOperator / Poly representation changes (rq/mod.rs:335-354) ---------------
+    def ntt_forward(self, polys):
+        return self._unary_inplace("fhe_ntt_forward", "fhe_ntt_forward_dev", polys)
+
+    def ntt_backward(self, polys):
+        return self._unary_inplace("fhe_ntt_backward", "fhe_ntt_backward_dev", polys)
+
+    # -- rq/ops.rs ----------------------------------------------------------------------
+    def add(self, a, b):
+        return self._binary_inplace("fhe_poly_add", "fhe_poly_add_dev", a, b)
+
+    def sub(self, a, b):
+        return self._binary_inplace("fhe_poly_sub", "fhe_poly_sub_dev", a, b)
+
+    def mul(self, a, b):
+        return self._binary_inplace("fhe_poly_mul", "fhe_poly_mul_dev", a, b)
+
+    def neg(self, a):
+        return self._unary_inplace("fhe_poly_neg", "fhe_poly_neg_dev", a)
+
+    def mul_shoup(self, a, b, b_shoup):
+        L = _lib.lib()
+        if _is_dev(a):
+            check(L.fhe_poly_mul_shoup_dev(self._h, _dptr(a), _dptr(b), _dptr(b_shoup), self._batch(a), _stream()))
+            return a
+        x, y, ys = _np(a).copy(), _np(b), _np(b_shoup)
+        check(L.fhe_poly_mul_shoup(self._h, _ptr(x), _ptr(y), _ptr(ys), self._batch(x)))
+        return x
+
+    def shoup(self, a):
+        """Poly::compute_coefficients_shoup (host, setup-time)."""
+        x = _np(a)
+        out = np.zeros_like(x)
+        check(_lib.lib().fhe_poly_shoup(self._h, _ptr(x), _ptr(out), self._batch(x)))
+        return out
+
+    def substitute(self, exponent, polys, ntt=True):
+        """Poly::substitute with SubstitutionExponent::new(ctx, exponent)."""
+        L = _lib.lib()
+        if _is_dev(polys):
+            out = torch.empty_like(polys)
+            check(L.fhe_poly_substitute_dev(self._h, exponent, _dptr(polys), _dptr(out), self._batch(polys),
+                                            1 if ntt else 0, _stream()))
+            return out
+        x = _np(polys)
+        out = np.zeros_like(x)
+        check(L.fhe_poly_substitute(self._h, exponent, _ptr(x), _ptr(out), self._batch(x), 1 if ntt else 0))
+        return out
+
+    def switch_down(self, polys):
+        """Poly::<PowerBasis>::switch_down: [..., L, N] -> [..., L-1, N]."""
+        L = _lib.lib()
+        b = self._batch(polys)
+        oshape = tuple(polys.shape[:-2]) + (self.nmoduli - 1, self.degree)
+        if _is_dev(polys):
+            out = torch.empty(oshape, dtype=polys.dtype, device=polys.device)
+            check(L.fhe_poly_switch_down_dev(self._h, _dptr(polys), _dptr(out), b, _stream()))
+            return out
+        x = _np(polys)
+        out = np.zeros(oshape if self.nmoduli > 1 else (1,), dtype=np.uint64)
+        check(L.fhe_poly_switch_down(self._h, _ptr(x), _ptr(out), b))
+        return out
+
+    def ciphertext_switch_down(self, ct):
+        """Ciphertext::switch_down: [..., parts, L, N] Ntt -> [..., parts, L-1, N] Ntt."""
+        L = _lib.lib()
+        parts = ct.shape[-3]
+        b = self._batch(ct) // parts
+        oshape = tuple(ct.shape[:-2]) + (self.nmoduli - 1, self.degree)
+        if _is_dev(ct):
+            out = torch.empty(oshape, dtype=ct.dtype, device=ct.device)
+            check(L.fhe_bfv_switch_down_dev(self._h, parts, _dptr(ct), _dptr(out), b, _stream()))
+            return out
+        x = _np(ct)
+        out = np.zeros(oshape if self.nmoduli > 1 else (1,), dtype=np.uint64)
+        check(L.fhe_bfv_switch_down(self._h, parts, _ptr(x), _ptr(out), b))
+        return out
+
+    def synth_uniform(self, seed, ct0, part0, nparts, batch):
+        """Device-side synthetic residues [batch, nparts, L, N] (bench / parity inputs)."""
+        out = torch.empty((batch, nparts, self.nmoduli, self.degree), dtype=torch.int64, device=f"cuda:{self.device}")
+        check(_lib.lib().fhe_synth_uniform_dev(self._h, seed, ct0, part0, nparts, _dptr(out), batch, _stream()))
+        return out
+
+
+class Scaler:
+    """rq::scaler::Scaler (crates/fhe-math/src/rq/scaler.rs:18-127); the scaling factor is
+    ScalingFactor::new(numerator, denominator) given as Python ints."""
+
+    def __init__(self, from_ctx, to_ctx, numerator=1, denominator=1, _handle=None, _owner=None):
+        self.from_ctx, self.to_ctx = from_ctx, to_ctx
+        self._owner = _owner
+        if _handle is not None:
+            self._h = _handle
+        else:
+            n, d = _limbs(numerator), _limbs(denominator)
+            h = C.c_void_p()
+            check(_lib.lib().fhe_scaler_create(from_ctx._h, to_ctx._h, _ptr(n), len(n), _ptr(d), len(d), C.byref(h)))
+            self._h = h
+        self.number_common_moduli = _lib.lib().fhe_scaler_number_common_moduli(self._h)
+
+    @classmethod
+    def from_constants(cls, from_ctx, to_ctx, number_common_moduli, is_one, k):
+        """All RnsScaler fields supplied by the caller (what a Rust host already holds)."""
+        keep = {n: _np(k[n]) for n in ("gamma", "gamma_shoup", "omega", "omega_shoup", "theta_omega_lo",
+                                        "theta_omega_hi", "theta_garner_lo", "theta_garner_hi")}
+        sign = np.ascontiguousarray(np.asarray(k["theta_omega_sign"], dtype=np.uint8))
+        h = C.c_void_p()
+        check(_lib.lib().fhe_scaler_create_from_constants(
+            from_ctx._h, to_ctx._h, number_common_moduli, 1 if is_one else 0,
+            _ptr(keep["gamma"]), _ptr(keep["gamma_shoup"]), _ptr(keep["omega"]), _ptr(keep["omega_shoup"]),
+            int(k["theta_gamma_lo"]), int(k["theta_gamma_hi"]), 1 if k["theta_gamma_sign"] else 0,
+            _ptr(keep["theta_omega_lo"]), _ptr(keep["theta_omega_hi"]), sign.ctypes.data_as(_lib.u8p),
+            _ptr(keep["theta_garner_lo"]), _ptr(keep["theta_garner_hi"]), int(k["theta_garner_shift"]), C.byref(h)))
+        return cls(from_ctx, to_ctx, _handle=h)
+
+    def __del__(self):
+        if self._owner is None and getattr(self, "_h", None) is not None and _lib._lib is not None:
+            _lib._lib.fhe_scaler_destroy(self._h)
+
+    def constants(self, which):
+        nf, nt = self.from_ctx.nmoduli, self.to_ctx.nmoduli
+        size = {0: nt, 1: nt, 2: nt * nf, 3: nt * nf, 4: nf, 5: nf, 6: nf, 7: nf, 8: nf, 9: 5}[which]
+        out = np.zeros(size, dtype=np.uint64)
+        check(_lib.lib().fhe_scaler_get_constants(self._h, which, _ptr(out)))
+        return out
+
+    def scale(self, polys, ntt):
+        """Scaler::scale == Poly::scale(&scaler): [..., Lfrom, N] -> [..., Lto, N]."""
+        L = _lib.lib()
+        b = self.from_ctx._batch(polys)
+        oshape = tuple(polys.shape[:-2]) + (self.to_ctx.nmoduli, self.to_ctx.degree)
+        if _is_dev(polys):
+            out = torch.zeros(oshape, dtype=polys.dtype, device=polys.device)
+            check(L.fhe_poly_scale_dev(self._h, _dptr(polys), _dptr(out), b, 1 if ntt else 0, _stream()))
+            return out
+        x = _np(polys)
+        out = np.zeros(oshape, dtype=np.uint64)
+        check(L.fhe_poly_scale(self._h, _ptr(x), _ptr(out), b, 1 if ntt else 0))
+        return out
+
+
+class Switcher(Scaler):
+    """rq::switcher::Switcher (crates/fhe-math/src/rq/switcher.rs:11-26)."""
+
+    def __init__(self, from_ctx, to_ctx):
+        h = C.c_void_p()
+        check(_lib.lib().fhe_switcher_create(from_ctx._h, to_ctx._h, C.byref(h)))
+        super().__init__(from_ctx, to_ctx, _handle=h)
+
+    def switch(self, polys, ntt=False):
+        return self.scale(polys, ntt)
+
+
+class KeySwitchingKey:
+    """bfv::KeySwitchingKey (crates/fhe/src/bfv/keys/key_switching_key.rs:22-46): c0, c1 are
+    `[ndigits, Lk, N]` NttShoup polynomials over ctx_ksk; Shoup twins are optional."""
+
+    def __init__(self, ctx_ciphertext, ctx_ksk, c0, c1, c0_shoup=None, c1_shoup=None, log_base=0):
+        self.ctx_ciphertext, self.ctx_ksk, self.log_base = ctx_ciphertext, ctx_ksk, log_base
+        L = _lib.lib()
+        h = C.c_void_p()
+        if _is_dev(c0):
+            nd = c0.shape[0]
+            check(L.fhe_ksk_create_dev(ctx_ciphertext._h, ctx_ksk._h, nd, _dptr(c0), _dptr(c1), log_base, _stream(),
+                                       C.byref(h)))
+        else:
+            a0, a1 = _np(c0), _np(c1)
+            nd = a0.shape[0]
+            s0 = _np(c0_shoup) if c0_shoup is not None else None
+            s1 = _np(c1_shoup) if c1_shoup is not None else None
+            check(L.fhe_ksk_create(ctx_ciphertext._h, ctx_ksk._h, nd, _ptr(a0), _ptr(s0) if s0 is not None else None,
+                                   _ptr(a1), _ptr(s1) if s1 is not None else None, log_base, C.byref(h)))
+        self.ndigits = nd
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and _lib._lib is not None:
+            _lib._lib.fhe_ksk_destroy(self._h)
+
+    def key_switch(self, p):
+        """KeySwitchingKey::key_switch: p [..., L, N] PowerBasis -> (c0, c1) [..., Lk, N] Ntt."""
+        L = _lib.lib()
+        b = self.ctx_ciphertext._batch(p)
+        oshape = tuple(p.shape[:-2]) + (self.ctx_ksk.nmoduli, self.ctx_ksk.degree)
+        if _is_dev(p):
+            o0 = torch.empty(oshape, dtype=p.dtype, device=p.device)
+            o1 = torch.empty_like(o0)
+            check(L.fhe_key_switch_dev(self._h, _dptr(p), _dptr(o0), _dptr(o1), b, _stream()))
+            return o0, o1
+        x = _np(p)
+        o0, o1 = np.zeros(oshape, dtype=np.uint64), np.zeros(oshape, dtype=np.uint64)
+        check(L.fhe_key_switch(self._h, _ptr(x), _ptr(o0), _ptr(o1), b))
+        return o0, o1
+
+
+class RelinearizationKey:
+    """bfv::RelinearizationKey (crates/fhe/src/bfv/keys/relinearization_key.rs:24-110)."""
+
+    def __init__(self, ksk: KeySwitchingKey):
+        if ksk.ctx_ksk.nmoduli == 1:
+            raise FheError(-17, "KeySwitchingNotSupported")
+        self.ksk = ksk
+
+    def relinearizes(self, ct3):
+        """[..., 3, L, N] Ntt -> [..., 2, L, N] Ntt."""
+        L = _lib.lib()
+        ctx = self.ksk.ctx_ciphertext
+        if ct3.shape[-3] != 3:
+            raise FheError(-13, "InvalidPolynomialCount: relinearization expects 3 parts")
+        b = ctx._batch(ct3) // 3
+        oshape = tuple(ct3.shape[:-3]) + (2, ctx.nmoduli, ctx.degree)
+        if _is_dev(ct3):
+            out = torch.empty(oshape, dtype=ct3.dtype, device=ct3.device)
+            check(L.fhe_bfv_relinearize_dev(self.ksk._h, _dptr(ct3), _dptr(out), b, _stream()))
+            return out
+        x = _np(ct3)
+        out = np.zeros(oshape, dtype=np.uint64)
+        check(L.fhe_bfv_relinearize(self.ksk._h, _ptr(x), _ptr(out), b))
+        return out
+
+
+class GaloisKey:
+    """bfv::GaloisKey (crates/fhe/src/bfv/keys/galois_key.rs:19-123)."""
+
+    def __init__(self, ksk: KeySwitchingKey, exponent: int):
+        n = ksk.ctx_ciphertext.degree
+        if (exponent % (2 * n)) & 1 == 0:
+            raise FheError(-10, "InvalidSubstitutionExponent")
+        self.ksk, self.exponent = ksk, exponent % (2 * n)
+
+    def relinearize(self, ct):
+        """[..., 2, L, N] Ntt -> same shape."""
+        L = _lib.lib()
+        ctx = self.ksk.ctx_ciphertext
+        if ct.shape[-3] != 2:
+            raise FheError(-13, "InvalidPolynomialCount: rotation expects 2 parts")
+        b = ctx._batch(ct) // 2
+        if _is_dev(ct):
+            out = torch.empty_like(ct)
+            check(L.fhe_bfv_galois_dev(self.ksk._h, self.exponent, _dptr(ct), _dptr(out), b, _stream()))
+            return out
+        x = _np(ct)
+        out = np.zeros_like(x)
+        check(L.fhe_bfv_galois(self.ksk._h, self.exponent, _ptr(x), _ptr(out), b))
+        return out
+
+
+class EvaluationKey:
+    """The rotation part of bfv::EvaluationKey (crates/fhe/src/bfv/keys/evaluation_key.rs:
+    rotates_rows :110-131, rotates_columns_by :145-170, exponent map :278-286)."""
+
+    def __init__(self, degree, galois_keys):
+        self.degree = degree
+        self.gk = {g.exponent: g for g in galois_keys}
+
+    def rotates_rows(self, ct):
+        e = 2 * self.degree - 1
+        if e not in self.gk:
+            raise FheError(-11, "EvaluationKeyError::Unsupported(RowRotation)")
+        return self.gk[e].relinearize(ct)
+
+    def rotates_columns_by(self, ct, i):
+        if not (1 <= i < self.degree // 2):
+            raise FheError(-1, "InvalidRotationStep")
+        e = pow(3, i, 2 * self.degree)
+        if e not in self.gk:
+            raise FheError(-11, "EvaluationKeyError::Unsupported(ColumnRotation)")
+        return self.gk[e].relinearize(ct)
+
+
+class BfvParameters:
+    """The device-table part of bfv::BfvParameters (crates/fhe/src/bfv/parameters.rs:560-738):
+    per-level contexts, the extended multiplication basis and per-level mul parameters."""
+
+    def __init__(self, degree, plaintext_modulus, moduli=None, moduli_sizes=None, device=0):
+        L = _lib.lib()
+        if moduli_sizes:
+            sizes = (C.c_size_t * len(moduli_sizes))(*moduli_sizes)
+            out = np.zeros(len(moduli_sizes), dtype=np.uint64)
+            check(L.fhe_generate_moduli(sizes, len(moduli_sizes), degree, _ptr(out)))
+            moduli = [int(x) for x in out]
+        m = _np(moduli)
+        h = C.c_void_p()
+        check(L.fhe_params_create(device, degree, len(m), _ptr(m), plaintext_modulus, C.byref(h)))
+        self._h = h
+        self.degree, self.plaintext, self.moduli, self.device = degree, plaintext_modulus, [int(x) for x in m], device
+        self.max_level = L.fhe_params_max_level(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and _lib._lib is not None:
+            _lib._lib.fhe_params_destroy(self._h)
+
+    def _get(self, fn, level):
+        h = C.c_void_p()
+        check(getattr(_lib.lib(), fn)(self._h, level, C.byref(h)))
+        return h
+
+    def context_at_level(self, level):
+        return Context(None, None, _handle=self._get("fhe_params_ctx", level), _owner=self)
+
+    def mul_context_at_level(self, level):
+        return Context(None, None, _handle=self._get("fhe_params_mul_ctx", level), _owner=self)
+
+    def extender(self, level):
+        return Scaler(self.context_at_level(level), self.mul_context_at_level(level),
+                      _handle=self._get("fhe_params_extender", level), _owner=self)
+
+    def down_scaler(self, level):
+        return Scaler(self.mul_context_at_level(level), self.context_at_level(level),
+                      _handle=self._get("fhe_params_down_scaler", level), _owner=self)
+
+
+class Multiplicator:
+    """bfv::Multiplicator (crates/fhe/src/bfv/ops/mul.rs:21-243)."""
+
+    def __init__(self, extender_lhs, extender_rhs, down_scaler, rk=None, mod_switch=False, _handle=None, _keep=()):
+        self._keep = (extender_lhs, extender_rhs, down_scaler, rk) + tuple(_keep)
+        if _handle is None:
+            h = C.c_void_p()
+            check(_lib.lib().fhe_mul_create(extender_lhs._h, extender_rhs._h, down_scaler._h,
+                                            rk.ksk._h if rk is not None else None, 1 if mod_switch else 0, C.byref(h)))
+            _handle = h
+        self._h = _handle
+        p, r = C.c_size_t(), C.c_size_t()
+        check(_lib.lib().fhe_mul_out_shape(self._h, C.byref(p), C.byref(r)))
+        self.out_parts, self.out_rows = p.value, r.value
+
+    @classmethod
+    def default(cls, params: BfvParameters, rk: RelinearizationKey = None, level=0, mod_switch=False):
+        """Multiplicator::default(rk) (+ enable_mod_switching); rk=None gives `&ct * &ct`."""
+        h = C.c_void_p()
+        check(_lib.lib().fhe_mul_create_default(params._h, level, rk.ksk._h if rk is not None else None,
+                                                1 if mod_switch else 0, C.byref(h)))
+        m = cls(None, None, None, rk, mod_switch, _handle=h, _keep=(params,))
+        m.base_ctx = params.context_at_level(level)
+        return m
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and _lib._lib is not None:
+            _lib._lib.fhe_mul_destroy(self._h)
+
+    def multiply(self, lhs, rhs):
+        """Multiplicator::multiply: lhs, rhs [..., 2, L, N] Ntt -> [..., parts, rows, N] Ntt."""
+        L = _lib.lib()
+        if tuple(lhs.shape) != tuple(rhs.shape) or lhs.shape[-3] != 2:
+            raise FheError(-13, "MultiplicationPolynomialCount: expected 2-part ciphertexts of equal shape")
+        b = 1
+        for d in lhs.shape[:-3]:
+            b *= d
+        oshape = tuple(lhs.shape[:-3]) + (self.out_parts, self.out_rows, lhs.shape[-1])
+        if _is_dev(lhs):
+            out = torch.empty(oshape, dtype=lhs.dtype, device=lhs.device)
+            check(L.fhe_bfv_mul_dev(self._h, _dptr(lhs), _dptr(rhs), _dptr(out), b, _stream()))
+            return out
+        x, y = _np(lhs), _np(rhs)
+        out = np.zeros(oshape, dtype=np.uint64)
+        check(L.fhe_bfv_mul(self._h, _ptr(x), _ptr(y), _ptr(out), b))
+        return out
+
+
+# ---- zq::primes (host) ---------------------------------------------------------------------
+def generate_prime(num_bits, modulo, upper_bound):
+    p = _lib.lib().fhe_generate_prime(num_bits, modulo, upper_bound)
+    return p or None
+
+
+def supports_opt(p):
+    return bool(_lib.lib().fhe_supports_opt(p))
+
+
+def is_prime(p):
+    return bool(_lib.lib().fhe_is_prime(p))
+
+
+def generate_moduli(sizes, degree):
+    arr = (C.c_size_t * len(sizes))(*sizes)
+    out = np.zeros(len(sizes), dtype=np.uint64)
+    check(_lib.lib().fhe_generate_moduli(arr, len(sizes), degree, _ptr(out)))
+    return [int(x) for x in out]
+
+
+def device_count():
+    return _lib.lib().fhe_device_count()
+
+
+# ---- profiling ---------------------------------------------------------------------------------
+def prof_enable(on=True):
+    _lib.lib().fhe_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    _lib.lib().fhe_prof_reset()
+
+
+def prof_report():
+    """{kernel name: (launches, total_ms)} from HIP events recorded on the launching stream."""
+    L = _lib.lib()
+    out = {}
+    for i in range(L.fhe_prof_count()):
+        name = C.create_string_buffer(64)
+        n, ms = C.c_uint64(), C.c_double()
+        check(L.fhe_prof_get(i, name, 64, C.byref(n), C.byref(ms)))
+        out[name.value.decode()] = (n.value, ms.value)
+    return out
+
+
+def set_chunk(chunk):
+    _lib.lib().fhe_set_chunk(chunk)

@@ -1,0 +1,797 @@
+// engine.hpp -- host runtime above the kernels: handles (contexts, scalers, keys,
+// multiplicators, parameter sets), stream-ordered workspace, launch geometry and the batched
+// pipelines (Scaler::scale, key switch, relinearise, rotate, modulus switch, ct x ct).
+// C++ because the reference's host is compiled code (Rust) and no Rust toolchain exists in
+// this image; the C ABI in fhe_hip.cpp is a thin layer over these classes.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "hostmath.hpp"
+#include "kernels.hpp"
+
+namespace fhe {
+
+// ------------------------------------------------------------------ error plumbing ----
+enum : int {
+    E_OK = 0, E_ARG = -1, E_HIP = -2, E_INVALID_MODULUS = -3, E_INVALID_DEGREE = -4, E_NTT_UNAVAILABLE = -5,
+    E_CONTEXT_MISMATCH = -6, E_DEGREE_MISMATCH = -7, E_NO_MORE_CONTEXT = -8, E_CONTEXT_NOT_REACHABLE = -9,
+    E_INVALID_SUBST = -10, E_PARAMETER_MISMATCH = -11, E_INVALID_LEVEL = -12, E_MUL_POLY_COUNT = -13,
+    E_EMPTY_MODULI = -14, E_NON_COPRIME = -15, E_NOT_ENOUGH_PRIMES = -16, E_KEYSWITCH_UNSUPPORTED = -17,
+    E_NO_DEVICE = -18
+};
+
+#define FHE_HIP_CHECK(expr)                                                                        \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            throw StatusError(E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+inline void require(bool cond, int code, const char *msg) {
+    if (!cond) throw StatusError(code, msg);
+}
+
+// ------------------------------------------------------------------------ profiling ----
+// Optional per-kernel timing with HIP events recorded on the launching stream
+// (bench.py reads these to compute the dominant kernel's achieved bytes/s live).
+class Profiler {
+public:
+    static Profiler &get() {
+        static Profiler p;
+        return p;
+    }
+    bool enabled = false;
+    struct Pending {
+        int id;
+        hipEvent_t a, b;
+    };
+    struct Entry {
+        std::string name;
+        uint64_t launches = 0;
+        double ms = 0;
+    };
+    int id_of(const char *name) {
+        for (size_t i = 0; i < entries.size(); i++)
+            if (entries[i].name == name) return (int)i;
+        entries.push_back(Entry{name, 0, 0});
+        return (int)entries.size() - 1;
+    }
+    hipEvent_t take_event() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        FHE_HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+    void begin(const char *name, hipStream_t s) {
+        cur = Pending{id_of(name), take_event(), take_event()};
+        FHE_HIP_CHECK(hipEventRecord(cur.a, s));
+    }
+    void end(hipStream_t s) {
+        FHE_HIP_CHECK(hipEventRecord(cur.b, s));
+        pending.push_back(cur);
+    }
+    void drain() {
+        for (auto &p : pending) {
+            FHE_HIP_CHECK(hipEventSynchronize(p.b));
+            float ms = 0;
+            FHE_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+            entries[p.id].launches++;
+            entries[p.id].ms += ms;
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+    void reset() {
+        drain();
+        entries.clear();
+    }
+    std::vector<Entry> entries;
+    std::mutex mu;
+
+private:
+    Pending cur{};
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+#define FHE_LAUNCH(name, kernel, grid, block, smem, stream, ...)                         \
+    do {                                                                                 \
+        Profiler &_pf = Profiler::get();                                                 \
+        if (_pf.enabled) {                                                               \
+            std::lock_guard<std::mutex> _lk(_pf.mu);                                     \
+            _pf.begin(name, stream);                                                     \
+            hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);          \
+            _pf.end(stream);                                                             \
+        } else {                                                                         \
+            hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);          \
+        }                                                                                \
+        FHE_HIP_CHECK(hipGetLastError());                                                \
+    } while (0)
+
+// --------------------------------------------------------------- device allocations ----
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { reset(); }
+    void reset() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    void alloc(size_t n) {
+        reset();
+        if (n) FHE_HIP_CHECK(hipMalloc((void **)&p, n * sizeof(T)));
+        count = n;
+    }
+    void upload(const std::vector<T> &h) {
+        alloc(h.size());
+        if (!h.empty()) FHE_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+// Grow-only workspace blocks, reused in stream order: a block released by stream S is handed
+// out again only to work enqueued on S, so no cross-stream hazard and no per-call hipMalloc.
+class Workspace {
+public:
+    static Workspace &get() {
+        static Workspace w;
+        return w;
+    }
+    void *acquire(size_t bytes, hipStream_t s) {
+        std::lock_guard<std::mutex> lk(mu);
+        Block *best = nullptr;
+        for (auto &b : blocks)
+            if (!b.in_use && b.stream == s && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+        if (!best) {
+            // free idle blocks of this stream that are too small before growing
+            for (auto &b : blocks)
+                if (!b.in_use && b.stream == s && b.ptr) {
+                    (void)hipFree(b.ptr);
+                    b.ptr = nullptr;
+                    b.bytes = 0;
+                }
+            blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const Block &b) { return !b.ptr; }),
+                         blocks.end());
+            Block nb;
+            FHE_HIP_CHECK(hipMalloc(&nb.ptr, bytes ? bytes : 8));
+            nb.bytes = bytes;
+            nb.stream = s;
+            blocks.push_back(nb);
+            best = &blocks.back();
+        }
+        best->in_use = true;
+        return best->ptr;
+    }
+    void release(void *p) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &b : blocks)
+            if (b.ptr == p) b.in_use = false;
+    }
+
+private:
+    struct Block {
+        void *ptr = nullptr;
+        size_t bytes = 0;
+        hipStream_t stream = nullptr;
+        bool in_use = false;
+    };
+    std::vector<Block> blocks;
+    std::mutex mu;
+};
+struct WsGuard {
+    void *p;
+    WsGuard(size_t bytes, hipStream_t s) : p(Workspace::get().acquire(bytes, s)) {}
+    ~WsGuard() { Workspace::get().release(p); }
+    u64 *u() const { return (u64 *)p; }
+};
+
+// ---------------------------------------------------------------------- rq::Context ----
+struct Ctx {
+    int device = -1;
+    size_t n = 0, logn = 0, L = 0;
+    std::vector<u64> moduli;
+    const Ctx *root = nullptr;  // owner of the tables (children are moduli prefixes of it)
+    // host tables (root only)
+    std::vector<NttTables> tabs;
+    std::vector<ModConsts> mods;
+    // per-context
+    std::vector<u64> inv_last, inv_last_shoup;  // M/rq/context.rs:66-73
+    std::unique_ptr<Ctx> next;                  // next_context
+    // device tables (owned by root; children alias them)
+    DevBuf<DevMod> d_mods;
+    DevBuf<k::u64x2> d_tw, d_itw, d_ninv, d_inv_last;
+
+    const DevMod *dmods() const { return root->d_mods.p; }
+    const k::u64x2 *dtw() const { return root->d_tw.p; }
+    const k::u64x2 *ditw() const { return root->d_itw.p; }
+    const k::u64x2 *dninv() const { return root->d_ninv.p; }
+    const NttTables &tab(size_t i) const { return root->tabs[i]; }
+    size_t poly_elems() const { return L * n; }
+    void need_device() const { require(device >= 0, E_NO_DEVICE, "handle was created host-only (device = -1)"); }
+    bool same_ring(const Ctx &o) const { return n == o.n && moduli == o.moduli; }
+    const Ctx *at_level(size_t i) const {
+        const Ctx *c = this;
+        for (size_t k = 0; k < i; k++) {
+            if (!c->next) return nullptr;
+            c = c->next.get();
+        }
+        return c;
+    }
+    // Context::niterations_to (M/rq/context.rs:117-141); -1 if unreachable
+    long niterations_to(const Ctx &to) const {
+        long it = 0;
+        for (const Ctx *c = this; c; c = c->next.get(), it++)
+            if (c->same_ring(to)) return it;
+        return -1;
+    }
+};
+
+inline void ctx_fill_inv_last(Ctx &c) {
+    c.inv_last.clear();
+    c.inv_last_shoup.clear();
+    const u64 q_last = c.moduli.back();
+    for (size_t i = 0; i + 1 < c.L; i++) {
+        const u64 qi = c.moduli[i];
+        const u64 inv = powmod(q_last % qi, qi - 2, qi);
+        c.inv_last.push_back(inv);
+        c.inv_last_shoup.push_back(shoup(inv, qi));
+    }
+    if (c.device >= 0) {
+        std::vector<k::u64x2> h(std::max<size_t>(c.L - 1, 1), k::u64x2{0, 0});
+        for (size_t i = 0; i + 1 < c.L; i++) h[i] = k::u64x2{c.inv_last[i], c.inv_last_shoup[i]};
+        c.d_inv_last.upload(h);
+    }
+}
+
+inline std::unique_ptr<Ctx> ctx_create(int device, size_t degree, const std::vector<u64> &moduli,
+                                       const u64 *omegas, const u64 *omegas_shoup, const u64 *zetas_inv,
+                                       const u64 *zetas_inv_shoup, const u64 *size_inv,
+                                       const u64 *size_inv_shoup) {
+    require(degree >= 8 && (degree & (degree - 1)) == 0 && degree <= 65536, E_INVALID_DEGREE,
+            "InvalidPolynomialDegree: degree must be a power of two in [8, 65536]");
+    RnsContext rns_check(moduli);  // EmptyModuli / NonCoprimeModuli / InvalidModulus
+    auto c = std::make_unique<Ctx>();
+    c->device = device;
+    c->n = degree;
+    while (((size_t)1 << c->logn) < degree) c->logn++;
+    c->L = moduli.size();
+    c->moduli = moduli;
+    c->root = c.get();
+    const bool have_tables = omegas != nullptr;
+    if (have_tables)
+        require(omegas_shoup && zetas_inv && zetas_inv_shoup && size_inv && size_inv_shoup, E_ARG,
+                "either all six NTT tables or none must be supplied");
+    for (size_t i = 0; i < c->L; i++) {
+        c->mods.push_back(make_mod_consts(moduli[i]));
+        if (have_tables) {
+            if (!supports_ntt(moduli[i], degree)) throw StatusError(E_NTT_UNAVAILABLE, "NttOperatorUnavailable");
+            NttTables t;
+            t.omegas.assign(omegas + i * degree, omegas + (i + 1) * degree);
+            t.omegas_shoup.assign(omegas_shoup + i * degree, omegas_shoup + (i + 1) * degree);
+            t.zetas_inv.assign(zetas_inv + i * degree, zetas_inv + (i + 1) * degree);
+            t.zetas_inv_shoup.assign(zetas_inv_shoup + i * degree, zetas_inv_shoup + (i + 1) * degree);
+            t.size_inv = size_inv[i];
+            t.size_inv_shoup = size_inv_shoup[i];
+            c->tabs.push_back(std::move(t));
+        } else {
+            c->tabs.push_back(make_ntt_tables(moduli[i], degree));
+        }
+    }
+    if (device >= 0) {
+        int ndev = 0;
+        FHE_HIP_CHECK(hipGetDeviceCount(&ndev));
+        require(device < ndev, E_HIP, "no such HIP device");
+        FHE_HIP_CHECK(hipSetDevice(device));
+        std::vector<DevMod> hm(c->L);
+        static_assert(sizeof(DevMod) == sizeof(ModConsts), "DevMod layout");
+        std::memcpy(hm.data(), c->mods.data(), c->L * sizeof(DevMod));
+        c->d_mods.upload(hm);
+        std::vector<k::u64x2> tw(c->L * degree), itw(c->L * degree), ninv(c->L);
+        for (size_t i = 0; i < c->L; i++) {
+            const NttTables &t = c->tabs[i];
+            for (size_t j = 0; j < degree; j++) {
+                tw[i * degree + j] = k::u64x2{t.omegas[j], t.omegas_shoup[j]};
+                itw[i * degree + j] = k::u64x2{t.zetas_inv[j], t.zetas_inv_shoup[j]};
+            }
+            ninv[i] = k::u64x2{t.size_inv, t.size_inv_shoup};
+        }
+        c->d_tw.upload(tw);
+        c->d_itw.upload(itw);
+        c->d_ninv.upload(ninv);
+    }
+    ctx_fill_inv_last(*c);
+    // next_context chain (M/rq/context.rs:75-79): prefixes sharing the root's tables
+    Ctx *parent = c.get();
+    for (size_t l = c->L - 1; l >= 1; l--) {
+        auto ch = std::make_unique<Ctx>();
+        ch->device = device;
+        ch->n = degree;
+        ch->logn = c->logn;
+        ch->L = l;
+        ch->moduli.assign(moduli.begin(), moduli.begin() + l);
+        ch->root = c.get();
+        ctx_fill_inv_last(*ch);
+        parent->next = std::move(ch);
+        parent = parent->next.get();
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------- launch helpers ----
+inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
+inline unsigned blocks_for(u64 total, unsigned threads) { return (unsigned)((total + threads - 1) / threads); }
+constexpr unsigned EW_THREADS = 256;
+
+inline unsigned ntt_threads(size_t m) { return (unsigned)std::min<size_t>(1024, std::max<size_t>(64, m / 16)); }
+
+template <class K>
+inline void allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        FHE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+// Forward / inverse NTT of `npolys * map.rows` residue rows.  N <= 16384: one LDS-resident
+// kernel.  N = 32768 / 65536: G0 global radix stages + LDS kernel on 8192-point sub-blocks.
+inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::RowMap map, size_t npolys,
+                       uint32_t prologue, hipStream_t s) {
+    if (npolys == 0 || map.rows == 0) return;
+    const uint32_t logn = (uint32_t)c.logn;
+    const unsigned rows_total = (unsigned)(npolys * map.rows);
+    if (logn <= 14) {
+        const size_t lds = k::lds_words((uint32_t)c.n) * sizeof(u64);
+        const unsigned th = ntt_threads(c.n);
+        if (!inverse) {
+            allow_big_lds(k::ntt_kernel<false>, lds);
+            FHE_LAUNCH("ntt_fwd", (k::ntt_kernel<false>), dim3(rows_total), dim3(th), lds, s, in, out, map,
+                       c.dmods(), c.dtw(), c.dninv(), logn, logn, prologue);
+        } else {
+            allow_big_lds(k::ntt_kernel<true>, lds);
+            FHE_LAUNCH("ntt_inv", (k::ntt_kernel<true>), dim3(rows_total), dim3(th), lds, s, in, out, map,
+                       c.dmods(), c.ditw(), c.dninv(), logn, logn, prologue);
+        }
+        return;
+    }
+    const uint32_t logm = 13, g0 = logn - logm, m = 1u << logm;
+    const size_t lds = k::lds_words(m) * sizeof(u64);
+    const unsigned th = ntt_threads(m);
+    const unsigned gth = 256, gblocks = rows_total * (m / gth);
+    k::RowMap inplace = map;
+    inplace.src_poly_stride = map.dst_poly_stride;
+    inplace.src_row_fixed = -1;
+    if (!inverse) {
+        if (g0 == 2)
+            FHE_LAUNCH("ntt_fwd_global", (k::ntt_global_kernel<false, 2>), dim3(gblocks), dim3(gth), 0, s, in, out,
+                       map, c.dmods(), c.dtw(), c.dninv(), logn, prologue);
+        else
+            FHE_LAUNCH("ntt_fwd_global", (k::ntt_global_kernel<false, 3>), dim3(gblocks), dim3(gth), 0, s, in, out,
+                       map, c.dmods(), c.dtw(), c.dninv(), logn, prologue);
+        allow_big_lds(k::ntt_kernel<false>, lds);
+        FHE_LAUNCH("ntt_fwd", (k::ntt_kernel<false>), dim3(rows_total << g0), dim3(th), lds, s, out, out, inplace,
+                   c.dmods(), c.dtw(), c.dninv(), logn, logm, (uint32_t)k::PRO_NONE);
+    } else {
+        allow_big_lds(k::ntt_kernel<true>, lds);
+        FHE_LAUNCH("ntt_inv", (k::ntt_kernel<true>), dim3(rows_total << g0), dim3(th), lds, s, in, out, map,
+                   c.dmods(), c.ditw(), c.dninv(), logn, logm, prologue);
+        if (g0 == 2)
+            FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 2>), dim3(gblocks), dim3(gth), 0, s, out, out,
+                       inplace, c.dmods(), c.ditw(), c.dninv(), logn, (uint32_t)k::PRO_NONE);
+        else
+            FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 3>), dim3(gblocks), dim3(gth), 0, s, out, out,
+                       inplace, c.dmods(), c.ditw(), c.dninv(), logn, (uint32_t)k::PRO_NONE);
+    }
+}
+
+// all rows of [npolys][rows_in_poly][N], modulus = row index
+inline k::RowMap full_map(const Ctx &c, size_t rows_in_poly) {
+    k::RowMap m{};
+    m.rows = (uint32_t)rows_in_poly;
+    m.row_begin = 0;
+    m.mod_offset = 0;
+    m.src_row_fixed = -1;
+    m.src_poly_stride = m.dst_poly_stride = (u64)rows_in_poly * c.n;
+    return m;
+}
+
+inline void ntt_polys(const Ctx &c, bool inverse, const u64 *in, u64 *out, size_t npolys, hipStream_t s) {
+    c.need_device();
+    launch_ntt(c, inverse, in, out, full_map(c, c.L), npolys, k::PRO_NONE, s);
+}
+
+inline void ew_op(const Ctx &c, u64 *a, const u64 *b, size_t npolys, uint32_t op, hipStream_t s) {
+    c.need_device();
+    const u64 total = (u64)npolys * c.L * c.n;
+    if (!total) return;
+    FHE_LAUNCH("ew", k::ew_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, a, b, c.dmods(),
+               (uint32_t)c.L, (uint32_t)c.logn, op, total);
+}
+
+// ----------------------------------------------------------------------- rq::Scaler ----
+struct Scaler {
+    const Ctx *from = nullptr, *to = nullptr;
+    size_t ncommon = 0;
+    ScalerConstants c;
+    DevBuf<u64> d_all;
+    k::ScalerDev dev{};
+};
+
+inline void scaler_upload(Scaler &s) {
+    const ScalerConstants &c = s.c;
+    if (s.from->device < 0) return;
+    std::vector<u64> all;
+    auto push = [&](const std::vector<u64> &v) {
+        size_t off = all.size();
+        all.insert(all.end(), v.begin(), v.end());
+        return off;
+    };
+    std::vector<u64> sign64(c.theta_omega_sign.begin(), c.theta_omega_sign.end());
+    size_t o_gamma = push(c.gamma), o_gs = push(c.gamma_shoup), o_om = push(c.omega), o_oms = push(c.omega_shoup);
+    size_t o_tol = push(c.theta_omega_lo), o_toh = push(c.theta_omega_hi), o_tos = push(sign64);
+    size_t o_tgl = push(c.theta_garner_lo), o_tgh = push(c.theta_garner_hi);
+    s.d_all.upload(all);
+    u64 *b = s.d_all.p;
+    s.dev.gamma = b + o_gamma;
+    s.dev.gamma_shoup = b + o_gs;
+    s.dev.omega = b + o_om;
+    s.dev.omega_shoup = b + o_oms;
+    s.dev.theta_omega_lo = b + o_tol;
+    s.dev.theta_omega_hi = b + o_toh;
+    s.dev.theta_omega_sign = b + o_tos;
+    s.dev.theta_garner_lo = b + o_tgl;
+    s.dev.theta_garner_hi = b + o_tgh;
+    s.dev.theta_gamma_lo = c.theta_gamma_lo;
+    s.dev.theta_gamma_hi = c.theta_gamma_hi;
+    s.dev.theta_gamma_sign = c.theta_gamma_sign ? 1 : 0;
+    s.dev.is_one = c.is_one ? 1 : 0;
+    s.dev.shift = (uint32_t)c.theta_garner_shift;
+    s.dev.nfrom = (uint32_t)c.nfrom;
+    s.dev.nto = (uint32_t)c.nto;
+    s.dev.ncommon = (uint32_t)s.ncommon;
+}
+
+// Scaler::new (M/rq/scaler.rs:27-52)
+inline std::unique_ptr<Scaler> scaler_create(const Ctx &from, const Ctx &to, const BigUint &num,
+                                             const BigUint &den) {
+    require(from.n == to.n, E_DEGREE_MISMATCH, "DegreeMismatch");
+    require(from.device == to.device, E_PARAMETER_MISMATCH, "contexts live on different devices");
+    auto s = std::make_unique<Scaler>();
+    s->from = &from;
+    s->to = &to;
+    RnsContext rf(from.moduli), rt(to.moduli);
+    s->c = make_scaler_constants(rf, rt, num, den);
+    if (s->c.is_one) {
+        size_t k = 0;
+        while (k < from.L && k < to.L && from.moduli[k] == to.moduli[k]) k++;
+        s->ncommon = k;
+    }
+    scaler_upload(*s);
+    return s;
+}
+
+// Scaler::scale (M/rq/scaler.rs:55-127) on npolys polynomials.
+inline void scale_polys(const Scaler &sc, const u64 *in, u64 *out, size_t npolys, bool repr_is_ntt, hipStream_t s) {
+    const Ctx &f = *sc.from, &t = *sc.to;
+    f.need_device();
+    if (!npolys) return;
+    const u64 in_stride = (u64)f.L * f.n, out_stride = (u64)t.L * t.n;
+    if (sc.ncommon > 0) {
+        const u64 per = (u64)sc.ncommon * f.n, total = per * npolys;
+        FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in,
+                   out, in_stride, out_stride, per, total);
+    }
+    if (sc.ncommon >= t.L) return;
+    const u64 total = (u64)npolys * f.n;
+    if (repr_is_ntt) {
+        WsGuard pb(npolys * in_stride * sizeof(u64), s);
+        launch_ntt(f, true, in, pb.u(), full_map(f, f.L), npolys, k::PRO_NONE, s);
+        FHE_LAUNCH("scale", k::scale_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, pb.u(), out,
+                   in_stride, out_stride, sc.dev, t.dmods(), (uint32_t)f.logn, total);
+        k::RowMap m = full_map(t, t.L);
+        m.rows = (uint32_t)(t.L - sc.ncommon);
+        m.row_begin = (uint32_t)sc.ncommon;
+        launch_ntt(t, false, out, out, m, npolys, k::PRO_NONE, s);
+    } else {
+        FHE_LAUNCH("scale", k::scale_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in, out,
+                   in_stride, out_stride, sc.dev, t.dmods(), (uint32_t)f.logn, total);
+    }
+}
+
+// Poly::<PowerBasis>::switch_down (M/rq/mod.rs:433-492) on npolys polynomials.
+inline void switch_down_polys(const Ctx &c, const u64 *in, u64 in_stride, u64 *out, u64 out_stride, size_t npolys,
+                              hipStream_t s) {
+    c.need_device();
+    require(c.next != nullptr, E_NO_MORE_CONTEXT, "NoMoreContext");
+    const u64 total = (u64)npolys * c.n;
+    if (!total) return;
+    FHE_LAUNCH("switch_down", k::switch_down_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in,
+               out, in_stride, out_stride, c.dmods(), c.d_inv_last.p, (uint32_t)c.L, (uint32_t)c.logn, total);
+}
+
+inline void substitute_polys(const Ctx &c, size_t exponent, const u64 *in, u64 *out, size_t npolys, bool ntt,
+                             hipStream_t s) {
+    c.need_device();
+    const size_t e = exponent % (2 * c.n);
+    require((e & 1) == 1, E_INVALID_SUBST, "InvalidSubstitutionExponent");
+    const u64 total = (u64)npolys * c.L * c.n;
+    if (!total) return;
+    const u64 stride = (u64)c.L * c.n;
+    FHE_LAUNCH("substitute", k::substitute_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in,
+               out, stride, stride, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, (uint32_t)e, ntt ? 1u : 0u, total);
+}
+
+// ------------------------------------------------------------------ KeySwitchingKey ----
+struct Ksk {
+    const Ctx *ct_ctx = nullptr, *ksk_ctx = nullptr;
+    size_t ndigits = 0, log_base = 0;
+    DevBuf<u64> c0, c0s, c1, c1s;  // [ndigits][Lk][N]
+};
+
+inline void ksk_validate(const Ctx &ct_ctx, const Ctx &ksk_ctx, size_t ndigits, size_t log_base) {
+    require(ct_ctx.n == ksk_ctx.n, E_DEGREE_MISMATCH, "DegreeMismatch");
+    require(ct_ctx.device == ksk_ctx.device, E_PARAMETER_MISMATCH, "contexts live on different devices");
+    require(ksk_ctx.niterations_to(ct_ctx) >= 0, E_CONTEXT_NOT_REACHABLE,
+            "ciphertext context is not reachable from the key context");
+    if (log_base != 0) {
+        require(ksk_ctx.L == 1 && ct_ctx.L == 1, E_PARAMETER_MISMATCH,
+                "decomposition keys need single-modulus contexts");
+        require(log_base < 63 && ndigits * log_base < 64 + log_base, E_ARG, "bad log_base / ndigits");
+    } else {
+        require(ndigits == ct_ctx.L, E_PARAMETER_MISMATCH, "ndigits must equal the ciphertext context's moduli count");
+        require(ksk_ctx.L >= 2, E_KEYSWITCH_UNSUPPORTED, "KeySwitchingNotSupported: single-modulus key without log_base");
+    }
+}
+
+template <int EPT>
+inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
+                            const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, unsigned th, size_t lds,
+                            hipStream_t s) {
+    const Ctx &kc = *k_.ksk_ctx;
+    allow_big_lds(k::ks_fused_kernel<EPT>, lds);
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<EPT>), dim3((unsigned)(npolys * kc.L)), dim3(th), lds, s, p,
+               p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p,
+               kc.dmods(), kc.dtw(), (uint32_t)kc.logn, (uint32_t)k_.ndigits, (uint32_t)kc.L,
+               (uint32_t)k_.log_base);
+}
+
+// KeySwitchingKey::key_switch (:241-320): p [npolys][L][N] PowerBasis (poly stride p_stride) ->
+// o0,o1 [npolys][Lk][N] Ntt over ksk_ctx (poly stride out_stride).  If a0/a1 are given (and the
+// key lives at the ciphertext level) the result is added to them on the fly.
+inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
+                             const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s) {
+    const Ctx &kc = *k_.ksk_ctx;
+    kc.need_device();
+    if (!npolys) return;
+    if (kc.logn <= 14) {
+        const unsigned th = ntt_threads(kc.n);
+        const size_t lds = k::lds_words((uint32_t)kc.n) * sizeof(u64);
+        const size_t ept = (kc.n + th - 1) / th;
+        switch (ept) {
+            case 1: launch_ks_fused<1>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
+            case 2: launch_ks_fused<2>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
+            case 4: launch_ks_fused<4>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
+            case 8: launch_ks_fused<8>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
+            default: launch_ks_fused<16>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
+        }
+        return;
+    }
+    // Unfused path for rows that do not fit LDS: per digit, lift + NTT into scratch, then MAC.
+    const u64 kstride = (u64)kc.L * kc.n;
+    WsGuard t(npolys * kstride * sizeof(u64), s);
+    WsGuard dig(k_.log_base ? npolys * kc.n * sizeof(u64) : 8, s);
+    const u64 total = (u64)npolys * kstride;
+    for (size_t i = 0; i < k_.ndigits; i++) {
+        k::RowMap m{};
+        m.rows = (uint32_t)kc.L;
+        m.row_begin = 0;
+        m.mod_offset = 0;
+        m.dst_poly_stride = kstride;
+        const u64 *src = p;
+        if (k_.log_base) {
+            const u64 tot1 = (u64)npolys * kc.n;
+            require(p_stride == kc.n, E_ARG, "decomposition key switch expects contiguous single-row input");
+            FHE_LAUNCH("digit", k::digit_kernel, dim3(blocks_for(tot1, EW_THREADS)), dim3(EW_THREADS), 0, s, p,
+                       dig.u(), (uint32_t)(i * k_.log_base), (uint32_t)k_.log_base, tot1);
+            src = dig.u();
+            m.src_row_fixed = 0;
+            m.src_poly_stride = kc.n;
+        } else {
+            m.src_row_fixed = (int32_t)i;
+            m.src_poly_stride = p_stride;
+        }
+        launch_ntt(kc, false, src, t.u(), m, npolys, k::PRO_REDUCE, s);
+        FHE_LAUNCH("key_switch_mac", k::ks_mac_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s,
+                   t.u(), o0, o1, out_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), (uint32_t)kc.logn,
+                   (uint32_t)kc.L, (uint32_t)i, i == 0 ? 1u : 0u, total);
+    }
+    if (a0 || a1) {
+        // out += addend, one polynomial at a time (strides may differ)
+        for (size_t i = 0; i < npolys; i++) {
+            if (a0) ew_op(kc, o0 + i * out_stride, a0 + i * a_stride, 1, k::EW_ADD, s);
+            if (a1) ew_op(kc, o1 + i * out_stride, a1 + i * a_stride, 1, k::EW_ADD, s);
+        }
+    }
+}
+
+// switch_down_to (M/rq/mod.rs:498-507) for Ntt polys living over `from`, `iters` times:
+// in [npolys][from.L][N] Ntt -> out [npolys][from.L-iters][N] Ntt
+inline void switch_down_to_ntt(const Ctx &from, size_t iters, const u64 *in, u64 *out, size_t npolys, hipStream_t s) {
+    const u64 stride = (u64)from.L * from.n;
+    WsGuard a(npolys * stride * sizeof(u64), s), b(npolys * stride * sizeof(u64), s);
+    launch_ntt(from, true, in, a.u(), full_map(from, from.L), npolys, k::PRO_NONE, s);
+    const Ctx *c = &from;
+    u64 *cur = a.u(), *nxt = b.u();
+    for (size_t i = 0; i < iters; i++) {
+        switch_down_polys(*c, cur, (u64)c->L * c->n, nxt, (u64)(c->L - 1) * c->n, npolys, s);
+        std::swap(cur, nxt);
+        c = c->next.get();
+    }
+    launch_ntt(*c, false, cur, out, full_map(*c, c->L), npolys, k::PRO_NONE, s);
+}
+
+// key switch followed by the level fix-up and "+= (a0, a1)" used by relinearise / rotate:
+// out0/out1 [npolys][Lct][N] (poly stride out_stride) = a + switch_down_to(key_switch(p), ct_ctx)
+inline void key_switch_add(const Ksk &k_, const u64 *p, u64 p_stride, const u64 *a0, const u64 *a1, u64 a_stride,
+                           u64 *out0, u64 *out1, u64 out_stride, size_t npolys, hipStream_t s) {
+    const Ctx &kc = *k_.ksk_ctx, &cc = *k_.ct_ctx;
+    const long iters = kc.niterations_to(cc);
+    if (iters == 0) {
+        key_switch_polys(k_, p, p_stride, out0, out1, out_stride, a0, a1, a_stride, npolys, s);
+        return;
+    }
+    const u64 kstride = (u64)kc.L * kc.n, cstride = (u64)cc.L * cc.n;
+    WsGuard r0(npolys * kstride * sizeof(u64), s), r1(npolys * kstride * sizeof(u64), s);
+    WsGuard d0(npolys * cstride * sizeof(u64), s), d1(npolys * cstride * sizeof(u64), s);
+    key_switch_polys(k_, p, p_stride, r0.u(), r1.u(), kstride, nullptr, nullptr, 0, npolys, s);
+    switch_down_to_ntt(kc, (size_t)iters, r0.u(), d0.u(), npolys, s);
+    switch_down_to_ntt(kc, (size_t)iters, r1.u(), d1.u(), npolys, s);
+    // out = a + d  (strided copy of a -- or of d when there is no addend -- then add)
+    const u64 per = cstride, total = per * npolys;
+    struct {
+        const u64 *a, *d;
+        u64 *o;
+    } jobs[2] = {{a0, d0.u(), out0}, {a1, d1.u(), out1}};
+    for (auto &jb : jobs) {
+        if (jb.a) {
+            FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s,
+                       jb.a, jb.o, a_stride, out_stride, per, total);
+            for (size_t i = 0; i < npolys; i++) ew_op(cc, jb.o + i * out_stride, jb.d + i * cstride, 1, k::EW_ADD, s);
+        } else {
+            FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s,
+                       jb.d, jb.o, cstride, out_stride, per, total);
+        }
+    }
+}
+
+// --------------------------------------------------------------------- Multiplicator ----
+struct Mul {
+    const Scaler *ext_lhs = nullptr, *ext_rhs = nullptr, *down = nullptr;
+    const Ksk *rk = nullptr;
+    bool mod_switch = false;
+    const Ctx *base = nullptr, *mulc = nullptr;
+    size_t out_parts() const { return rk ? 2 : 3; }
+    size_t out_rows() const { return mod_switch ? base->L - 1 : base->L; }
+};
+
+inline size_t &chunk_setting() {
+    static size_t chunk = 0;
+    return chunk;
+}
+inline size_t default_chunk(const Ctx &mulc) {
+    if (chunk_setting()) return chunk_setting();
+    // keep the per-chunk working set (~11 extended polys) inside the 256 MiB Infinity Cache
+    const size_t ext_poly_bytes = mulc.L * mulc.n * sizeof(u64);
+    size_t c = (160u << 20) / (11 * ext_poly_bytes);
+    return std::max<size_t>(1, std::min<size_t>(c, 256));
+}
+
+// Ciphertext::switch_down (F/bfv/ciphertext.rs:148-161): ct [b][nparts][L][N] Ntt -> [b][nparts][L-1][N] Ntt
+inline void bfv_switch_down(const Ctx &c, size_t nparts, const u64 *ct, u64 *out, size_t batch, hipStream_t s) {
+    c.need_device();
+    require(c.next != nullptr, E_NO_MORE_CONTEXT, "NoMoreContext");
+    switch_down_to_ntt(c, 1, ct, out, batch * nparts, s);
+}
+
+// Multiplicator::multiply (F/bfv/ops/mul.rs:165-243) on `batch` ciphertext pairs.
+inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size_t batch, hipStream_t s) {
+    const Ctx &b = *m.base, &e = *m.mulc;
+    b.need_device();
+    const size_t L = b.L, K = e.L, N = b.n;
+    const u64 PL = (u64)L * N, PK = (u64)K * N;
+    const size_t parts = m.out_parts();
+    const size_t chunk = std::min(batch, default_chunk(e));
+    if (!batch) return;
+    WsGuard ext(chunk * 4 * PK * sizeof(u64), s), ten(chunk * 3 * PK * sizeof(u64), s);
+    WsGuard d(chunk * 3 * PL * sizeof(u64), s);
+    WsGuard pre(m.mod_switch ? chunk * parts * PL * sizeof(u64) : 8, s);
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = std::min(chunk, batch - b0);
+        const u64 *l = lhs + b0 * 2 * PL, *r = rhs + b0 * 2 * PL;
+        // EXTEND (mul.rs:192-195): ext[b][0..1] = lhs parts, ext[b][2..3] = rhs parts, K rows each.
+        // Two polys of one ciphertext are `PL` apart in the input and `PK` apart in ext; the
+        // scaler works on [npolys] with fixed strides, so run it per input part.
+        for (int part = 0; part < 2; part++) {
+            // lhs part -> ext slot `part`, rhs part -> ext slot 2 + part
+            struct {
+                const Scaler *sc;
+                const u64 *src;
+                int slot;
+            } jobs[2] = {{m.ext_lhs, l + (u64)part * PL, part}, {m.ext_rhs, r + (u64)part * PL, 2 + part}};
+            for (auto &jb : jobs) {
+                const Scaler &sc = *jb.sc;
+                u64 *dst = ext.u() + (u64)jb.slot * PK;
+                // strided variant of scale_polys: input poly stride 2*PL, output poly stride 4*PK
+                const u64 in_stride = 2 * PL, out_stride = 4 * PK;
+                if (sc.ncommon > 0) {
+                    const u64 per = (u64)sc.ncommon * N, total = per * nb;
+                    FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)),
+                               dim3(EW_THREADS), 0, s, jb.src, dst, in_stride, out_stride, per, total);
+                }
+                if (sc.ncommon < K) {
+                    WsGuard pb(nb * PL * sizeof(u64), s);
+                    k::RowMap im = full_map(b, L);
+                    im.src_poly_stride = in_stride;
+                    im.dst_poly_stride = PL;
+                    launch_ntt(b, true, jb.src, pb.u(), im, nb, k::PRO_NONE, s);
+                    const u64 total = (u64)nb * N;
+                    FHE_LAUNCH("scale", k::scale_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s,
+                               pb.u(), dst, PL, out_stride, sc.dev, e.dmods(), (uint32_t)b.logn, total);
+                    k::RowMap fm = full_map(e, K);
+                    fm.rows = (uint32_t)(K - sc.ncommon);
+                    fm.row_begin = (uint32_t)sc.ncommon;
+                    fm.src_poly_stride = fm.dst_poly_stride = out_stride;
+                    launch_ntt(e, false, dst, dst, fm, nb, k::PRO_NONE, s);
+                }
+            }
+        }
+        // TENSOR (mul.rs:198-201)
+        {
+            const u64 total = (u64)nb * PK;
+            FHE_LAUNCH("tensor", k::tensor_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, ext.u(),
+                       ten.u(), e.dmods(), (uint32_t)K, (uint32_t)e.logn, total);
+        }
+        // DOWN-SCALE (mul.rs:204-206): 3 polys per ciphertext, K -> L rows
+        u64 *dst = m.mod_switch ? pre.u() : out + b0 * parts * PL;
+        if (m.rk) {
+            // c0, c1 are needed in Ntt form, c2 in PowerBasis (the reference converts c2 back with
+            // an exact inverse NTT, mul.rs:212; skipping NTT(iNTT(x)) = x keeps the same values).
+            launch_ntt(e, true, ten.u(), ten.u(), full_map(e, K), nb * 3, k::PRO_NONE, s);
+            const u64 total = (u64)nb * 3 * N;
+            FHE_LAUNCH("scale", k::scale_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, ten.u(),
+                       d.u(), PK, PL, m.down->dev, b.dmods(), (uint32_t)b.logn, total);
+            // NTT of c0, c1 (poly index 0,1 of every triple) in place in d
+            k::RowMap fm = full_map(b, L);
+            fm.src_poly_stride = fm.dst_poly_stride = PL;
+            // polys are [nb][3]; transform slots 0 and 1 of each triple: two launches with stride 3*PL
+            for (int slot = 0; slot < 2; slot++) {
+                k::RowMap sm = fm;
+                sm.src_poly_stride = sm.dst_poly_stride = 3 * PL;
+                launch_ntt(b, false, d.u() + (u64)slot * PL, d.u() + (u64)slot * PL, sm, nb, k::PRO_NONE, s);
+            }
+            // RELINEARIZE (mul.rs:211-227): (c0, c1) += key_switch(c2)
+            const Ksk &rk = *m.rk;
+            const long iters = rk.ksk_ctx->niterations_to(b);
+            (void)iters;
+            key_switch_add(rk, d.u() + 2 * PL, 3 * PL, d.u(), d.u() + PL, 3 * PL, dst, dst + PL, 2 * PL, nb, s);
+        } else {
+            // no relinearisation: all three parts are returned in Ntt form
+            scale_polys(*m.down, ten.u(), dst, nb * 3, true, s);
+        }
+        if (m.mod_switch) bfv_switch_down(b, parts, pre.u(), out + b0 * parts * (PL - N), nb, s);
+    }
+}
+
+}  // namespace fhe

@@ -1,0 +1,980 @@
+// fhe_hip.cpp -- the extern "C" boundary declared in include/fhe_hip.h.
+// Compiled as HIP for gfx950 (`hipcc -x hip --offload-arch=gfx950`, see __graft_entry__.build()).
+// Every entry point: validate -> run engine code -> translate exceptions to status codes;
+// nothing throws across the boundary.
+#include "../../include/fhe_hip.h"
+
+#include <cstdio>
+
+#include "engine.hpp"
+
+using namespace fhe;
+
+struct fhe_ctx {
+    std::unique_ptr<Ctx> owned;  // set on handles returned by fhe_ctx_create
+    const Ctx *c = nullptr;
+    std::vector<std::unique_ptr<fhe_ctx>> level_handles;  // borrowed-handle storage for fhe_ctx_at_level
+    const fhe_ctx *root_handle = nullptr;                 // set on borrowed handles
+    size_t level_in_root = 0;
+};
+struct fhe_scaler {
+    std::unique_ptr<Scaler> s;
+};
+struct fhe_ksk {
+    std::unique_ptr<Ksk> k;
+};
+struct fhe_mul {
+    std::unique_ptr<Mul> m;
+    // scalers created by fhe_mul_create_default are owned here
+    std::vector<std::unique_ptr<fhe_ctx>> ctxs;
+    std::vector<std::unique_ptr<fhe_scaler>> scalers;
+};
+struct fhe_params {
+    size_t degree = 0;
+    u64 plaintext = 0;
+    std::vector<u64> moduli;
+    std::vector<size_t> moduli_sizes;
+    std::unique_ptr<fhe_ctx> top;                       // level-0 context (+ chain)
+    std::vector<std::unique_ptr<fhe_ctx>> mul_ctx;      // per level
+    std::vector<std::unique_ptr<fhe_scaler>> extender;  // per level
+    std::vector<std::unique_ptr<fhe_scaler>> down;      // per level
+};
+
+namespace {
+thread_local std::string g_last_error;
+
+template <class F>
+fhe_status guard(F &&f) {
+    try {
+        f();
+        return FHE_OK;
+    } catch (const StatusError &e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        g_last_error = "out of host memory";
+        return FHE_E_ARG;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return FHE_E_ARG;
+    }
+}
+void need(const void *p, const char *what) {
+    if (!p) throw StatusError(FHE_E_ARG, std::string("null argument: ") + what);
+}
+std::unique_ptr<fhe_ctx> wrap_ctx(std::unique_ptr<Ctx> c) {
+    auto h = std::make_unique<fhe_ctx>();
+    h->c = c.get();
+    h->owned = std::move(c);
+    // one borrowed handle per level of the chain
+    for (const Ctx *l = h->c->next.get(); l; l = l->next.get()) {
+        auto b = std::make_unique<fhe_ctx>();
+        b->c = l;
+        b->root_handle = h.get();
+        b->level_in_root = h->level_handles.size() + 1;
+        h->level_handles.push_back(std::move(b));
+    }
+    return h;
+}
+const fhe_ctx *ctx_level_handle(const fhe_ctx *h, size_t level) {
+    if (level == 0) return h;
+    if (h->root_handle) return ctx_level_handle(h->root_handle, h->level_in_root + level);
+    if (level - 1 < h->level_handles.size()) return h->level_handles[level - 1].get();
+    return nullptr;
+}
+void set_device(const Ctx &c) {
+    if (c.device >= 0) FHE_HIP_CHECK(hipSetDevice(c.device));
+}
+
+// Host-pointer convenience: copy in, run `body(device_ptrs...)` on the null stream, copy out.
+struct HostIO {
+    std::vector<void *> bufs;
+    ~HostIO() {
+        for (void *p : bufs) (void)hipFree(p);
+    }
+    u64 *in(const u64 *h, size_t count) {
+        u64 *d = out(count);
+        if (count) FHE_HIP_CHECK(hipMemcpy(d, h, count * sizeof(u64), hipMemcpyHostToDevice));
+        return d;
+    }
+    u64 *out(size_t count) {
+        void *d = nullptr;
+        FHE_HIP_CHECK(hipMalloc(&d, std::max<size_t>(count, 1) * sizeof(u64)));
+        bufs.push_back(d);
+        return (u64 *)d;
+    }
+    void back(u64 *h, const u64 *d, size_t count) {
+        FHE_HIP_CHECK(hipStreamSynchronize(nullptr));
+        if (count) FHE_HIP_CHECK(hipMemcpy(h, d, count * sizeof(u64), hipMemcpyDeviceToHost));
+    }
+};
+
+std::unique_ptr<Ksk> make_ksk(const Ctx &ct, const Ctx &kc, size_t ndigits, size_t log_base) {
+    ksk_validate(ct, kc, ndigits, log_base);
+    kc.need_device();
+    auto k_ = std::make_unique<Ksk>();
+    k_->ct_ctx = &ct;
+    k_->ksk_ctx = &kc;
+    k_->ndigits = ndigits;
+    k_->log_base = log_base;
+    return k_;
+}
+}  // namespace
+
+extern "C" {
+
+const char *fhe_last_error(void) { return g_last_error.c_str(); }
+const char *fhe_version(void) { return "fhe.rs_amd 0.1 (gfx950)"; }
+int fhe_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ----------------------------------------------------------------------------- ctx ----
+fhe_status fhe_ctx_create(int device, size_t degree, size_t nmoduli, const uint64_t *moduli, const uint64_t *omegas,
+                          const uint64_t *omegas_shoup, const uint64_t *zetas_inv, const uint64_t *zetas_inv_shoup,
+                          const uint64_t *size_inv, const uint64_t *size_inv_shoup, fhe_ctx **out) {
+    return guard([&] {
+        need(out, "out");
+        *out = nullptr;
+        if (nmoduli == 0) throw StatusError(FHE_E_EMPTY_MODULI, "EmptyModuli");
+        need(moduli, "moduli");
+        std::vector<u64> m(moduli, moduli + nmoduli);
+        *out = wrap_ctx(ctx_create(device, degree, m, omegas, omegas_shoup, zetas_inv, zetas_inv_shoup, size_inv,
+                                   size_inv_shoup))
+                   .release();
+    });
+}
+void fhe_ctx_destroy(fhe_ctx *ctx) {
+    if (ctx && ctx->owned) delete ctx;
+}
+fhe_status fhe_ctx_at_level(const fhe_ctx *ctx, size_t level, const fhe_ctx **out) {
+    return guard([&] {
+        need(ctx, "ctx");
+        need(out, "out");
+        // a borrowed level handle can itself be asked for deeper levels: resolve on the Ctx chain
+        const Ctx *target = ctx->c->at_level(level);
+        if (!target) throw StatusError(FHE_E_INVALID_LEVEL, "InvalidContextLevel");
+        if (level == 0) {
+            *out = ctx;
+            return;
+        }
+        const fhe_ctx *h = ctx_level_handle(ctx, level);
+        if (!h) throw StatusError(FHE_E_ARG, "fhe_ctx_at_level must be called on a handle from fhe_ctx_create");
+        *out = h;
+    });
+}
+fhe_status fhe_ctx_niterations_to(const fhe_ctx *from, const fhe_ctx *to, size_t *out) {
+    return guard([&] {
+        need(from, "from");
+        need(to, "to");
+        need(out, "out");
+        long it = from->c->niterations_to(*to->c);
+        if (it < 0) throw StatusError(FHE_E_CONTEXT_NOT_REACHABLE, "ContextNotReachable");
+        *out = (size_t)it;
+    });
+}
+size_t fhe_ctx_degree(const fhe_ctx *ctx) { return ctx ? ctx->c->n : 0; }
+size_t fhe_ctx_nmoduli(const fhe_ctx *ctx) { return ctx ? ctx->c->L : 0; }
+int fhe_ctx_device(const fhe_ctx *ctx) { return ctx ? ctx->c->device : -1; }
+fhe_status fhe_ctx_moduli(const fhe_ctx *ctx, uint64_t *out) {
+    return guard([&] {
+        need(ctx, "ctx");
+        need(out, "out");
+        std::copy(ctx->c->moduli.begin(), ctx->c->moduli.end(), out);
+    });
+}
+fhe_status fhe_ctx_get_table(const fhe_ctx *ctx, int which, uint64_t *out) {
+    return guard([&] {
+        need(ctx, "ctx");
+        need(out, "out");
+        const Ctx &c = *ctx->c;
+        for (size_t i = 0; i < c.L; i++) {
+            const NttTables &t = c.tab(i);
+            switch (which) {
+                case 0: std::copy(t.omegas.begin(), t.omegas.end(), out + i * c.n); break;
+                case 1: std::copy(t.omegas_shoup.begin(), t.omegas_shoup.end(), out + i * c.n); break;
+                case 2: std::copy(t.zetas_inv.begin(), t.zetas_inv.end(), out + i * c.n); break;
+                case 3: std::copy(t.zetas_inv_shoup.begin(), t.zetas_inv_shoup.end(), out + i * c.n); break;
+                case 4: out[i] = t.size_inv; break;
+                case 5: out[i] = t.size_inv_shoup; break;
+                case 6: if (i + 1 < c.L) out[i] = c.inv_last[i]; break;
+                case 7: if (i + 1 < c.L) out[i] = c.inv_last_shoup[i]; break;
+                default: throw StatusError(FHE_E_ARG, "unknown table selector");
+            }
+        }
+    });
+}
+
+#define FHE_POLY_IO_PROLOGUE(ctxh)      \
+    need(ctxh, "ctx");                  \
+    const Ctx &c = *(ctxh)->c;          \
+    c.need_device();                    \
+    set_device(c);                      \
+    const size_t pe = c.L * c.n
+
+fhe_status fhe_ntt_forward_dev(const fhe_ctx *ctx, uint64_t *polys, size_t batch, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        if (batch) need(polys, "polys");
+        ntt_polys(c, false, polys, polys, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_ntt_backward_dev(const fhe_ctx *ctx, uint64_t *polys, size_t batch, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        if (batch) need(polys, "polys");
+        ntt_polys(c, true, polys, polys, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_ntt_forward(const fhe_ctx *ctx, uint64_t *polys, size_t batch) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch) need(polys, "polys");
+        HostIO io;
+        u64 *d = io.in(polys, batch * pe);
+        ntt_polys(c, false, d, d, batch, nullptr);
+        io.back(polys, d, batch * pe);
+    });
+}
+fhe_status fhe_ntt_backward(const fhe_ctx *ctx, uint64_t *polys, size_t batch) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch) need(polys, "polys");
+        HostIO io;
+        u64 *d = io.in(polys, batch * pe);
+        ntt_polys(c, true, d, d, batch, nullptr);
+        io.back(polys, d, batch * pe);
+    });
+}
+
+static fhe_status ew_host(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t batch, uint32_t op) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch) {
+            need(a, "a");
+            if (op != k::EW_NEG) need(b, "b");
+        }
+        HostIO io;
+        u64 *da = io.in(a, batch * pe);
+        u64 *db = op != k::EW_NEG ? io.in(b, batch * pe) : nullptr;
+        ew_op(c, da, db, batch, op, nullptr);
+        io.back(a, da, batch * pe);
+    });
+}
+static fhe_status ew_dev(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t batch, uint32_t op, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        if (batch) {
+            need(a, "a");
+            if (op != k::EW_NEG) need(b, "b");
+        }
+        ew_op(c, a, b, batch, op, as_stream(stream));
+    });
+}
+fhe_status fhe_poly_add(const fhe_ctx *c, uint64_t *a, const uint64_t *b, size_t n) { return ew_host(c, a, b, n, k::EW_ADD); }
+fhe_status fhe_poly_sub(const fhe_ctx *c, uint64_t *a, const uint64_t *b, size_t n) { return ew_host(c, a, b, n, k::EW_SUB); }
+fhe_status fhe_poly_mul(const fhe_ctx *c, uint64_t *a, const uint64_t *b, size_t n) { return ew_host(c, a, b, n, k::EW_MUL); }
+fhe_status fhe_poly_neg(const fhe_ctx *c, uint64_t *a, size_t n) { return ew_host(c, a, nullptr, n, k::EW_NEG); }
+fhe_status fhe_poly_add_dev(const fhe_ctx *c, uint64_t *a, const uint64_t *b, size_t n, void *s) { return ew_dev(c, a, b, n, k::EW_ADD, s); }
+fhe_status fhe_poly_sub_dev(const fhe_ctx *c, uint64_t *a, const uint64_t *b, size_t n, void *s) { return ew_dev(c, a, b, n, k::EW_SUB, s); }
+fhe_status fhe_poly_mul_dev(const fhe_ctx *c, uint64_t *a, const uint64_t *b, size_t n, void *s) { return ew_dev(c, a, b, n, k::EW_MUL, s); }
+fhe_status fhe_poly_neg_dev(const fhe_ctx *c, uint64_t *a, size_t n, void *s) { return ew_dev(c, a, nullptr, n, k::EW_NEG, s); }
+
+static void mul_shoup_run(const Ctx &c, u64 *a, const u64 *b, const u64 *bs, size_t batch, hipStream_t s) {
+    const u64 total = (u64)batch * c.L * c.n;
+    if (!total) return;
+    FHE_LAUNCH("mul_shoup", k::mul_shoup_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, a, b, bs,
+               c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, total);
+}
+fhe_status fhe_poly_mul_shoup_dev(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, const uint64_t *b_shoup,
+                                  size_t batch, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        if (batch) {
+            need(a, "a");
+            need(b, "b");
+            need(b_shoup, "b_shoup");
+        }
+        mul_shoup_run(c, a, b, b_shoup, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_poly_mul_shoup(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, const uint64_t *b_shoup,
+                              size_t batch) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch) {
+            need(a, "a");
+            need(b, "b");
+            need(b_shoup, "b_shoup");
+        }
+        HostIO io;
+        u64 *da = io.in(a, batch * pe), *db = io.in(b, batch * pe), *dbs = io.in(b_shoup, batch * pe);
+        mul_shoup_run(c, da, db, dbs, batch, nullptr);
+        io.back(a, da, batch * pe);
+    });
+}
+fhe_status fhe_poly_shoup(const fhe_ctx *ctx, const uint64_t *a, uint64_t *a_shoup, size_t batch) {
+    return guard([&] {
+        need(ctx, "ctx");
+        const Ctx &c = *ctx->c;
+        if (batch) {
+            need(a, "a");
+            need(a_shoup, "a_shoup");
+        }
+        // setup-time host computation (128/64-bit division), M/zq/mod.rs:195-199
+        for (size_t b = 0; b < batch; b++)
+            for (size_t r = 0; r < c.L; r++)
+                for (size_t j = 0; j < c.n; j++) {
+                    const size_t i = (b * c.L + r) * c.n + j;
+                    a_shoup[i] = shoup(a[i], c.moduli[r]);
+                }
+    });
+}
+
+fhe_status fhe_poly_substitute_dev(const fhe_ctx *ctx, size_t exponent, const uint64_t *in, uint64_t *out,
+                                   size_t batch, int repr_is_ntt, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        if (batch) {
+            need(in, "in");
+            need(out, "out");
+        }
+        if (in == out) throw StatusError(FHE_E_ARG, "substitute is not in-place");
+        substitute_polys(c, exponent, in, out, batch, repr_is_ntt != 0, as_stream(stream));
+    });
+}
+fhe_status fhe_poly_substitute(const fhe_ctx *ctx, size_t exponent, const uint64_t *in, uint64_t *out, size_t batch,
+                               int repr_is_ntt) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch) {
+            need(in, "in");
+            need(out, "out");
+        }
+        HostIO io;
+        u64 *di = io.in(in, batch * pe), *dout = io.out(batch * pe);
+        substitute_polys(c, exponent, di, dout, batch, repr_is_ntt != 0, nullptr);
+        io.back(out, dout, batch * pe);
+    });
+}
+
+fhe_status fhe_poly_switch_down_dev(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, size_t batch, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch) {
+            need(in, "in");
+            need(out, "out");
+        }
+        switch_down_polys(c, in, pe, out, pe - c.n, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_poly_switch_down(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, size_t batch) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch) {
+            need(in, "in");
+            need(out, "out");
+        }
+        if (!c.next) throw StatusError(FHE_E_NO_MORE_CONTEXT, "NoMoreContext");
+        HostIO io;
+        u64 *di = io.in(in, batch * pe), *dout = io.out(batch * (pe - c.n));
+        switch_down_polys(c, di, pe, dout, pe - c.n, batch, nullptr);
+        io.back(out, dout, batch * (pe - c.n));
+    });
+}
+
+// -------------------------------------------------------------------------- scaler ----
+fhe_status fhe_scaler_create(const fhe_ctx *from, const fhe_ctx *to, const uint64_t *numerator, size_t numerator_limbs,
+                             const uint64_t *denominator, size_t denominator_limbs, fhe_scaler **out) {
+    return guard([&] {
+        need(from, "from");
+        need(to, "to");
+        need(out, "out");
+        need(numerator, "numerator");
+        need(denominator, "denominator");
+        *out = nullptr;
+        set_device(*from->c);
+        BigUint num = BigUint::from_limbs(numerator, numerator_limbs);
+        BigUint den = BigUint::from_limbs(denominator, denominator_limbs);
+        auto h = std::make_unique<fhe_scaler>();
+        h->s = scaler_create(*from->c, *to->c, num, den);
+        *out = h.release();
+    });
+}
+fhe_status fhe_scaler_create_from_constants(const fhe_ctx *from, const fhe_ctx *to, size_t number_common_moduli,
+                                            int is_one, const uint64_t *gamma, const uint64_t *gamma_shoup,
+                                            const uint64_t *omega, const uint64_t *omega_shoup, uint64_t theta_gamma_lo,
+                                            uint64_t theta_gamma_hi, int theta_gamma_sign,
+                                            const uint64_t *theta_omega_lo, const uint64_t *theta_omega_hi,
+                                            const uint8_t *theta_omega_sign, const uint64_t *theta_garner_lo,
+                                            const uint64_t *theta_garner_hi, size_t theta_garner_shift,
+                                            fhe_scaler **out) {
+    return guard([&] {
+        need(from, "from");
+        need(to, "to");
+        need(out, "out");
+        *out = nullptr;
+        need(gamma, "gamma");
+        need(gamma_shoup, "gamma_shoup");
+        need(omega, "omega");
+        need(omega_shoup, "omega_shoup");
+        need(theta_omega_lo, "theta_omega_lo");
+        need(theta_omega_hi, "theta_omega_hi");
+        need(theta_omega_sign, "theta_omega_sign");
+        need(theta_garner_lo, "theta_garner_lo");
+        need(theta_garner_hi, "theta_garner_hi");
+        const Ctx &f = *from->c, &t = *to->c;
+        require(f.n == t.n, E_DEGREE_MISMATCH, "DegreeMismatch");
+        require(f.device == t.device, E_PARAMETER_MISMATCH, "contexts live on different devices");
+        require(theta_garner_shift >= 2 && theta_garner_shift <= 127, E_ARG, "theta_garner_shift out of range");
+        require(number_common_moduli <= std::min(f.L, t.L), E_ARG, "number_common_moduli too large");
+        set_device(f);
+        auto h = std::make_unique<fhe_scaler>();
+        h->s = std::make_unique<Scaler>();
+        Scaler &s = *h->s;
+        s.from = &f;
+        s.to = &t;
+        s.ncommon = number_common_moduli;
+        ScalerConstants &c = s.c;
+        c.nfrom = f.L;
+        c.nto = t.L;
+        c.is_one = is_one != 0;
+        c.gamma.assign(gamma, gamma + t.L);
+        c.gamma_shoup.assign(gamma_shoup, gamma_shoup + t.L);
+        c.omega.assign(omega, omega + t.L * f.L);
+        c.omega_shoup.assign(omega_shoup, omega_shoup + t.L * f.L);
+        c.theta_gamma_lo = theta_gamma_lo;
+        c.theta_gamma_hi = theta_gamma_hi;
+        c.theta_gamma_sign = theta_gamma_sign != 0;
+        c.theta_omega_lo.assign(theta_omega_lo, theta_omega_lo + f.L);
+        c.theta_omega_hi.assign(theta_omega_hi, theta_omega_hi + f.L);
+        c.theta_omega_sign.assign(theta_omega_sign, theta_omega_sign + f.L);
+        c.theta_garner_lo.assign(theta_garner_lo, theta_garner_lo + f.L);
+        c.theta_garner_hi.assign(theta_garner_hi, theta_garner_hi + f.L);
+        c.theta_garner_shift = theta_garner_shift;
+        scaler_upload(s);
+        *out = h.release();
+    });
+}
+fhe_status fhe_switcher_create(const fhe_ctx *from, const fhe_ctx *to, fhe_scaler **out) {
+    return guard([&] {
+        need(from, "from");
+        need(to, "to");
+        need(out, "out");
+        *out = nullptr;
+        set_device(*from->c);
+        RnsContext rf(from->c->moduli), rt(to->c->moduli);
+        auto h = std::make_unique<fhe_scaler>();
+        h->s = scaler_create(*from->c, *to->c, rt.product, rf.product);
+        *out = h.release();
+    });
+}
+void fhe_scaler_destroy(fhe_scaler *s) { delete s; }
+size_t fhe_scaler_number_common_moduli(const fhe_scaler *s) { return s ? s->s->ncommon : 0; }
+fhe_status fhe_scaler_get_constants(const fhe_scaler *s, int which, uint64_t *out) {
+    return guard([&] {
+        need(s, "scaler");
+        need(out, "out");
+        const ScalerConstants &c = s->s->c;
+        auto cp = [&](const std::vector<u64> &v) { std::copy(v.begin(), v.end(), out); };
+        switch (which) {
+            case 0: cp(c.gamma); break;
+            case 1: cp(c.gamma_shoup); break;
+            case 2: cp(c.omega); break;
+            case 3: cp(c.omega_shoup); break;
+            case 4: cp(c.theta_omega_lo); break;
+            case 5: cp(c.theta_omega_hi); break;
+            case 6: for (size_t i = 0; i < c.nfrom; i++) out[i] = c.theta_omega_sign[i]; break;
+            case 7: cp(c.theta_garner_lo); break;
+            case 8: cp(c.theta_garner_hi); break;
+            case 9:
+                out[0] = c.theta_gamma_lo;
+                out[1] = c.theta_gamma_hi;
+                out[2] = c.theta_gamma_sign ? 1 : 0;
+                out[3] = c.theta_garner_shift;
+                out[4] = c.is_one ? 1 : 0;
+                break;
+            default: throw StatusError(FHE_E_ARG, "unknown constant selector");
+        }
+    });
+}
+fhe_status fhe_poly_scale_dev(const fhe_scaler *s, const uint64_t *in, uint64_t *out, size_t batch, int repr_is_ntt,
+                              void *stream) {
+    return guard([&] {
+        need(s, "scaler");
+        if (batch) {
+            need(in, "in");
+            need(out, "out");
+        }
+        set_device(*s->s->from);
+        scale_polys(*s->s, in, out, batch, repr_is_ntt != 0, as_stream(stream));
+    });
+}
+fhe_status fhe_poly_scale(const fhe_scaler *s, const uint64_t *in, uint64_t *out, size_t batch, int repr_is_ntt) {
+    return guard([&] {
+        need(s, "scaler");
+        if (batch) {
+            need(in, "in");
+            need(out, "out");
+        }
+        const Scaler &sc = *s->s;
+        sc.from->need_device();
+        set_device(*sc.from);
+        HostIO io;
+        const size_t ie = sc.from->L * sc.from->n, oe = sc.to->L * sc.to->n;
+        u64 *di = io.in(in, batch * ie), *dout = io.out(batch * oe);
+        FHE_HIP_CHECK(hipMemsetAsync(dout, 0, std::max<size_t>(batch * oe, 1) * sizeof(u64), nullptr));
+        scale_polys(sc, di, dout, batch, repr_is_ntt != 0, nullptr);
+        io.back(out, dout, batch * oe);
+    });
+}
+
+// ----------------------------------------------------------------------------- ksk ----
+fhe_status fhe_ksk_create(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, size_t ndigits, const uint64_t *c0,
+                          const uint64_t *c0_shoup, const uint64_t *c1, const uint64_t *c1_shoup, size_t log_base,
+                          fhe_ksk **out) {
+    return guard([&] {
+        need(ct_ctx, "ct_ctx");
+        need(ksk_ctx, "ksk_ctx");
+        need(out, "out");
+        *out = nullptr;
+        need(c0, "c0");
+        need(c1, "c1");
+        const Ctx &kc = *ksk_ctx->c;
+        set_device(kc);
+        auto h = std::make_unique<fhe_ksk>();
+        h->k = make_ksk(*ct_ctx->c, kc, ndigits, log_base);
+        const size_t count = ndigits * kc.L * kc.n;
+        auto up = [&](DevBuf<u64> &d, const u64 *src) {
+            d.alloc(count);
+            FHE_HIP_CHECK(hipMemcpy(d.p, src, count * sizeof(u64), hipMemcpyHostToDevice));
+        };
+        auto shoup_of = [&](const u64 *src) {
+            std::vector<u64> v(count);
+            for (size_t i = 0; i < ndigits; i++)
+                for (size_t r = 0; r < kc.L; r++)
+                    for (size_t j = 0; j < kc.n; j++) {
+                        const size_t x = (i * kc.L + r) * kc.n + j;
+                        if (src[x] >= kc.moduli[r]) throw StatusError(FHE_E_ARG, "key coefficient not reduced");
+                        v[x] = shoup(src[x], kc.moduli[r]);
+                    }
+            return v;
+        };
+        up(h->k->c0, c0);
+        up(h->k->c1, c1);
+        if (c0_shoup) up(h->k->c0s, c0_shoup);
+        else {
+            auto v = shoup_of(c0);
+            up(h->k->c0s, v.data());
+        }
+        if (c1_shoup) up(h->k->c1s, c1_shoup);
+        else {
+            auto v = shoup_of(c1);
+            up(h->k->c1s, v.data());
+        }
+        *out = h.release();
+    });
+}
+fhe_status fhe_ksk_create_dev(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, size_t ndigits, const uint64_t *c0,
+                              const uint64_t *c1, size_t log_base, void *stream, fhe_ksk **out) {
+    return guard([&] {
+        need(ct_ctx, "ct_ctx");
+        need(ksk_ctx, "ksk_ctx");
+        need(out, "out");
+        *out = nullptr;
+        need(c0, "c0");
+        need(c1, "c1");
+        const Ctx &kc = *ksk_ctx->c;
+        set_device(kc);
+        auto h = std::make_unique<fhe_ksk>();
+        h->k = make_ksk(*ct_ctx->c, kc, ndigits, log_base);
+        const size_t count = ndigits * kc.L * kc.n;
+        hipStream_t s = as_stream(stream);
+        FHE_HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<u64> h0(count), h1(count), s0(count), s1(count);
+        FHE_HIP_CHECK(hipMemcpy(h0.data(), c0, count * sizeof(u64), hipMemcpyDeviceToHost));
+        FHE_HIP_CHECK(hipMemcpy(h1.data(), c1, count * sizeof(u64), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ndigits; i++)
+            for (size_t r = 0; r < kc.L; r++)
+                for (size_t j = 0; j < kc.n; j++) {
+                    const size_t x = (i * kc.L + r) * kc.n + j;
+                    s0[x] = shoup(h0[x], kc.moduli[r]);
+                    s1[x] = shoup(h1[x], kc.moduli[r]);
+                }
+        h->k->c0.upload(h0);
+        h->k->c1.upload(h1);
+        h->k->c0s.upload(s0);
+        h->k->c1s.upload(s1);
+        *out = h.release();
+    });
+}
+void fhe_ksk_destroy(fhe_ksk *k_) { delete k_; }
+
+fhe_status fhe_key_switch_dev(const fhe_ksk *k_, const uint64_t *p, uint64_t *c0_out, uint64_t *c1_out, size_t batch,
+                              void *stream) {
+    return guard([&] {
+        need(k_, "ksk");
+        if (batch) {
+            need(p, "p");
+            need(c0_out, "c0_out");
+            need(c1_out, "c1_out");
+        }
+        const Ksk &ks = *k_->k;
+        set_device(*ks.ksk_ctx);
+        key_switch_polys(ks, p, (u64)ks.ct_ctx->L * ks.ct_ctx->n, c0_out, c1_out, (u64)ks.ksk_ctx->L * ks.ksk_ctx->n,
+                         nullptr, nullptr, 0, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_key_switch(const fhe_ksk *k_, const uint64_t *p, uint64_t *c0_out, uint64_t *c1_out, size_t batch) {
+    return guard([&] {
+        need(k_, "ksk");
+        if (batch) {
+            need(p, "p");
+            need(c0_out, "c0_out");
+            need(c1_out, "c1_out");
+        }
+        const Ksk &ks = *k_->k;
+        set_device(*ks.ksk_ctx);
+        HostIO io;
+        const size_t ie = ks.ct_ctx->L * ks.ct_ctx->n, oe = ks.ksk_ctx->L * ks.ksk_ctx->n;
+        u64 *dp = io.in(p, batch * ie), *d0 = io.out(batch * oe), *d1 = io.out(batch * oe);
+        key_switch_polys(ks, dp, ie, d0, d1, oe, nullptr, nullptr, 0, batch, nullptr);
+        io.back(c0_out, d0, batch * oe);
+        io.back(c1_out, d1, batch * oe);
+    });
+}
+
+// relinearizes: ct3 [b][3][L][N] -> out [b][2][L][N]
+static void relinearize_run(const Ksk &ks, const u64 *ct3, u64 *out, size_t batch, hipStream_t s) {
+    const Ctx &cc = *ks.ct_ctx;
+    const u64 PL = (u64)cc.L * cc.n;
+    if (!batch) return;
+    WsGuard c2(batch * PL * sizeof(u64), s);
+    k::RowMap m = full_map(cc, cc.L);
+    m.src_poly_stride = 3 * PL;
+    m.dst_poly_stride = PL;
+    launch_ntt(cc, true, ct3 + 2 * PL, c2.u(), m, batch, k::PRO_NONE, s);
+    key_switch_add(ks, c2.u(), PL, ct3, ct3 + PL, 3 * PL, out, out + PL, 2 * PL, batch, s);
+}
+fhe_status fhe_bfv_relinearize_dev(const fhe_ksk *rk, const uint64_t *ct3, uint64_t *out, size_t batch, void *stream) {
+    return guard([&] {
+        need(rk, "rk");
+        if (batch) {
+            need(ct3, "ct3");
+            need(out, "out");
+        }
+        set_device(*rk->k->ksk_ctx);
+        relinearize_run(*rk->k, ct3, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_relinearize(const fhe_ksk *rk, const uint64_t *ct3, uint64_t *out, size_t batch) {
+    return guard([&] {
+        need(rk, "rk");
+        if (batch) {
+            need(ct3, "ct3");
+            need(out, "out");
+        }
+        const Ksk &ks = *rk->k;
+        set_device(*ks.ksk_ctx);
+        const size_t pe = ks.ct_ctx->L * ks.ct_ctx->n;
+        HostIO io;
+        u64 *di = io.in(ct3, batch * 3 * pe), *dout = io.out(batch * 2 * pe);
+        relinearize_run(ks, di, dout, batch, nullptr);
+        io.back(out, dout, batch * 2 * pe);
+    });
+}
+
+// GaloisKey::relinearize: ct [b][2][L][N] -> out [b][2][L][N]
+static void galois_run(const Ksk &ks, size_t exponent, const u64 *ct, u64 *out, size_t batch, hipStream_t s) {
+    const Ctx &cc = *ks.ct_ctx;
+    const u64 PL = (u64)cc.L * cc.n;
+    if (!batch) return;
+    // substitute both parts at once: sub [b][2][L][N]; c2 = PowerBasis(substitute(c1))
+    WsGuard sub(batch * 2 * PL * sizeof(u64), s), c2(batch * PL * sizeof(u64), s);
+    substitute_polys(cc, exponent, ct, sub.u(), batch * 2, true, s);
+    k::RowMap m = full_map(cc, cc.L);
+    m.src_poly_stride = 2 * PL;
+    m.dst_poly_stride = PL;
+    launch_ntt(cc, true, sub.u() + PL, c2.u(), m, batch, k::PRO_NONE, s);
+    // out0 = key_switch0 + substitute(c0) ; out1 = key_switch1   (galois_key.rs:66-79)
+    key_switch_add(ks, c2.u(), PL, sub.u(), nullptr, 2 * PL, out, out + PL, 2 * PL, batch, s);
+}
+fhe_status fhe_bfv_galois_dev(const fhe_ksk *gk, size_t exponent, const uint64_t *ct, uint64_t *out, size_t batch,
+                              void *stream) {
+    return guard([&] {
+        need(gk, "gk");
+        if (batch) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        set_device(*gk->k->ksk_ctx);
+        galois_run(*gk->k, exponent, ct, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_galois(const fhe_ksk *gk, size_t exponent, const uint64_t *ct, uint64_t *out, size_t batch) {
+    return guard([&] {
+        need(gk, "gk");
+        if (batch) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        const Ksk &ks = *gk->k;
+        set_device(*ks.ksk_ctx);
+        const size_t pe = ks.ct_ctx->L * ks.ct_ctx->n;
+        HostIO io;
+        u64 *di = io.in(ct, batch * 2 * pe), *dout = io.out(batch * 2 * pe);
+        galois_run(ks, exponent, di, dout, batch, nullptr);
+        io.back(out, dout, batch * 2 * pe);
+    });
+}
+
+fhe_status fhe_bfv_switch_down_dev(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, uint64_t *out, size_t batch,
+                                   void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        if (batch && nparts) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        bfv_switch_down(c, nparts, ct, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_switch_down(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, uint64_t *out, size_t batch) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch && nparts) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        if (!c.next) throw StatusError(FHE_E_NO_MORE_CONTEXT, "NoMoreContext");
+        HostIO io;
+        u64 *di = io.in(ct, batch * nparts * pe), *dout = io.out(batch * nparts * (pe - c.n));
+        bfv_switch_down(c, nparts, di, dout, batch, nullptr);
+        io.back(out, dout, batch * nparts * (pe - c.n));
+    });
+}
+
+// ----------------------------------------------------------------------------- mul ----
+static std::unique_ptr<Mul> make_mul(const Scaler *el, const Scaler *er, const Scaler *dn, const Ksk *rk,
+                                     bool mod_switch) {
+    require(el->from->same_ring(*er->from) && el->to->same_ring(*er->to), E_PARAMETER_MISMATCH,
+            "extenders disagree on contexts");
+    require(dn->from->same_ring(*el->to) && dn->to->same_ring(*el->from), E_PARAMETER_MISMATCH,
+            "down scaler does not invert the extenders' contexts");
+    auto m = std::make_unique<Mul>();
+    m->ext_lhs = el;
+    m->ext_rhs = er;
+    m->down = dn;
+    m->rk = rk;
+    m->mod_switch = mod_switch;
+    m->base = el->from;
+    m->mulc = el->to;
+    if (rk)  // enable_relinearization (mul.rs:141-151)
+        require(rk->ct_ctx->same_ring(*m->base), E_PARAMETER_MISMATCH,
+                "ParameterMismatch: relinearization key level != multiplicator level");
+    if (mod_switch) require(m->base->next != nullptr, E_NO_MORE_CONTEXT, "NoMoreContext");  // mul.rs:155-162
+    return m;
+}
+fhe_status fhe_mul_create(const fhe_scaler *extender_lhs, const fhe_scaler *extender_rhs, const fhe_scaler *down_scaler,
+                          const fhe_ksk *rk_or_null, int mod_switch, fhe_mul **out) {
+    return guard([&] {
+        need(extender_lhs, "extender_lhs");
+        need(extender_rhs, "extender_rhs");
+        need(down_scaler, "down_scaler");
+        need(out, "out");
+        *out = nullptr;
+        auto h = std::make_unique<fhe_mul>();
+        h->m = make_mul(extender_lhs->s.get(), extender_rhs->s.get(), down_scaler->s.get(),
+                        rk_or_null ? rk_or_null->k.get() : nullptr, mod_switch != 0);
+        *out = h.release();
+    });
+}
+void fhe_mul_destroy(fhe_mul *m) { delete m; }
+fhe_status fhe_mul_out_shape(const fhe_mul *m, size_t *parts, size_t *rows) {
+    return guard([&] {
+        need(m, "mul");
+        if (parts) *parts = m->m->out_parts();
+        if (rows) *rows = m->m->out_rows();
+    });
+}
+fhe_status fhe_bfv_mul_dev(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out, size_t batch,
+                           void *stream) {
+    return guard([&] {
+        need(m, "mul");
+        if (batch) {
+            need(lhs, "lhs");
+            need(rhs, "rhs");
+            need(out, "out");
+        }
+        set_device(*m->m->base);
+        bfv_mul(*m->m, lhs, rhs, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out, size_t batch) {
+    return guard([&] {
+        need(m, "mul");
+        if (batch) {
+            need(lhs, "lhs");
+            need(rhs, "rhs");
+            need(out, "out");
+        }
+        const Mul &mm = *m->m;
+        mm.base->need_device();
+        set_device(*mm.base);
+        const size_t ie = 2 * mm.base->L * mm.base->n, oe = mm.out_parts() * mm.out_rows() * mm.base->n;
+        HostIO io;
+        u64 *dl = io.in(lhs, batch * ie), *dr = io.in(rhs, batch * ie), *dout = io.out(batch * oe);
+        bfv_mul(mm, dl, dr, dout, batch, nullptr);
+        io.back(out, dout, batch * oe);
+    });
+}
+
+// -------------------------------------------------------------------------- params ----
+fhe_status fhe_params_create(int device, size_t degree, size_t nmoduli, const uint64_t *moduli,
+                             uint64_t plaintext_modulus, fhe_params **out) {
+    return guard([&] {
+        need(out, "out");
+        *out = nullptr;
+        if (nmoduli == 0) throw StatusError(FHE_E_EMPTY_MODULI, "EmptyModuli");
+        need(moduli, "moduli");
+        require(plaintext_modulus >= 2, E_ARG, "plaintext modulus must be >= 2");
+        auto p = std::make_unique<fhe_params>();
+        p->degree = degree;
+        p->plaintext = plaintext_modulus;
+        p->moduli.assign(moduli, moduli + nmoduli);
+        for (u64 q : p->moduli) p->moduli_sizes.push_back(64 - (size_t)__builtin_clzll(q | 1));
+        p->top = wrap_ctx(ctx_create(device, degree, p->moduli, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+        // extended basis: n+1 primes of 62 bits (parameters.rs:660-676)
+        std::vector<u64> ext = extended_basis_primes(degree, p->moduli, nmoduli + 1);
+        BigUint t(plaintext_modulus);
+        for (size_t level = 0; level < nmoduli; level++) {
+            const size_t nl = nmoduli - level;
+            size_t modulus_size = 0;
+            for (size_t i = 0; i < nl; i++) modulus_size += p->moduli_sizes[i];
+            const size_t n_moduli = (modulus_size + 60 + 61) / 62;  // div_ceil
+            std::vector<u64> mm(p->moduli.begin(), p->moduli.begin() + nl);
+            mm.insert(mm.end(), ext.begin(), ext.begin() + n_moduli);
+            auto mc = wrap_ctx(ctx_create(device, degree, mm, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+            const Ctx &base = *p->top->c->at_level(level);
+            RnsContext rb(base.moduli);
+            auto e = std::make_unique<fhe_scaler>();
+            e->s = scaler_create(base, *mc->c, BigUint(1), BigUint(1));
+            auto d = std::make_unique<fhe_scaler>();
+            d->s = scaler_create(*mc->c, base, t, rb.product);
+            p->mul_ctx.push_back(std::move(mc));
+            p->extender.push_back(std::move(e));
+            p->down.push_back(std::move(d));
+        }
+        *out = p.release();
+    });
+}
+void fhe_params_destroy(fhe_params *p) { delete p; }
+size_t fhe_params_max_level(const fhe_params *p) { return p ? p->moduli.size() - 1 : 0; }
+#define FHE_PARAMS_LEVEL_CHECK()                                                          \
+    need(p, "params");                                                                    \
+    need(out, "out");                                                                     \
+    if (level >= p->moduli.size()) throw StatusError(FHE_E_INVALID_LEVEL, "InvalidLevel")
+fhe_status fhe_params_ctx(const fhe_params *p, size_t level, const fhe_ctx **out) {
+    return guard([&] {
+        FHE_PARAMS_LEVEL_CHECK();
+        *out = ctx_level_handle(p->top.get(), level);
+    });
+}
+fhe_status fhe_params_mul_ctx(const fhe_params *p, size_t level, const fhe_ctx **out) {
+    return guard([&] {
+        FHE_PARAMS_LEVEL_CHECK();
+        *out = p->mul_ctx[level].get();
+    });
+}
+fhe_status fhe_params_extender(const fhe_params *p, size_t level, const fhe_scaler **out) {
+    return guard([&] {
+        FHE_PARAMS_LEVEL_CHECK();
+        *out = p->extender[level].get();
+    });
+}
+fhe_status fhe_params_down_scaler(const fhe_params *p, size_t level, const fhe_scaler **out) {
+    return guard([&] {
+        FHE_PARAMS_LEVEL_CHECK();
+        *out = p->down[level].get();
+    });
+}
+fhe_status fhe_mul_create_default(const fhe_params *p, size_t level, const fhe_ksk *rk_or_null, int mod_switch,
+                                  fhe_mul **out) {
+    return guard([&] {
+        FHE_PARAMS_LEVEL_CHECK();
+        *out = nullptr;
+        // Multiplicator::default (mul.rs:101-138) derives the same extended basis as
+        // BfvParameters::build does for this level, so the per-level scalers are reused.
+        auto h = std::make_unique<fhe_mul>();
+        h->m = make_mul(p->extender[level]->s.get(), p->extender[level]->s.get(), p->down[level]->s.get(),
+                        rk_or_null ? rk_or_null->k.get() : nullptr, mod_switch != 0);
+        *out = h.release();
+    });
+}
+
+// --------------------------------------------------------------------------- primes ----
+uint64_t fhe_generate_prime(size_t num_bits, uint64_t modulo, uint64_t upper_bound) {
+    return generate_prime(num_bits, modulo, upper_bound);
+}
+int fhe_supports_opt(uint64_t p) { return supports_opt(p) ? 1 : 0; }
+int fhe_is_prime(uint64_t p) { return is_prime_u64(p) ? 1 : 0; }
+fhe_status fhe_generate_moduli(const size_t *sizes, size_t count, size_t degree, uint64_t *out) {
+    return guard([&] {
+        need(sizes, "sizes");
+        need(out, "out");
+        std::vector<size_t> sz(sizes, sizes + count);
+        auto m = generate_moduli(sz, degree);
+        std::copy(m.begin(), m.end(), out);
+    });
+}
+
+// ---------------------------------------------------------------------- bench / test ----
+fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0, uint64_t part0, size_t nparts,
+                                 uint64_t *out, size_t batch, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        const u64 total = (u64)batch * nparts * pe;
+        if (!total) return;
+        need(out, "out");
+        FHE_LAUNCH("synth", k::synth_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0,
+                   as_stream(stream), out, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, (uint32_t)nparts, seed, ct0,
+                   part0, total);
+    });
+}
+void fhe_set_chunk(size_t chunk) { chunk_setting() = chunk; }
+size_t fhe_get_chunk(void) { return chunk_setting(); }
+void fhe_prof_enable(int on) { Profiler::get().enabled = on != 0; }
+void fhe_prof_reset(void) {
+    try {
+        Profiler::get().reset();
+    } catch (...) {
+    }
+}
+size_t fhe_prof_count(void) {
+    try {
+        Profiler::get().drain();
+    } catch (...) {
+    }
+    return Profiler::get().entries.size();
+}
+fhe_status fhe_prof_get(size_t index, char *name, size_t name_cap, uint64_t *launches, double *total_ms) {
+    return guard([&] {
+        Profiler &p = Profiler::get();
+        p.drain();
+        if (index >= p.entries.size()) throw StatusError(FHE_E_ARG, "profile index out of range");
+        const auto &e = p.entries[index];
+        if (name && name_cap) std::snprintf(name, name_cap, "%s", e.name.c_str());
+        if (launches) *launches = e.launches;
+        if (total_ms) *total_ms = e.ms;
+    });
+}
+
+}  // extern "C"

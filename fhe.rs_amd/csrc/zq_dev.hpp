@@ -1,0 +1,175 @@
+// zq_dev.hpp -- 64-bit modular arithmetic for the kernels (moduli < 2^62).
+//
+// Value semantics follow fhe_math::zq::Modulus (M/zq/mod.rs): Shoup multiplication for every
+// constant operand (lazy_mul_shoup :224-234), lazy [0,2p)/[0,4p) ranges inside the NTT
+// butterflies (M/ntt/native.rs:256-300) and canonical [0,p) at every kernel boundary.  Only
+// canonical values cross the C ABI, and a canonical residue is a mathematical function of the
+// inputs, so any exact reduction gives bit-identical outputs; the single-word Barrett below
+// replaces the reference's 128-bit-ratio Barrett (:693-707) / NFLlib "opt" path (:730-740)
+// at 11 instead of ~18 32-bit multiplies and works for every modulus (no supports_opt split).
+//
+// There is no 64x64->128 multiplier on CDNA4: `__umul64hi` lowers to four v_mad_u64_u32 and
+// a low 64-bit product to one v_mad_u64_u32 + two v_mul_lo_u32, so a Shoup modmul costs ten
+// 32-bit multiplies.  Integer multiply issue, not HBM, bounds these kernels.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define FHE_HD __host__ __device__ __forceinline__
+#else
+#define FHE_HD inline
+#endif
+
+namespace fhe {
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128_t;
+
+struct DevMod {  // layout == hostmath.hpp ModConsts
+    u64 p, p2, mu, brt_hi, brt_lo;
+    uint32_t k, pad;
+};
+
+FHE_HD u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((u128_t)a * b) >> 64);
+#endif
+}
+
+// x in [0, 2m) -> [0, m)
+FHE_HD u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
+
+// M/zq/mod.rs:224-234: any a < 2^64, b < p, bs = floor(b * 2^64 / p); result in [0, 2p).
+FHE_HD u64 mul_shoup_lazy(u64 a, u64 b, u64 bs, u64 p) {
+    u64 q = mulhi64(a, bs);
+    return a * b - q * p;
+}
+FHE_HD u64 mul_shoup(u64 a, u64 b, u64 bs, u64 p) { return csub(mul_shoup_lazy(a, b, bs, p), p); }
+
+// Barrett reduction of x = hi:lo < 2^(2k) (e.g. a product of two residues) to [0, p).
+// q = floor(floor(x / 2^(k-1)) * floor(2^(2k)/p) / 2^(k+1)) underestimates floor(x/p) by <= 2.
+FHE_HD u64 barrett_reduce_wide(u64 hi, u64 lo, const DevMod &m) {
+    const uint32_t s = m.k - 1;
+    u64 xs = (s == 0) ? lo : ((lo >> s) | (hi << (64 - s)));  // x >> (k-1), < 2^(k+1)
+    u64 q = mulhi64(xs, m.mu);
+    u64 r = lo - q * m.p;  // < 3p < 2^64
+    r = csub(r, m.p2);
+    return csub(r, m.p);
+}
+FHE_HD u64 mul_mod(u64 a, u64 b, const DevMod &m) {  // a, b < p
+    u64 lo = a * b, hi = mulhi64(a, b);
+    return barrett_reduce_wide(hi, lo, m);
+}
+
+// Reduction of an arbitrary 64-bit value to [0, p): q = floor(a * floor(2^64/p) / 2^64).
+// floor(2^64/p) is brt_hi when p > 1 (M/zq/mod.rs:712-723 keeps the low word too; dropping it
+// costs at most one extra conditional subtraction).
+FHE_HD u64 reduce_u64(u64 a, const DevMod &m) {
+    u64 q = mulhi64(a, m.brt_hi);
+    u64 r = a - q * m.p;  // < 3p
+    r = csub(r, m.p2);
+    return csub(r, m.p);
+}
+
+// Full 128-bit reduction, M/zq/mod.rs:693-707 (needed only for the scaler's v and w words).
+FHE_HD u64 reduce_u128(u64 hi, u64 lo, const DevMod &m) {
+    u64 p_lo_lo = mulhi64(lo, m.brt_lo);
+    // (lo*brt_hi + hi*brt_lo + p_lo_lo) >> 64, with 128-bit carries
+    u64 a0 = lo * m.brt_hi, a1 = mulhi64(lo, m.brt_hi);
+    u64 b0 = hi * m.brt_lo, b1 = mulhi64(hi, m.brt_lo);
+    u64 s0 = a0 + b0;
+    u64 c0 = s0 < a0;
+    u64 s0b = s0 + p_lo_lo;
+    u64 c1 = s0b < s0;
+    u64 q = a1 + b1 + c0 + c1 + hi * m.brt_hi;
+    u64 r = lo - q * m.p;  // < 2p
+    return csub(r, m.p);
+}
+
+FHE_HD u64 add_mod(u64 a, u64 b, u64 p) { return csub(a + b, p); }
+FHE_HD u64 sub_mod(u64 a, u64 b, u64 p) { return csub(a + p - b, p); }
+FHE_HD u64 neg_mod(u64 a, u64 p) { return csub(p - a, p); }
+
+// Harvey lazy butterflies, M/ntt/native.rs:256-269 / 288-300.
+FHE_HD void fwd_butterfly(u64 &x, u64 &y, u64 w, u64 ws, u64 p, u64 p2) {
+    x = csub(x, p2);
+    u64 t = mul_shoup_lazy(y, w, ws, p);
+    y = x + p2 - t;
+    x = x + t;
+}
+FHE_HD void inv_butterfly(u64 &x, u64 &y, u64 z, u64 zs, u64 p, u64 p2) {
+    u64 t = x;
+    x = csub(y + t, p2);
+    y = mul_shoup_lazy(p2 + t - y, z, zs, p);
+}
+
+FHE_HD u64 splitmix64(u64 x) {
+    u64 z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// 256-bit wrap-around accumulator == ethnum::U256 as used by RnsScaler::scale
+// (M/rns/scaler.rs:260-313).
+struct U256 {
+    u64 w0, w1, w2, w3;
+};
+// acc +/-= r * (lo | hi << 64)   (mod 2^256)
+FHE_HD void u256_mac_64x128(U256 &acc, u64 r, u64 lo, u64 hi, bool negate) {
+    u64 p0l = r * lo, p0h = mulhi64(r, lo);
+    u64 p1l = r * hi, p1h = mulhi64(r, hi);
+    u64 t0 = p0l;
+    u64 t1 = p0h + p1l;
+    u64 c = t1 < p0h;
+    u64 t2 = p1h + c;
+    if (!negate) {
+        u64 s0 = acc.w0 + t0;
+        u64 c0 = s0 < t0;
+        u64 s1 = acc.w1 + t1;
+        u64 c1 = s1 < t1;
+        s1 += c0;
+        c1 += s1 < c0;
+        u64 s2 = acc.w2 + t2;
+        u64 c2 = s2 < t2;
+        s2 += c1;
+        c2 += s2 < c1;
+        acc.w0 = s0;
+        acc.w1 = s1;
+        acc.w2 = s2;
+        acc.w3 += c2;
+    } else {
+        u64 d0 = acc.w0 - t0;
+        u64 b0 = acc.w0 < t0;
+        u64 d1 = acc.w1 - t1;
+        u64 b1 = acc.w1 < t1;
+        u64 d1b = d1 - b0;
+        b1 += d1 < b0;
+        u64 d2 = acc.w2 - t2;
+        u64 b2 = acc.w2 < t2;
+        u64 d2b = d2 - b1;
+        b2 += d2 < b1;
+        acc.w0 = d0;
+        acc.w1 = d1b;
+        acc.w2 = d2b;
+        acc.w3 -= b2;
+    }
+}
+// bits [s, s+128) of a, for 1 <= s <= 127
+FHE_HD void u256_shr_lo128(const U256 &a, uint32_t s, u64 &lo, u64 &hi) {
+    if (s < 64) {
+        lo = (a.w0 >> s) | (a.w1 << (64 - s));
+        hi = (a.w1 >> s) | (a.w2 << (64 - s));
+    } else if (s == 64) {
+        lo = a.w1;
+        hi = a.w2;
+    } else {
+        uint32_t t = s - 64;
+        lo = (a.w1 >> t) | (a.w2 << (64 - t));
+        hi = (a.w2 >> t) | (a.w3 << (64 - t));
+    }
+}
+
+}  // namespace fhe

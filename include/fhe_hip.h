@@ -1,0 +1,251 @@
+/* fhe_hip.h -- C ABI of the MI355X-native RNS polynomial engine for fhe.rs' BFV hot path.
+ *
+ * This is the drop-in boundary: the entry points a `hip` cargo feature of fhe-math / fhe
+ * would bind (see INTEGRATION.md for the Rust `extern "C"` block and the call-site patches).
+ * fhe.rs has no FFI of its own; each entry point cites the Rust item it replaces
+ * (paths relative to the reference repo: M/ = crates/fhe-math/src, F/ = crates/fhe/src).
+ *
+ * Conventions
+ *  - All coefficient buffers are caller-owned, contiguous row-major u64 `[batch][...][L][N]`,
+ *    exactly `fhe_math::rq::Poly`'s `Array2<u64>` layout (M/rq/mod.rs:126-133, 189-204) with
+ *    outer batch dimensions.  Inputs and outputs are canonical residues in [0, q_i).
+ *  - Plain entry points take HOST pointers and are synchronous.  `_dev` twins take DEVICE
+ *    pointers plus a `hipStream_t` (passed as `void*`) and are stream-ordered.
+ *  - Handles are opaque, immutable after creation and may be shared by concurrent callers
+ *    working on different buffers (matches `Arc<Context>`, M/rq/context.rs:8-19).
+ *  - Every function returns 0 (FHE_OK) or a negative `fhe_status`; nothing throws or aborts
+ *    across the boundary.  `fhe_last_error()` gives a thread-local message.
+ *  - Results are bit-identical to the reference CPU path on the same inputs and tables.
+ */
+#ifndef FHE_HIP_H
+#define FHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t fhe_status;
+
+/* Status codes: 1:1 with the `Result` variants used on the path
+ * (M/errors.rs:12-118, F/errors.rs:18-70) plus runtime/argument errors. */
+enum {
+    FHE_OK = 0,
+    FHE_E_ARG = -1,                           /* null pointer, zero size, bad flag               */
+    FHE_E_HIP = -2,                           /* HIP runtime error (message in fhe_last_error)   */
+    FHE_E_INVALID_MODULUS = -3,               /* Error::InvalidModulus                            */
+    FHE_E_INVALID_DEGREE = -4,                /* Error::InvalidPolynomialDegree                   */
+    FHE_E_NTT_UNAVAILABLE = -5,               /* Error::NttOperatorUnavailable                    */
+    FHE_E_CONTEXT_MISMATCH = -6,              /* Error::PolynomialContextMismatch                 */
+    FHE_E_DEGREE_MISMATCH = -7,               /* Error::DegreeMismatch                            */
+    FHE_E_NO_MORE_CONTEXT = -8,               /* Error::NoMoreContext                             */
+    FHE_E_CONTEXT_NOT_REACHABLE = -9,         /* Error::ContextNotReachable                       */
+    FHE_E_INVALID_SUBSTITUTION_EXPONENT = -10,/* Error::InvalidSubstitutionExponent               */
+    FHE_E_PARAMETER_MISMATCH = -11,           /* fhe::Error::ParameterMismatch                    */
+    FHE_E_INVALID_LEVEL = -12,                /* fhe::Error::InvalidLevel / InvalidContextLevel   */
+    FHE_E_MUL_POLY_COUNT = -13,               /* CiphertextError::MultiplicationPolynomialCount   */
+    FHE_E_EMPTY_MODULI = -14,                 /* Error::EmptyModuli                               */
+    FHE_E_NON_COPRIME = -15,                  /* Error::NonCoprimeModuli                          */
+    FHE_E_NOT_ENOUGH_PRIMES = -16,            /* ParametersError::NotEnoughPrimes                 */
+    FHE_E_KEYSWITCH_UNSUPPORTED = -17,        /* EvaluationKeyError::KeySwitchingNotSupported     */
+    FHE_E_NO_DEVICE = -18                     /* compute call on a host-only (device = -1) handle */
+};
+
+typedef struct fhe_ctx fhe_ctx;       /* == rq::Context on one device   (M/rq/context.rs:9-19)        */
+typedef struct fhe_scaler fhe_scaler; /* == rq::scaler::Scaler          (M/rq/scaler.rs:18-23)        */
+typedef struct fhe_ksk fhe_ksk;       /* == bfv::KeySwitchingKey        (F/bfv/keys/key_switching_key.rs:22-46) */
+typedef struct fhe_mul fhe_mul;       /* == bfv::Multiplicator          (F/bfv/ops/mul.rs:21-32)      */
+typedef struct fhe_params fhe_params; /* == bfv::BfvParameters' level tables (F/bfv/parameters.rs:83-117) */
+
+const char *fhe_last_error(void);
+const char *fhe_version(void);
+/* Number of visible HIP devices (0 without a GPU).  Never fails. */
+int fhe_device_count(void);
+
+/* ------------------------------------------------------------------ rq::Context ---- */
+/* Context::new (M/rq/context.rs:42-92).  `device` >= 0 uploads tables to that GPU; -1 builds
+ * a host-only handle (setup / introspection, no compute).  Tables (M/ntt/native.rs:16-26,
+ * each `[nmoduli][degree]`, size_inv* `[nmoduli]`) are what the Rust host already holds in
+ * its NttOperators; pass all NULL to let the engine derive its own primitive roots
+ * (psi = g^((p-1)/2N) for the smallest g >= 2 that is a primitive 2N-th root).
+ * The whole `next_context` chain (moduli prefixes) is built eagerly. */
+fhe_status fhe_ctx_create(int device, size_t degree, size_t nmoduli, const uint64_t *moduli,
+                          const uint64_t *omegas, const uint64_t *omegas_shoup,
+                          const uint64_t *zetas_inv, const uint64_t *zetas_inv_shoup,
+                          const uint64_t *size_inv, const uint64_t *size_inv_shoup, fhe_ctx **out);
+void fhe_ctx_destroy(fhe_ctx *ctx);
+/* Context::context_at_level (M/rq/context.rs:143-156): borrowed handle owned by `ctx`. */
+fhe_status fhe_ctx_at_level(const fhe_ctx *ctx, size_t level, const fhe_ctx **out);
+/* Context::niterations_to (M/rq/context.rs:117-141). */
+fhe_status fhe_ctx_niterations_to(const fhe_ctx *from, const fhe_ctx *to, size_t *out);
+size_t fhe_ctx_degree(const fhe_ctx *ctx);
+size_t fhe_ctx_nmoduli(const fhe_ctx *ctx);
+int fhe_ctx_device(const fhe_ctx *ctx);
+fhe_status fhe_ctx_moduli(const fhe_ctx *ctx, uint64_t *out /* [nmoduli] */);
+/* Introspection (tests / Rust host cross-check): which: 0 omegas, 1 omegas_shoup, 2 zetas_inv,
+ * 3 zetas_inv_shoup (each [nmoduli][degree]); 4 size_inv, 5 size_inv_shoup (each [nmoduli]);
+ * 6 inv_last_qi_mod_qj, 7 its Shoup twin (each [nmoduli-1], M/rq/context.rs:66-73). */
+fhe_status fhe_ctx_get_table(const fhe_ctx *ctx, int which, uint64_t *out);
+
+/* NttOperator::{forward,backward} via Poly::{ntt_forward,ntt_backward} (M/rq/mod.rs:335-354):
+ * `polys` is [batch][L][N], transformed in place, canonical outputs. */
+fhe_status fhe_ntt_forward(const fhe_ctx *ctx, uint64_t *polys, size_t batch);
+fhe_status fhe_ntt_backward(const fhe_ctx *ctx, uint64_t *polys, size_t batch);
+fhe_status fhe_ntt_forward_dev(const fhe_ctx *ctx, uint64_t *polys, size_t batch, void *stream);
+fhe_status fhe_ntt_backward_dev(const fhe_ctx *ctx, uint64_t *polys, size_t batch, void *stream);
+
+/* AddAssign / SubAssign / MulAssign<&Poly<Ntt>> / Neg (M/rq/ops.rs:10-206, 354-418): a op= b. */
+fhe_status fhe_poly_add(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t batch);
+fhe_status fhe_poly_sub(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t batch);
+fhe_status fhe_poly_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t batch);
+fhe_status fhe_poly_neg(const fhe_ctx *ctx, uint64_t *a, size_t batch);
+/* MulAssign<&Poly<NttShoup>> (M/rq/ops.rs:208-245); Poly::compute_coefficients_shoup (M/rq/mod.rs:244-258). */
+fhe_status fhe_poly_mul_shoup(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, const uint64_t *b_shoup,
+                              size_t batch);
+fhe_status fhe_poly_shoup(const fhe_ctx *ctx, const uint64_t *a, uint64_t *a_shoup, size_t batch);
+fhe_status fhe_poly_add_dev(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t batch, void *stream);
+fhe_status fhe_poly_sub_dev(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t batch, void *stream);
+fhe_status fhe_poly_mul_dev(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t batch, void *stream);
+fhe_status fhe_poly_neg_dev(const fhe_ctx *ctx, uint64_t *a, size_t batch, void *stream);
+fhe_status fhe_poly_mul_shoup_dev(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, const uint64_t *b_shoup,
+                                  size_t batch, void *stream);
+
+/* Poly::substitute (M/rq/mod.rs:360-412) with SubstitutionExponent::new (M/rq/mod.rs:99-121).
+ * repr_is_ntt != 0: Ntt-domain permutation; 0: PowerBasis signed scatter.  in != out. */
+fhe_status fhe_poly_substitute(const fhe_ctx *ctx, size_t exponent, const uint64_t *in, uint64_t *out,
+                               size_t batch, int repr_is_ntt);
+fhe_status fhe_poly_substitute_dev(const fhe_ctx *ctx, size_t exponent, const uint64_t *in, uint64_t *out,
+                                   size_t batch, int repr_is_ntt, void *stream);
+
+/* Poly::<PowerBasis>::switch_down (M/rq/mod.rs:433-492): in [batch][L][N] -> out [batch][L-1][N]. */
+fhe_status fhe_poly_switch_down(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, size_t batch);
+fhe_status fhe_poly_switch_down_dev(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, size_t batch,
+                                    void *stream);
+
+/* ------------------------------------------------------------------ rq::Scaler ---- */
+/* Scaler::new (M/rq/scaler.rs:27-52) + RnsScaler::new (M/rns/scaler.rs:79-175): the engine
+ * derives gamma/omega/theta with its own big-integer code from the ScalingFactor
+ * numerator/denominator, given as little-endian u64 limbs (ScalingFactor::new,
+ * M/rns/scaler.rs:26-36; numerator == denominator <=> is_one). */
+fhe_status fhe_scaler_create(const fhe_ctx *from, const fhe_ctx *to, const uint64_t *numerator,
+                             size_t numerator_limbs, const uint64_t *denominator, size_t denominator_limbs,
+                             fhe_scaler **out);
+/* Same, but every RnsScaler field (M/rns/scaler.rs:52-72) is supplied by the Rust host. */
+fhe_status fhe_scaler_create_from_constants(
+    const fhe_ctx *from, const fhe_ctx *to, size_t number_common_moduli, int is_one,
+    const uint64_t *gamma, const uint64_t *gamma_shoup,   /* [to]       */
+    const uint64_t *omega, const uint64_t *omega_shoup,   /* [to][from] */
+    uint64_t theta_gamma_lo, uint64_t theta_gamma_hi, int theta_gamma_sign,
+    const uint64_t *theta_omega_lo, const uint64_t *theta_omega_hi, const uint8_t *theta_omega_sign, /* [from] */
+    const uint64_t *theta_garner_lo, const uint64_t *theta_garner_hi, size_t theta_garner_shift,     /* [from] */
+    fhe_scaler **out);
+/* Switcher::new (M/rq/switcher.rs:17-22): factor to.modulus / from.modulus. */
+fhe_status fhe_switcher_create(const fhe_ctx *from, const fhe_ctx *to, fhe_scaler **out);
+void fhe_scaler_destroy(fhe_scaler *s);
+size_t fhe_scaler_number_common_moduli(const fhe_scaler *s);
+/* Introspection: which: 0 gamma, 1 gamma_shoup ([to]); 2 omega, 3 omega_shoup ([to][from]);
+ * 4 theta_omega_lo, 5 theta_omega_hi, 6 theta_omega_sign, 7 theta_garner_lo, 8 theta_garner_hi ([from]);
+ * 9 {theta_gamma_lo, theta_gamma_hi, theta_gamma_sign, theta_garner_shift, is_one} ([5]). */
+fhe_status fhe_scaler_get_constants(const fhe_scaler *s, int which, uint64_t *out);
+/* Scaler::scale (M/rq/scaler.rs:55-127) == Poly::scale / Poly::switch (M/rq/mod.rs:660-680):
+ * in [batch][from.L][N] -> out [batch][to.L][N]; repr_is_ntt selects Ntt vs PowerBasis. */
+fhe_status fhe_poly_scale(const fhe_scaler *s, const uint64_t *in, uint64_t *out, size_t batch, int repr_is_ntt);
+fhe_status fhe_poly_scale_dev(const fhe_scaler *s, const uint64_t *in, uint64_t *out, size_t batch,
+                              int repr_is_ntt, void *stream);
+
+/* ------------------------------------------------------------ KeySwitchingKey ---- */
+/* KeySwitchingKey{c0,c1: Box<[Poly<NttShoup>]>, ctx_ciphertext, ctx_ksk, log_base}
+ * (F/bfv/keys/key_switching_key.rs:22-46).  c0/c1: [ndigits][Lk][N]; Shoup twins may be NULL
+ * (then computed as floor(c * 2^64 / q), M/zq/mod.rs:195-199).  log_base != 0 selects the
+ * single-modulus decomposition path (:323-362); otherwise ndigits must equal ct_ctx's L. */
+fhe_status fhe_ksk_create(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, size_t ndigits, const uint64_t *c0,
+                          const uint64_t *c0_shoup, const uint64_t *c1, const uint64_t *c1_shoup,
+                          size_t log_base, fhe_ksk **out);
+/* Same with key polynomials already resident on the device (copied device-to-device). */
+fhe_status fhe_ksk_create_dev(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, size_t ndigits, const uint64_t *c0,
+                              const uint64_t *c1, size_t log_base, void *stream, fhe_ksk **out);
+void fhe_ksk_destroy(fhe_ksk *k);
+/* KeySwitchingKey::key_switch / key_switch_assign (:241-320): p [batch][L][N] PowerBasis over
+ * ct_ctx -> c0_out, c1_out [batch][Lk][N] Ntt over ksk_ctx. */
+fhe_status fhe_key_switch(const fhe_ksk *k, const uint64_t *p, uint64_t *c0_out, uint64_t *c1_out, size_t batch);
+fhe_status fhe_key_switch_dev(const fhe_ksk *k, const uint64_t *p, uint64_t *c0_out, uint64_t *c1_out,
+                              size_t batch, void *stream);
+/* RelinearizationKey::relinearizes (F/bfv/keys/relinearization_key.rs:69-102):
+ * ct3 [batch][3][L][N] Ntt -> out [batch][2][L][N] Ntt (switch_down_to when the key level is higher). */
+fhe_status fhe_bfv_relinearize(const fhe_ksk *rk, const uint64_t *ct3, uint64_t *out, size_t batch);
+fhe_status fhe_bfv_relinearize_dev(const fhe_ksk *rk, const uint64_t *ct3, uint64_t *out, size_t batch,
+                                   void *stream);
+/* GaloisKey::relinearize / relinearize_into (F/bfv/keys/galois_key.rs:63-123), i.e.
+ * EvaluationKey::rotates_columns_by (exponent 3^i mod 2N) / rotates_rows (exponent 2N-1)
+ * (F/bfv/keys/evaluation_key.rs:110-170, 278-286): ct, out [batch][2][L][N] Ntt. */
+fhe_status fhe_bfv_galois(const fhe_ksk *gk, size_t exponent, const uint64_t *ct, uint64_t *out, size_t batch);
+fhe_status fhe_bfv_galois_dev(const fhe_ksk *gk, size_t exponent, const uint64_t *ct, uint64_t *out,
+                              size_t batch, void *stream);
+/* Ciphertext::switch_down (F/bfv/ciphertext.rs:148-161): ct [batch][nparts][L][N] Ntt ->
+ * out [batch][nparts][L-1][N] Ntt. */
+fhe_status fhe_bfv_switch_down(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, uint64_t *out, size_t batch);
+fhe_status fhe_bfv_switch_down_dev(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, uint64_t *out,
+                                   size_t batch, void *stream);
+
+/* ------------------------------------------------------------- Multiplicator ---- */
+/* Multiplicator::new_leveled_internal + enable_relinearization + enable_mod_switching
+ * (F/bfv/ops/mul.rs:74-163).  rk may be NULL (3-part output). */
+fhe_status fhe_mul_create(const fhe_scaler *extender_lhs, const fhe_scaler *extender_rhs,
+                          const fhe_scaler *down_scaler, const fhe_ksk *rk_or_null, int mod_switch,
+                          fhe_mul **out);
+void fhe_mul_destroy(fhe_mul *m);
+/* Output geometry: parts (2 with rk, else 3) and rows per part (L, or L-1 with mod switch). */
+fhe_status fhe_mul_out_shape(const fhe_mul *m, size_t *parts, size_t *rows);
+/* Multiplicator::multiply (F/bfv/ops/mul.rs:165-243), the metric's unit of work:
+ * lhs, rhs [batch][2][L][N] Ntt -> out [batch][parts][rows][N] Ntt. */
+fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out, size_t batch);
+fhe_status fhe_bfv_mul_dev(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out,
+                           size_t batch, void *stream);
+
+/* ------------------------------------------------------------- BfvParameters ---- */
+/* BfvParametersBuilder::build (F/bfv/parameters.rs:560-738), the part that defines device
+ * tables: per-level contexts, the extended multiplication basis (:660-676) and per-level
+ * MultiplicationParameters{extender, down_scaler} (:686-700, 793-814).
+ * moduli may be generated first with fhe_generate_moduli. */
+fhe_status fhe_params_create(int device, size_t degree, size_t nmoduli, const uint64_t *moduli,
+                             uint64_t plaintext_modulus, fhe_params **out);
+void fhe_params_destroy(fhe_params *p);
+size_t fhe_params_max_level(const fhe_params *p);
+fhe_status fhe_params_ctx(const fhe_params *p, size_t level, const fhe_ctx **out);      /* context_at_level */
+fhe_status fhe_params_mul_ctx(const fhe_params *p, size_t level, const fhe_ctx **out);  /* mul_params.to    */
+fhe_status fhe_params_extender(const fhe_params *p, size_t level, const fhe_scaler **out);
+fhe_status fhe_params_down_scaler(const fhe_params *p, size_t level, const fhe_scaler **out);
+/* Multiplicator::default(rk) (F/bfv/ops/mul.rs:101-138) at rk's ciphertext level; rk == NULL
+ * gives the `&ct * &ct` strategy without relinearisation (F/bfv/ops/mod.rs:259-358). */
+fhe_status fhe_mul_create_default(const fhe_params *p, size_t level, const fhe_ksk *rk_or_null, int mod_switch,
+                                  fhe_mul **out);
+
+/* ------------------------------------------------- zq::primes (host, no GPU) ---- */
+/* generate_prime (M/zq/primes.rs:30-59): returns 0 when none exists. */
+uint64_t fhe_generate_prime(size_t num_bits, uint64_t modulo, uint64_t upper_bound);
+int fhe_supports_opt(uint64_t p);                                      /* M/zq/primes.rs:10-24 */
+int fhe_is_prime(uint64_t p);                                          /* fhe-util/src/lib.rs:16-18 */
+/* BfvParametersBuilder::generate_moduli (F/bfv/parameters.rs:391-431). */
+fhe_status fhe_generate_moduli(const size_t *sizes, size_t count, size_t degree, uint64_t *out);
+
+/* ---------------------------------------------------------- bench / test aids ---- */
+/* Counter-based synthetic residues written on the device:
+ * x = splitmix64(seed ^ (ct<<40) ^ (part<<36) ^ (row<<28) ^ coeff) mod q_row for
+ * out[b][part_local][row][coeff], ct = ct0 + b, part = part0 + part_local. */
+fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0, uint64_t part0, size_t nparts,
+                                 uint64_t *out, size_t batch, void *stream);
+/* Chunk (ciphertexts per pipeline pass) used by the batched BFV entry points; 0 = default. */
+void fhe_set_chunk(size_t chunk);
+size_t fhe_get_chunk(void);
+/* Per-kernel HIP-event timing (events recorded on the launching stream). */
+void fhe_prof_enable(int on);
+void fhe_prof_reset(void);
+size_t fhe_prof_count(void);
+fhe_status fhe_prof_get(size_t index, char *name, size_t name_cap, uint64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FHE_HIP_H */

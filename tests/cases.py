@@ -1,0 +1,399 @@
+"""Parity cases shared by the CPU-emulation suite (tests/test_emu_parity.py) and the GPU suite
+(tests/test_gpu_parity.py).  Each case drives the engine through the C ABI (via the ctypes
+mirror in fhe.rs_amd/api.py) and compares bit-for-bit with the oracle; they read like the
+reference's own tests (cited per case)."""
+import random
+
+import numpy as np
+
+from fhe_oracle import bfv as obfv
+from fhe_oracle.rns import ScalingFactor
+from fhe_oracle.rq import (Context as OCtx, Poly, Scaler as OScaler, Switcher as OSwitcher,
+                           SubstitutionExponent, POWER_BASIS, NTT)
+from helpers import arr, rows, rand_poly, oracle_tables, ksk_arrays, ct_arr, Xfer
+
+Q3 = [4611686018282684417, 4611686018326724609, 4611686018309947393]
+P3 = [4611686018282684417, 4611686018309947393, 4611686018257518593]
+MODULI5 = [1153, 4611686018326724609, 4611686018309947393, 4611686018232352769, 4611686018171535361]
+
+
+def case_context_tables(fhe, n=32):
+    """Host-only setup (device = -1): tables, Shoup twins, inv_last (rq/context.rs:42-92,
+    ntt/native.rs:35-73) equal the oracle's; supplied tables are used verbatim."""
+    o = OCtx(MODULI5[1:], n)
+    c = fhe.Context(MODULI5[1:], n, device=-1)
+    t = oracle_tables(o)
+    for which, name in enumerate(("omegas", "omegas_shoup", "zetas_inv", "zetas_inv_shoup", "size_inv", "size_inv_shoup")):
+        assert np.array_equal(c.table(which), np.array(t[name], dtype=np.uint64)), name
+    assert c.table(6).tolist() == o.inv_last_qi_mod_qj and c.table(7).tolist() == o.inv_last_qi_mod_qj_shoup
+    lvl2 = c.at_level(2)
+    assert lvl2.moduli == MODULI5[1:3] and lvl2.table(6).tolist() == o.context_at_level(2).inv_last_qi_mod_qj
+    assert c.niterations_to(lvl2) == 2
+    # explicit tables with another primitive root
+    psis = [pow(op.psi, 3, op.p.p) for op in o.ops]
+    o2 = OCtx(MODULI5[1:], n, psis=psis)
+    c2 = fhe.Context(MODULI5[1:], n, device=-1, tables=oracle_tables(o2))
+    assert np.array_equal(c2.table(0), np.array(oracle_tables(o2)["omegas"], dtype=np.uint64))
+    assert not np.array_equal(c2.table(0), c.table(0))
+
+
+def case_ntt(fhe, dev, n, moduli=Q3, batch=2, coracle_ctx=None, seed=0):
+    """ntt/mod.rs:50-112 (bijection) + exact values vs the oracle butterflies."""
+    x = Xfer(dev)
+    rng = random.Random(n * 31 + seed)
+    c = fhe.Context(moduli, n)
+    a = np.array([[[rng.randrange(m) for _ in range(n)] for m in moduli] for _ in range(batch)], dtype=np.uint64)
+    if coracle_ctx is None:
+        o = OCtx(moduli, n)
+        want = np.array([[op.forward([int(v) for v in row]) for op, row in zip(o.ops, poly)] for poly in a],
+                        dtype=np.uint64)
+    else:
+        want = np.stack([coracle_ctx.poly_ntt_forward(poly) for poly in a])
+    f = x.back(c.ntt_forward(x.to(a)))
+    assert np.array_equal(f, want)
+    back = x.back(c.ntt_backward(x.to(f)))
+    assert np.array_equal(back, a)
+
+
+def case_ntt_explicit_tables(fhe, dev, n=16):
+    x = Xfer(dev)
+    base = OCtx(Q3, n)
+    o = OCtx(Q3, n, psis=[pow(op.psi, 5, op.p.p) for op in base.ops])
+    c = fhe.Context(Q3, n, tables=oracle_tables(o))
+    rng = random.Random(4)
+    p = rand_poly(o, POWER_BASIS, rng)
+    assert np.array_equal(x.back(c.ntt_forward(x.to(arr(p)))), arr(p.into_ntt()))
+
+
+def case_poly_ops(fhe, dev, n=32):
+    """rq/ops.rs:587-939."""
+    x = Xfer(dev)
+    rng = random.Random(9)
+    o = OCtx(MODULI5, n)
+    c = fhe.Context(MODULI5, n)
+    a, b = rand_poly(o, NTT, rng), rand_poly(o, NTT, rng)
+    A = np.stack([arr(a), arr(b)])
+    B = np.stack([arr(b), arr(a)])
+    assert np.array_equal(x.back(c.add(x.to(A), x.to(B)))[0], arr(a.add(b)))
+    assert np.array_equal(x.back(c.sub(x.to(A), x.to(B)))[1], arr(b.sub(a)))
+    assert np.array_equal(x.back(c.mul(x.to(A), x.to(B)))[0], arr(a.mul(b)))
+    assert np.array_equal(x.back(c.neg(x.to(A)))[1], arr(b.neg()))
+    bs = b.into_ntt_shoup()
+    sh = c.shoup(arr(b))
+    assert np.array_equal(sh, np.array(bs.coefficients_shoup, dtype=np.uint64))
+    assert np.array_equal(x.back(c.mul_shoup(x.to(arr(a)), x.to(arr(b)), x.to(sh))), arr(a.mul(bs)))
+    # lazy lhs (< 4p) is accepted by the Shoup product (ops.rs:208-245)
+    lazy = arr(a) + np.array([[2 * m] for m in MODULI5], dtype=np.uint64) * np.uint64(1)
+    assert np.array_equal(x.back(c.mul_shoup(x.to(lazy), x.to(arr(b)), x.to(sh))), arr(a.mul(bs)))
+
+
+def case_substitute(fhe, dev, n=16):
+    """rq/mod.rs:947-1036."""
+    x = Xfer(dev)
+    rng = random.Random(10)
+    o = OCtx(MODULI5, n)
+    c = fhe.Context(MODULI5, n)
+    p = rand_poly(o, POWER_BASIS, rng)
+    pn = p.into_ntt()
+    for e in (1, 3, 11, 2 * n - 1, 2 * n + 5):
+        se = SubstitutionExponent(o, e)
+        assert np.array_equal(x.back(c.substitute(e, x.to(arr(p)), ntt=False)), arr(p.substitute(se)))
+        assert np.array_equal(x.back(c.substitute(e, x.to(arr(pn)), ntt=True)), arr(pn.substitute(se)))
+    for bad in (0, 2, 2 * n):
+        try:
+            c.substitute(bad, x.to(arr(p)), ntt=True)
+            raise AssertionError("even exponent accepted")
+        except fhe.FheError as err:
+            assert err.code == -10
+
+
+def case_switch_down(fhe, dev, n=16):
+    """rq/mod.rs:1039-1073 + ciphertext.rs:148-161."""
+    x = Xfer(dev)
+    rng = random.Random(11)
+    o = OCtx(MODULI5, n)
+    c = fhe.Context(MODULI5, n)
+    p = rand_poly(o, POWER_BASIS, rng)
+    cur_o, cur_c, cur = o, c, p
+    while cur_o.next_context is not None:
+        nxt = cur.switch_down()
+        got = x.back(cur_c.switch_down(x.to(arr(cur))))
+        assert np.array_equal(got, arr(nxt))
+        cur, cur_o, cur_c = nxt, cur_o.next_context, cur_c.at_level(1)
+    try:
+        cur_c.switch_down(x.to(arr(cur)))
+        raise AssertionError("switch_down past the last context")
+    except fhe.FheError as err:
+        assert err.code == -8
+    # ciphertext-level switch_down on 3 parts x 2 ciphertexts
+    cts = [[rand_poly(o, NTT, rng) for _ in range(3)] for _ in range(2)]
+    want = np.array([[arr(q.into_power_basis().switch_down().into_ntt()) for q in ct] for ct in cts], dtype=np.uint64)
+    got = x.back(c.ciphertext_switch_down(x.to(np.array([[arr(q) for q in ct] for ct in cts], dtype=np.uint64))))
+    assert np.array_equal(got, want)
+
+
+NUMS = [1, 2, 3, 100, 1000, 4611686018326724610]
+DENS = [1, 2, 3, 4, 100, 101, 1000, 1001, 4611686018326724610]
+
+
+def case_scaler_grid(fhe, dev, n=16, pairs=None):
+    """rq/scaler.rs:154-204 (all 54 numerator/denominator pairs, PowerBasis and Ntt), also the
+    engine-derived constants vs the oracle's (rns/scaler.rs:79-229)."""
+    x = Xfer(dev)
+    rng = random.Random(12)
+    of, ot = OCtx(Q3, n), OCtx(P3, n)
+    cf, ct = fhe.Context(Q3, n), fhe.Context(P3, n)
+    for num in NUMS:
+        for den in DENS:
+            if pairs is not None and (num, den) not in pairs:
+                continue
+            osc = OScaler(of, ot, ScalingFactor(num, den))
+            sc = fhe.Scaler(cf, ct, num, den)
+            s = osc.scaler
+            assert sc.number_common_moduli == osc.number_common_moduli
+            assert sc.constants(0).tolist() == s.gamma and sc.constants(1).tolist() == s.gamma_shoup
+            assert sc.constants(2).tolist() == [v for r in s.omega for v in r]
+            assert sc.constants(3).tolist() == [v for r in s.omega_shoup for v in r]
+            assert sc.constants(4).tolist() == s.theta_omega_lo and sc.constants(5).tolist() == s.theta_omega_hi
+            assert sc.constants(6).tolist() == [1 if v else 0 for v in s.theta_omega_sign]
+            assert sc.constants(7).tolist() == s.theta_garner_lo and sc.constants(8).tolist() == s.theta_garner_hi
+            assert sc.constants(9).tolist() == [s.theta_gamma_lo, s.theta_gamma_hi, 1 if s.theta_gamma_sign else 0,
+                                                s.theta_garner_shift, 1 if s.scaling_factor.is_one else 0]
+            p = rand_poly(of, POWER_BASIS, rng)
+            both = np.stack([arr(p), arr(rand_poly(of, POWER_BASIS, rng))])
+            got = x.back(sc.scale(x.to(both), ntt=False))
+            assert np.array_equal(got[0], arr(osc.scale(p)))
+            pn = p.into_ntt()
+            assert np.array_equal(x.back(sc.scale(x.to(arr(pn)), ntt=True)), arr(osc.scale(pn)))
+
+
+def case_scaler_extend_and_constants_api(fhe, dev, n=16):
+    """Common-prefix extension (rq/scaler.rs:35-43, 61-65), Switcher (rq/mod.rs:1101-1122) and
+    the bring-your-own-constants constructor."""
+    x = Xfer(dev)
+    rng = random.Random(13)
+    base, ext = MODULI5[1:3], MODULI5[1:3] + [MODULI5[4], Q3[0]]
+    of, ot = OCtx(base, n), OCtx(ext, n)
+    cf, ct = fhe.Context(base, n), fhe.Context(ext, n)
+    osc = OScaler(of, ot, ScalingFactor.one())
+    sc = fhe.Scaler(cf, ct, 7, 7)
+    assert sc.number_common_moduli == 2 == osc.number_common_moduli
+    pn = rand_poly(of, NTT, rng)
+    want = arr(osc.scale(pn))
+    assert np.array_equal(x.back(sc.scale(x.to(arr(pn)), ntt=True)), want)
+    s = osc.scaler
+    k = dict(gamma=s.gamma, gamma_shoup=s.gamma_shoup, omega=s.omega, omega_shoup=s.omega_shoup,
+             theta_gamma_lo=s.theta_gamma_lo, theta_gamma_hi=s.theta_gamma_hi, theta_gamma_sign=s.theta_gamma_sign,
+             theta_omega_lo=s.theta_omega_lo, theta_omega_hi=s.theta_omega_hi, theta_omega_sign=s.theta_omega_sign,
+             theta_garner_lo=s.theta_garner_lo, theta_garner_hi=s.theta_garner_hi,
+             theta_garner_shift=s.theta_garner_shift)
+    sc2 = fhe.Scaler.from_constants(cf, ct, 2, True, k)
+    assert np.array_equal(x.back(sc2.scale(x.to(arr(pn)), ntt=True)), want)
+    a, b = OCtx(MODULI5[:2], n), OCtx(MODULI5[3:], n)
+    ca, cb = fhe.Context(MODULI5[:2], n), fhe.Context(MODULI5[3:], n)
+    p = rand_poly(a, POWER_BASIS, rng)
+    assert np.array_equal(x.back(fhe.Switcher(ca, cb).switch(x.to(arr(p)))), arr(p.switch(OSwitcher(a, b))))
+    try:
+        fhe.Scaler(cf, fhe.Context(ext, 2 * n), 1, 1)
+        raise AssertionError("degree mismatch accepted")
+    except fhe.FheError as err:
+        assert err.code == -7
+
+
+def _params(fhe, nmod, n, dev_needed=True):
+    opar = obfv.BfvParameters.default_arc(nmod, n)
+    par = fhe.BfvParameters(n, opar.plaintext, moduli=opar.moduli)
+    return opar, par
+
+
+def case_params(fhe, nmod=3, n=16):
+    """parameters.rs:560-738: per-level contexts, extended basis, mul params == oracle's."""
+    opar, par = _params(fhe, nmod, n)
+    assert fhe.generate_moduli([62] * nmod, n) == opar.moduli
+    for level in range(nmod):
+        assert par.context_at_level(level).moduli == opar.ctx[level].moduli
+        assert par.mul_context_at_level(level).moduli == opar.mul_params[level].to.moduli
+        e, d = par.extender(level), par.down_scaler(level)
+        oe, od = opar.mul_params[level].extender.scaler, opar.mul_params[level].down_scaler.scaler
+        assert e.number_common_moduli == nmod - level
+        assert e.constants(2).tolist() == [v for r in oe.omega for v in r]
+        assert d.constants(0).tolist() == od.gamma and d.constants(5).tolist() == od.theta_omega_hi
+        assert d.constants(9).tolist() == [od.theta_gamma_lo, od.theta_gamma_hi, 1 if od.theta_gamma_sign else 0,
+                                           od.theta_garner_shift, 0]
+
+
+def case_key_switch_levels(fhe, dev, nmod=4, n=16):
+    """key_switching_key.rs:241-320, 532-598 and relinearization_key.rs:219-273: every
+    (ciphertext level, key level) pair; relinearizes incl. the switch_down_to fix-up."""
+    x = Xfer(dev)
+    rng = random.Random(14)
+    opar, par = _params(fhe, nmod, n)
+    sk = obfv.SecretKey.random(opar, rng)
+    for ct_level in range(nmod - 1):
+        for key_level in range(ct_level + 1):
+            ork = obfv.RelinearizationKey(sk, rng, ct_level, key_level)
+            c0, c0s, c1, c1s = ksk_arrays(ork.ksk)
+            cctx, kctx = par.context_at_level(ct_level), par.context_at_level(key_level)
+            ksk = fhe.KeySwitchingKey(cctx, kctx, c0, c1, c0s if key_level % 2 else None, c1s if key_level % 2 else None)
+            p = [rand_poly(opar.ctx[ct_level], POWER_BASIS, rng) for _ in range(3)]
+            g0, g1 = ksk.key_switch(x.to(np.stack([arr(q) for q in p])))
+            g0, g1 = x.back(g0), x.back(g1)
+            for i, q in enumerate(p):
+                w0, w1 = ork.ksk.key_switch(q)
+                assert np.array_equal(g0[i], arr(w0)) and np.array_equal(g1[i], arr(w1))
+            # relinearizes on 2 three-part ciphertexts
+            cts = []
+            for _ in range(2):
+                a = sk.encrypt([rng.randrange(opar.plaintext) for _ in range(n)], rng, ct_level)
+                b = sk.encrypt([rng.randrange(opar.plaintext) for _ in range(n)], rng, ct_level)
+                cts.append(a.mul(b))
+            inp = np.stack([ct_arr(c) for c in cts])
+            got = x.back(fhe.RelinearizationKey(ksk).relinearizes(x.to(inp)))
+            for i, c in enumerate(cts):
+                ork.relinearizes(c)
+                assert np.array_equal(got[i], ct_arr(c))
+
+
+def case_key_switch_decomposition(fhe, dev, n=16):
+    """key_switching_key.rs:323-362, 600-633 (single-modulus key level, base-2^k digits)."""
+    x = Xfer(dev)
+    rng = random.Random(15)
+    opar, par = _params(fhe, 3, n)
+    sk = obfv.SecretKey.random(opar, rng)
+    octx = opar.ctx[2]
+    frm = rand_poly(octx, POWER_BASIS, rng)
+    oksk = obfv.KeySwitchingKey(sk, frm, 2, 2, rng)
+    c0, c0s, c1, c1s = ksk_arrays(oksk)
+    ctx = par.context_at_level(2)
+    ksk = fhe.KeySwitchingKey(ctx, ctx, c0, c1, log_base=oksk.log_base)
+    p = rand_poly(octx, POWER_BASIS, rng)
+    g0, g1 = ksk.key_switch(x.to(arr(p)))
+    w0, w1 = oksk.key_switch(p)
+    assert np.array_equal(x.back(g0), arr(w0)) and np.array_equal(x.back(g1), arr(w1))
+    try:
+        fhe.KeySwitchingKey(ctx, ctx, c0, c1)  # single modulus without log_base
+        raise AssertionError("accepted")
+    except fhe.FheError as err:
+        assert err.code in (-11, -17)
+
+
+def case_galois(fhe, dev, nmod=3, n=16):
+    """galois_key.rs:63-123, 186-256; evaluation_key.rs:110-170, 278-286."""
+    x = Xfer(dev)
+    rng = random.Random(16)
+    opar, par = _params(fhe, nmod, n)
+    sk = obfv.SecretKey.random(opar, rng)
+    for ct_level, key_level in ((0, 0), (1, 0), (1, 1)):
+        gks, ogks = [], {}
+        for e in (3, pow(3, 2, 2 * n), 2 * n - 1):
+            ogk = obfv.GaloisKey(sk, e, ct_level, key_level, rng)
+            c0, c0s, c1, c1s = ksk_arrays(ogk.ksk)
+            ksk = fhe.KeySwitchingKey(par.context_at_level(ct_level), par.context_at_level(key_level), c0, c1)
+            gks.append(fhe.GaloisKey(ksk, e))
+            ogks[e] = ogk
+        ek = fhe.EvaluationKey(n, gks)
+        cts = [sk.encrypt([rng.randrange(opar.plaintext) for _ in range(n)], rng, ct_level) for _ in range(2)]
+        inp = x.to(np.stack([ct_arr(c) for c in cts]))
+        for got, e in ((ek.rotates_columns_by(inp, 1), 3), (ek.rotates_columns_by(inp, 2), pow(3, 2, 2 * n)),
+                       (ek.rotates_rows(inp), 2 * n - 1)):
+            got = x.back(got)
+            for i, c in enumerate(cts):
+                assert np.array_equal(got[i], ct_arr(ogks[e].relinearize(c)))
+    try:
+        fhe.GaloisKey(gks[0].ksk, 4)
+        raise AssertionError("even exponent accepted")
+    except fhe.FheError as err:
+        assert err.code == -10
+
+
+def case_multiply(fhe, dev, nmod=3, n=16, batch=3, level=0, chunk=0):
+    """ops/mul.rs:165-243, 263-367 and ops/mod.rs:259-358: Multiplicator::default with
+    relinearisation (+/- modulus switching) and the `&ct * &ct` tensor without it; results
+    equal the oracle bit for bit AND decrypt to the plaintext product."""
+    x = Xfer(dev)
+    rng = random.Random(17 + nmod + level)
+    opar, par = _params(fhe, nmod, n)
+    sk = obfv.SecretKey.random(opar, rng)
+    ork = obfv.RelinearizationKey(sk, rng, level, level)
+    c0, c0s, c1, c1s = ksk_arrays(ork.ksk)
+    ctx = par.context_at_level(level)
+    rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1, c0s, c1s))
+    t = opar.plaintext
+    A = [sk.encrypt([rng.randrange(t) for _ in range(n)], rng, level) for _ in range(batch)]
+    B = [sk.encrypt([rng.randrange(t) for _ in range(n)], rng, level) for _ in range(batch)]
+    lhs, rhs = x.to(np.stack([ct_arr(c) for c in A])), x.to(np.stack([ct_arr(c) for c in B]))
+    if chunk:
+        fhe.set_chunk(chunk)
+    try:
+        for mod_switch in ([False, True] if level < opar.max_level() else [False]):
+            om = obfv.Multiplicator.default(ork)
+            if mod_switch:
+                om.enable_mod_switching()
+            m = fhe.Multiplicator.default(par, rk, level, mod_switch)
+            got = x.back(m.multiply(lhs, rhs))
+            for i in range(batch):
+                want = om.multiply(A[i], B[i])
+                assert np.array_equal(got[i], ct_arr(want)), (mod_switch, i)
+        m3 = fhe.Multiplicator.default(par, None, level)
+        got = x.back(m3.multiply(lhs, rhs))
+        for i in range(batch):
+            assert np.array_equal(got[i], ct_arr(A[i].mul(B[i])))
+    finally:
+        fhe.set_chunk(0)
+
+
+def case_multiply_custom_factors(fhe, dev, n=16):
+    """ops/mul.rs:369-418 (`different_mul_strategy`): rhs pre-scaled by P/Q, post-scale t/P."""
+    x = Xfer(dev)
+    rng = random.Random(18)
+    opar, par = _params(fhe, 3, n)
+    sk = obfv.SecretKey.random(opar, rng)
+    ork = obfv.RelinearizationKey(sk, rng)
+    octx = opar.ctx[0]
+    ext = obfv.extended_basis_primes(n, opar.moduli, 4)
+    pprod = 1
+    for v in ext:
+        pprod *= v
+    basis = ext  # the second strategy multiplies in the fresh basis P only
+    # HPS "second strategy": lhs factor 1, rhs factor P/Q, post factor t/P, basis = q ++ P
+    full = opar.moduli + ext
+    om = obfv.Multiplicator(ScalingFactor.one(), ScalingFactor(pprod, octx.modulus()), full,
+                            ScalingFactor(opar.plaintext, pprod), opar)
+    om.enable_relinearization(ork)
+    ctx = par.context_at_level(0)
+    mctx = fhe.Context(full, n)
+    el = fhe.Scaler(ctx, mctx, 1, 1)
+    er = fhe.Scaler(ctx, mctx, pprod, octx.modulus())
+    dn = fhe.Scaler(mctx, ctx, opar.plaintext, pprod)
+    c0, c0s, c1, c1s = ksk_arrays(ork.ksk)
+    rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1))
+    m = fhe.Multiplicator(el, er, dn, rk)
+    t = opar.plaintext
+    a = sk.encrypt([rng.randrange(t) for _ in range(n)], rng)
+    b = sk.encrypt([rng.randrange(t) for _ in range(n)], rng)
+    got = x.back(m.multiply(x.to(ct_arr(a)), x.to(ct_arr(b))))
+    assert np.array_equal(got, ct_arr(om.multiply(a, b)))
+    del basis
+
+
+def case_errors(fhe):
+    """Error conventions (include/fhe_hip.h status codes <-> fhe_math::Error variants)."""
+    def code(fn):
+        try:
+            fn()
+        except fhe.FheError as e:
+            return e.code
+        return 0
+    assert code(lambda: fhe.Context([], 16, device=-1)) == -14          # EmptyModuli
+    assert code(lambda: fhe.Context([1 << 62], 16, device=-1)) == -3    # InvalidModulus
+    assert code(lambda: fhe.Context(Q3, 12, device=-1)) == -4           # InvalidPolynomialDegree
+    assert code(lambda: fhe.Context(Q3, 4, device=-1)) == -4
+    assert code(lambda: fhe.Context([1153, 1153], 16, device=-1)) == -15  # NonCoprimeModuli
+    assert code(lambda: fhe.Context([1153], 1024, device=-1)) == -5     # NttOperatorUnavailable
+    c = fhe.Context(Q3, 16, device=-1)
+    assert code(lambda: c.at_level(3)) == -12
+    assert code(lambda: c.ntt_forward(np.zeros((3, 16), dtype=np.uint64))) == -18  # host-only handle
+    assert fhe.generate_prime(62, 2 * 1048576, (1 << 62)) == 4611686018326724609
+    assert fhe.generate_prime(11, 16, 1033) is None
+    assert fhe.supports_opt(4611686018326724609) and not fhe.supports_opt(1153)
+    assert fhe.is_prime(1153) and not fhe.is_prime(1155)

@@ -1,0 +1,180 @@
+// emu_rt.hpp -- TEST INFRASTRUCTURE ONLY.  A tiny host stand-in for the slice of the HIP
+// runtime that fhe.rs_amd/csrc uses, so the *same kernel sources* can be compiled with g++
+// and executed in a container without a GPU (tests/emu/build.sh -> tests/emu/_build/libfhe_emu.so).
+//
+// Workgroups run one at a time; every "thread" of a workgroup is a ucontext fiber and
+// __syncthreads() yields to a round-robin scheduler, which gives real barrier semantics
+// (all fibers reach barrier k before any passes it).  This checks indexing, barrier placement
+// and arithmetic against the oracle.  It says nothing about performance, bank conflicts or
+// memory-model hazards -- those are checked on the MI355X by `pytest -m gpu`.
+// The shipped package never loads this library (see fhe.rs_amd/_lib.py).
+#pragma once
+#include <ucontext.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__ static
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __restrict__
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace emu {
+struct State {
+    dim3 threadIdx, blockIdx, blockDim, gridDim;
+    unsigned char *smem = nullptr;
+    ucontext_t main_ctx;
+    std::vector<ucontext_t> fibers;
+    std::vector<unsigned char *> stacks;
+    std::vector<char> done;
+    unsigned current = 0;
+    const std::function<void()> *body = nullptr;
+};
+inline State &st() {
+    static State s;
+    return s;
+}
+inline void fiber_entry() {
+    State &s = st();
+    (*s.body)();
+    s.done[s.current] = 1;
+    swapcontext(&s.fibers[s.current], &s.main_ctx);
+}
+inline void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()> &body) {
+    State &s = st();
+    const unsigned nthreads = block.x * block.y * block.z;
+    constexpr size_t STACK = 96 * 1024;
+    while (s.stacks.size() < nthreads) s.stacks.push_back((unsigned char *)malloc(STACK));
+    s.fibers.resize(nthreads);
+    s.done.assign(nthreads, 0);
+    std::vector<unsigned char> smem(smem_bytes + 64);
+    s.smem = (unsigned char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
+    s.blockDim = block;
+    s.gridDim = grid;
+    s.body = &body;
+    for (unsigned bz = 0; bz < grid.z; bz++)
+        for (unsigned by = 0; by < grid.y; by++)
+            for (unsigned bx = 0; bx < grid.x; bx++) {
+                s.blockIdx = dim3(bx, by, bz);
+                for (unsigned t = 0; t < nthreads; t++) {
+                    getcontext(&s.fibers[t]);
+                    s.fibers[t].uc_stack.ss_sp = s.stacks[t];
+                    s.fibers[t].uc_stack.ss_size = STACK;
+                    s.fibers[t].uc_link = &s.main_ctx;
+                    makecontext(&s.fibers[t], (void (*)())fiber_entry, 0);
+                    s.done[t] = 0;
+                }
+                unsigned live = nthreads;
+                while (live) {
+                    live = 0;
+                    for (unsigned t = 0; t < nthreads; t++) {
+                        if (s.done[t]) continue;
+                        s.current = t;
+                        s.threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                        swapcontext(&s.main_ctx, &s.fibers[t]);
+                        if (!s.done[t]) live++;
+                    }
+                }
+            }
+    s.body = nullptr;
+}
+inline void syncthreads() {
+    State &s = st();
+    swapcontext(&s.fibers[s.current], &s.main_ctx);
+}
+}  // namespace emu
+
+#define threadIdx (emu::st().threadIdx)
+#define blockIdx (emu::st().blockIdx)
+#define blockDim (emu::st().blockDim)
+#define gridDim (emu::st().gridDim)
+inline void __syncthreads() { emu::syncthreads(); }
+inline unsigned __brev(unsigned x) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; i++) {
+        r = (r << 1) | (x & 1);
+        x >>= 1;
+    }
+    return r;
+}
+#define FHE_DYN_SMEM(type, name) type *name = reinterpret_cast<type *>(emu::st().smem)
+
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
+    emu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
+
+// ---- runtime API subset ---------------------------------------------------------------
+typedef int hipError_t;
+typedef void *hipStream_t;
+struct emuEvent {
+    std::chrono::steady_clock::time_point t;
+};
+typedef emuEvent *hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) {
+    *n = 1;
+    return hipSuccess;
+}
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) {
+    *d = 0;
+    return hipSuccess;
+}
+inline hipError_t hipMalloc(void **p, size_t n) {
+    *p = aligned_alloc(64, (n + 63) / 64 * 64 + 64);
+    return *p ? hipSuccess : hipErrorInvalidValue;
+}
+inline hipError_t hipFree(void *p) {
+    free(p);
+    return hipSuccess;
+}
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) {
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
+    memset(d, v, n);
+    return hipSuccess;
+}
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) {
+    *e = new emuEvent();
+    return hipSuccess;
+}
+inline hipError_t hipEventDestroy(hipEvent_t e) {
+    delete e;
+    return hipSuccess;
+}
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+    e->t = std::chrono::steady_clock::now();
+    return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+template <class F>
+inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) {
+    return hipSuccess;
+}

@@ -1,0 +1,75 @@
+"""CPU suite: the engine's host logic and its *kernel sources compiled for the host*
+(tests/emu, fiber-emulated workgroups) against the oracle.  This validates indexing, barrier
+placement, pipelines and the C ABI without a GPU; `tests/test_gpu_parity.py` runs the same
+cases on the MI355X through the real HIP build."""
+import pytest
+
+import cases
+from helpers import load_engine
+
+
+@pytest.fixture(scope="module")
+def fhe():
+    return load_engine("emu")
+
+
+def test_context_tables(fhe):
+    cases.case_context_tables(fhe)
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 64, 256, 1024])
+def test_ntt(fhe, n):
+    cases.case_ntt(fhe, False, n, batch=2 if n < 1024 else 1)
+
+
+def test_ntt_explicit_tables(fhe):
+    cases.case_ntt_explicit_tables(fhe, False)
+
+
+def test_poly_ops(fhe):
+    cases.case_poly_ops(fhe, False)
+
+
+def test_substitute(fhe):
+    cases.case_substitute(fhe, False)
+
+
+def test_switch_down(fhe):
+    cases.case_switch_down(fhe, False)
+
+
+def test_scaler_grid(fhe):
+    cases.case_scaler_grid(fhe, False)
+
+
+def test_scaler_extend_switcher_constants(fhe):
+    cases.case_scaler_extend_and_constants_api(fhe, False)
+
+
+def test_params(fhe):
+    cases.case_params(fhe)
+
+
+def test_key_switch_levels(fhe):
+    cases.case_key_switch_levels(fhe, False)
+
+
+def test_key_switch_decomposition(fhe):
+    cases.case_key_switch_decomposition(fhe, False)
+
+
+def test_galois(fhe):
+    cases.case_galois(fhe, False)
+
+
+@pytest.mark.parametrize("nmod,level,chunk", [(2, 0, 0), (3, 0, 2), (3, 1, 0), (4, 1, 1)])
+def test_multiply(fhe, nmod, level, chunk):
+    cases.case_multiply(fhe, False, nmod=nmod, level=level, chunk=chunk)
+
+
+def test_multiply_custom_factors(fhe):
+    cases.case_multiply_custom_factors(fhe, False)
+
+
+def test_errors(fhe):
+    cases.case_errors(fhe)

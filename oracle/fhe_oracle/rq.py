@@ -16,6 +16,16 @@ NTT = "Ntt"
 NTT_SHOUP = "NttShoup"
 
 
+_OP_CACHE = {}
+
+
+def cached_ntt_operator(q, degree, psi):
+    key = (q.p, degree, psi)
+    if key not in _OP_CACHE:
+        _OP_CACHE[key] = NttOperator(q, degree, psi)
+    return _OP_CACHE[key]
+
+
 class Context:
     """rq/context.rs:9-92."""
 
@@ -27,7 +37,9 @@ class Context:
         self.logn = degree.bit_length() - 1
         self.rns = RnsContext(self.moduli)
         self.q = [Modulus(m) for m in self.moduli]
-        self.ops = [NttOperator(qi, degree, None if psis is None else psis[i])
+        # NttOperator::new is a pure function of (p, degree, psi): memoised, because the
+        # next_context chain below would otherwise rebuild every table O(L^2) times.
+        self.ops = [cached_ntt_operator(qi, degree, None if psis is None else psis[i])
                     for i, qi in enumerate(self.q)]
         self.bitrev = [bitrev(j, self.logn) for j in range(degree)]
         q_last = self.moduli[-1]

@@ -1,0 +1,144 @@
+"""GPU suite (`pytest -m gpu`): the parity tests proper.  Every case calls the HIP build
+through the C ABI on the MI355X and compares bit-for-bit with the oracle -- host-pointer and
+device-pointer (`_dev`, torch tensors on the current stream) entry points, small sizes
+against the Python oracle, BASELINE.json's full sizes against the plain-C oracle, plus
+size-independent properties (round trips, linearity) at full batch."""
+import numpy as np
+import pytest
+
+import cases
+from helpers import HIP_LIB, load_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fhe():
+    eng = load_engine("hip")
+    from fhe_rs_amd import _lib
+    assert _lib.loaded_path() == HIP_LIB, "GPU tests must run on the HIP build"
+    assert eng.device_count() >= 1, "no HIP device visible"
+    return eng
+
+
+@pytest.mark.parametrize("dev", [False, True])
+@pytest.mark.parametrize("n", [8, 16, 64, 1024, 4096])
+def test_ntt_small(fhe, n, dev):
+    cases.case_ntt(fhe, dev, n, batch=3)
+
+
+@pytest.mark.parametrize("n,mods", [(8192, [1152921504606830593, 1152921504606748673, 4611686018427322369]),
+                                    (16384, [1152921504606748673, 4611686018427322369]),
+                                    (32768, [1152921504606584833, 4611686018427322369]),
+                                    (65536, [4611686018427322369 - 0])])
+def test_ntt_full_sizes(fhe, n, mods):
+    from fhe_oracle import coracle
+    from fhe_oracle.rq import Context as OCtx
+    from fhe_oracle.zq import generate_prime
+    mods = [m if m % (2 * n) == 1 else generate_prime(62, 2 * n, 1 << 62) for m in mods]
+    mods = list(dict.fromkeys(mods))
+    cases.case_ntt(fhe, True, n, moduli=mods, batch=5, coracle_ctx=coracle.CCtx(OCtx(mods, n)))
+
+
+def test_ntt_explicit_tables(fhe):
+    cases.case_ntt_explicit_tables(fhe, True)
+
+
+@pytest.mark.parametrize("dev", [False, True])
+def test_poly_ops(fhe, dev):
+    cases.case_poly_ops(fhe, dev)
+
+
+@pytest.mark.parametrize("dev", [False, True])
+def test_substitute(fhe, dev):
+    cases.case_substitute(fhe, dev)
+
+
+@pytest.mark.parametrize("dev", [False, True])
+def test_switch_down(fhe, dev):
+    cases.case_switch_down(fhe, dev)
+
+
+def test_scaler_grid(fhe):
+    cases.case_scaler_grid(fhe, True)
+
+
+def test_scaler_grid_host_api(fhe):
+    cases.case_scaler_grid(fhe, False, pairs={(1, 1), (3, 4), (1000, 101), (4611686018326724610, 1001)})
+
+
+def test_scaler_extend_switcher_constants(fhe):
+    cases.case_scaler_extend_and_constants_api(fhe, True)
+
+
+def test_params(fhe):
+    cases.case_params(fhe)
+
+
+@pytest.mark.parametrize("dev", [False, True])
+def test_key_switch_levels(fhe, dev):
+    cases.case_key_switch_levels(fhe, dev)
+
+
+def test_key_switch_decomposition(fhe):
+    cases.case_key_switch_decomposition(fhe, True)
+
+
+@pytest.mark.parametrize("dev", [False, True])
+def test_galois(fhe, dev):
+    cases.case_galois(fhe, dev)
+
+
+@pytest.mark.parametrize("nmod,n,level,chunk,dev", [(2, 16, 0, 0, True), (3, 16, 0, 2, False), (3, 64, 1, 0, True),
+                                                    (4, 32, 1, 1, True), (6, 16, 0, 0, True)])
+def test_multiply(fhe, nmod, n, level, chunk, dev):
+    cases.case_multiply(fhe, dev, nmod=nmod, n=n, level=level, chunk=chunk)
+
+
+def test_multiply_custom_factors(fhe):
+    cases.case_multiply_custom_factors(fhe, True)
+
+
+def test_errors(fhe):
+    cases.case_errors(fhe)
+
+
+def test_empty_batch(fhe):
+    import torch
+    c = fhe.Context(cases.Q3, 16)
+    e = torch.empty((0, 3, 16), dtype=torch.int64, device="cuda")
+    assert c.ntt_forward(e).shape[0] == 0
+    assert c.ntt_forward(np.zeros((0, 3, 16), dtype=np.uint64)).shape[0] == 0
+
+
+# ---------------------------------------------------------------- BASELINE.json configs ----
+def test_config_c1_ct_times_ct_n4096(fhe):
+    """configs[0]: N=4096, one 50-bit modulus, `&ct * &ct` (no relin: one modulus)."""
+    import full_size
+    full_size.check_mul(fhe, n=4096, sizes=[50], batch=4, relin=False, cfg=1)
+
+
+def test_config_c2_mul_relin_n8192(fhe):
+    """configs[1]: N=8192, 4x60-bit moduli, ct x ct + relinearise; sampled against the C oracle."""
+    import full_size
+    full_size.check_mul(fhe, n=8192, sizes=[60] * 4, batch=70, relin=True, cfg=2, sample=(0, 1, 33, 69))
+
+
+def test_config_c2_properties_full_batch(fhe):
+    """Full batch (1024): size-independent properties -- batch consistency (every ciphertext
+    pair gives the same result alone as inside the batch) and NTT round trip."""
+    import full_size
+    full_size.check_batch_properties(fhe, n=8192, sizes=[60] * 4, batch=1024, cfg=2)
+
+
+def test_config_c3_relin_rotate_n16384(fhe):
+    """configs[2]: N=16384, 8x60-bit moduli, relinearise + rotation (Galois key switch)."""
+    import full_size
+    full_size.check_relin_rotate(fhe, n=16384, sizes=[60] * 8, batch=6, cfg=3)
+
+
+def test_config_c5_chain_n32768(fhe):
+    """configs[4]: N=32768, 16x60-bit moduli, multiply + relinearise + modulus switch for the
+    first levels of the chain (RNS basis-conversion stress; the row does not fit LDS)."""
+    import full_size
+    full_size.check_chain(fhe, n=32768, sizes=[60] * 16, batch=2, levels=2, cfg=5)

@@ -55,10 +55,14 @@ def cpu_baseline(n, sizes, t, seed, budget_s):
     lhs = np.stack([np.stack([o["cb"].synth_poly(seed, i, 0), o["cb"].synth_poly(seed, i, 1)]) for i in range(npairs)])
     rhs = np.stack([np.stack([o["cb"].synth_poly(seed, i, 2), o["cb"].synth_poly(seed, i, 3)]) for i in range(npairs)])
     cm.time_multiply(lhs, rhs, 2, 1)  # warm up (page in tables)
-    s1, _ = cm.time_multiply(lhs, rhs, 16, 1)
-    single = 16 / s1
+    s1, _ = cm.time_multiply(lhs, rhs, 24, 1)
+    single = 24 / s1
     threads = coracle.max_threads()
-    count = max(threads * 2, int(min(budget_s, 30.0) * single * threads * 0.6))
+    # calibrate the all-core rate on a short run, then size the timed sample to the budget
+    cal_n = threads * 2
+    cal_s, _ = cm.time_multiply(lhs, rhs, cal_n, threads)
+    count = int(max(threads * 2, min(budget_s, 30.0) * cal_n / cal_s))
+    count -= count % npairs          # the last op then is pair npairs-1 (used for the parity spot check)
     sN, last = cm.time_multiply(lhs, rhs, count, threads)
     return dict(value=round(count / sN, 2), unit="ops/s", cores=threads, kind="port",
                 sample=f"{count} ct x ct + relinearise ops of the C2 workload (16 distinct synthetic pairs cycled), "

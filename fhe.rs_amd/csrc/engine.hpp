@@ -5,6 +5,7 @@
 // this image; the C ABI in fhe_hip.cpp is a thin layer over these classes.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -336,7 +337,16 @@ inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 inline unsigned blocks_for(u64 total, unsigned threads) { return (unsigned)((total + threads - 1) / threads); }
 constexpr unsigned EW_THREADS = 256;
 
-inline unsigned ntt_threads(size_t m) { return (unsigned)std::min<size_t>(1024, std::max<size_t>(64, m / 16)); }
+// Threads per NTT workgroup: one radix-16 group per thread per pass by default.  The
+// FHE_NTT_ELEMS_PER_THREAD environment variable (8/16/32/64) is a tuning knob for experiments.
+inline unsigned ntt_threads(size_t m) {
+    static const size_t ept = [] {
+        const char *e = std::getenv("FHE_NTT_ELEMS_PER_THREAD");
+        size_t v = e ? (size_t)std::atoi(e) : 16;
+        return (v == 8 || v == 16 || v == 32 || v == 64) ? v : (size_t)16;
+    }();
+    return (unsigned)std::min<size_t>(1024, std::max<size_t>(64, m / ept));
+}
 
 template <class K>
 inline void allow_big_lds(K kernel, size_t bytes) {
@@ -579,6 +589,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
         const unsigned th = ntt_threads(kc.n);
         const size_t lds = k::lds_words((uint32_t)kc.n) * sizeof(u64);
         const size_t ept = (kc.n + th - 1) / th;
+        require(ept <= 16, E_ARG, "fused key switch supports at most 16 coefficients per thread");
         switch (ept) {
             case 1: launch_ks_fused<1>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
             case 2: launch_ks_fused<2>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;

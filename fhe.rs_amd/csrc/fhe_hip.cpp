@@ -368,6 +368,7 @@ fhe_status fhe_poly_substitute(const fhe_ctx *ctx, size_t exponent, const uint64
 fhe_status fhe_poly_switch_down_dev(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, size_t batch, void *stream) {
     return guard([&] {
         FHE_POLY_IO_PROLOGUE(ctx);
+        if (!c.next) throw StatusError(FHE_E_NO_MORE_CONTEXT, "NoMoreContext");
         if (batch) {
             need(in, "in");
             need(out, "out");
@@ -740,6 +741,7 @@ fhe_status fhe_bfv_switch_down_dev(const fhe_ctx *ctx, size_t nparts, const uint
     return guard([&] {
         FHE_POLY_IO_PROLOGUE(ctx);
         (void)pe;
+        if (!c.next) throw StatusError(FHE_E_NO_MORE_CONTEXT, "NoMoreContext");
         if (batch && nparts) {
             need(ct, "ct");
             need(out, "out");

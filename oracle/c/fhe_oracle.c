@@ -28,6 +28,26 @@
 typedef unsigned __int128 u128;
 typedef uint64_t u64;
 
+/* Scratch memory: a per-thread bump arena when one is installed (the timed loops install
+ * one so that the CPU baseline does not pay malloc/page-fault costs per call), else malloc. */
+static __thread char *g_arena = 0;
+static __thread size_t g_arena_off = 0, g_arena_cap = 0;
+static void *scratch_alloc(size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (g_arena && g_arena_off + bytes <= g_arena_cap) {
+        void *p = g_arena + g_arena_off;
+        g_arena_off += bytes;
+        return p;
+    }
+    return malloc(bytes);
+}
+static void scratch_free(void *p) {
+    if (g_arena && (char *)p >= g_arena && (char *)p < g_arena + g_arena_cap) return; /* released by mark */
+    free(p);
+}
+static size_t scratch_mark(void) { return g_arena_off; }
+static void scratch_release(size_t mark) { if (g_arena) g_arena_off = mark; }
+
 /* ---------------------------------------------------------------- zq ---- */
 typedef struct {
     u64 p, barrett_hi, barrett_lo;
@@ -312,14 +332,14 @@ static void rns_scale(const orc_scaler *s, const orc_mod *to_mods, const u64 *re
 void orc_poly_scale(const orc_scaler *s, const orc_ctx *from, const orc_ctx *to, const u64 *in, u64 *out,
                     int repr_is_ntt) {
     const u64 n = from->n;
-    orc_mod *to_mods = (orc_mod *)malloc(sizeof(orc_mod) * to->nmod);
+    orc_mod *to_mods = (orc_mod *)scratch_alloc(sizeof(orc_mod) * to->nmod);
     for (u64 i = 0; i < to->nmod; i++) mod_init(&to_mods[i], to->moduli[i]);
     memset(out, 0, sizeof(u64) * to->nmod * n);
     if (s->ncommon > 0) memcpy(out, in, sizeof(u64) * s->ncommon * n);
     if (s->ncommon < to->nmod) {
         u64 *pb = (u64 *)in;
         if (repr_is_ntt) {
-            pb = (u64 *)malloc(sizeof(u64) * from->nmod * n);
+            pb = (u64 *)scratch_alloc(sizeof(u64) * from->nmod * n);
             memcpy(pb, in, sizeof(u64) * from->nmod * n);
             orc_poly_ntt_backward(from, pb);
         }
@@ -327,19 +347,19 @@ void orc_poly_scale(const orc_scaler *s, const orc_ctx *from, const orc_ctx *to,
             rns_scale(s, to_mods, pb + col, n, out + s->ncommon * n + col, n, to->nmod - s->ncommon, s->ncommon);
         if (repr_is_ntt) {
             for (u64 r = s->ncommon; r < to->nmod; r++) orc_ntt_forward(to, r, out + r * n, 0);
-            free(pb);
+            scratch_free(pb);
         }
     }
-    free(to_mods);
+    scratch_free(to_mods);
 }
 
 /* One column through RnsScaler::scale (for fine-grained tests). */
 void orc_rns_scale(const orc_scaler *s, const u64 *to_moduli, const u64 *rests, u64 *out, u64 size,
                    u64 starting_index) {
-    orc_mod *to_mods = (orc_mod *)malloc(sizeof(orc_mod) * s->nto);
+    orc_mod *to_mods = (orc_mod *)scratch_alloc(sizeof(orc_mod) * s->nto);
     for (u64 i = 0; i < s->nto; i++) mod_init(&to_mods[i], to_moduli[i]);
     rns_scale(s, to_mods, rests, 1, out, 1, size, starting_index);
-    free(to_mods);
+    scratch_free(to_mods);
 }
 
 /* ------------------------------------------------------ switch_down ---- */
@@ -408,8 +428,8 @@ void orc_key_switch(const orc_ctx *ct_ctx, const orc_ctx *ksk_ctx, const orc_ksk
     const u64 n = ksk_ctx->n, Lk = ksk_ctx->nmod;
     memset(out0, 0, sizeof(u64) * Lk * n);
     memset(out1, 0, sizeof(u64) * Lk * n);
-    u64 *c2 = (u64 *)malloc(sizeof(u64) * Lk * n);
-    orc_mod *mods = (orc_mod *)malloc(sizeof(orc_mod) * Lk);
+    u64 *c2 = (u64 *)scratch_alloc(sizeof(u64) * Lk * n);
+    orc_mod *mods = (orc_mod *)scratch_alloc(sizeof(orc_mod) * Lk);
     for (u64 j = 0; j < Lk; j++) mod_init(&mods[j], ksk_ctx->moduli[j]);
     for (u64 i = 0; i < k->ndigits; i++) {
         const u64 *row = p + i * n;
@@ -432,8 +452,8 @@ void orc_key_switch(const orc_ctx *ct_ctx, const orc_ctx *ksk_ctx, const orc_ksk
             }
         }
     }
-    free(mods);
-    free(c2);
+    scratch_free(mods);
+    scratch_free(c2);
     (void)ct_ctx;
 }
 
@@ -447,36 +467,37 @@ typedef struct {
 
 /* ops/mul.rs:165-243.  lhs, rhs: [2][L][n] Ntt.  out: [2 or 3][L or L-1][n] Ntt. */
 void orc_bfv_multiply(const orc_mul *m, const u64 *lhs, const u64 *rhs, u64 *out) {
+    const size_t mark = scratch_mark();
     const orc_ctx *b = m->base_ctx, *e = m->mul_ctx;
     const u64 n = b->n, L = b->nmod, K = e->nmod, PL = L * n, PK = K * n;
-    u64 *ext = (u64 *)malloc(sizeof(u64) * 4 * PK);
+    u64 *ext = (u64 *)scratch_alloc(sizeof(u64) * 4 * PK);
     orc_poly_scale(m->extender_lhs, b, e, lhs, ext, 1);
     orc_poly_scale(m->extender_lhs, b, e, lhs + PL, ext + PK, 1);
     orc_poly_scale(m->extender_rhs, b, e, rhs, ext + 2 * PK, 1);
     orc_poly_scale(m->extender_rhs, b, e, rhs + PL, ext + 3 * PK, 1);
     u64 *c00 = ext, *c01 = ext + PK, *c10 = ext + 2 * PK, *c11 = ext + 3 * PK;
-    u64 *t = (u64 *)malloc(sizeof(u64) * 4 * PK);
+    u64 *t = (u64 *)scratch_alloc(sizeof(u64) * 4 * PK);
     u64 *c0 = t, *c1 = t + PK, *c2 = t + 2 * PK, *tmp = t + 3 * PK;
     memcpy(c0, c00, sizeof(u64) * PK); orc_poly_mul(e, c0, c10);
     memcpy(c1, c00, sizeof(u64) * PK); orc_poly_mul(e, c1, c11);
     memcpy(tmp, c01, sizeof(u64) * PK); orc_poly_mul(e, tmp, c10);
     orc_poly_add(e, c1, tmp);
     memcpy(c2, c01, sizeof(u64) * PK); orc_poly_mul(e, c2, c11);
-    u64 *d = (u64 *)malloc(sizeof(u64) * 3 * PL);
+    u64 *d = (u64 *)scratch_alloc(sizeof(u64) * 3 * PL);
     orc_poly_scale(m->down_scaler, e, b, c0, d, 1);
     orc_poly_scale(m->down_scaler, e, b, c1, d + PL, 1);
     orc_poly_scale(m->down_scaler, e, b, c2, d + 2 * PL, 1);
     u64 nparts = 3;
     if (m->rk) {
-        u64 *c2pb = (u64 *)malloc(sizeof(u64) * PL);
+        u64 *c2pb = (u64 *)scratch_alloc(sizeof(u64) * PL);
         memcpy(c2pb, d + 2 * PL, sizeof(u64) * PL);
         orc_poly_ntt_backward(b, c2pb);
-        u64 *r = (u64 *)malloc(sizeof(u64) * 2 * PL);
+        u64 *r = (u64 *)scratch_alloc(sizeof(u64) * 2 * PL);
         orc_key_switch(b, b, m->rk, c2pb, r, r + PL);
         orc_poly_add(b, d, r);
         orc_poly_add(b, d + PL, r + PL);
-        free(r);
-        free(c2pb);
+        scratch_free(r);
+        scratch_free(c2pb);
         nparts = 2;
     }
     if (m->mod_switch) { /* ciphertext.rs:148-161 */
@@ -490,22 +511,23 @@ void orc_bfv_multiply(const orc_mul *m, const u64 *lhs, const u64 *rhs, u64 *out
     } else {
         memcpy(out, d, sizeof(u64) * nparts * PL);
     }
-    free(d);
-    free(t);
-    free(ext);
+    scratch_free(d);
+    scratch_free(t);
+    scratch_free(ext);
+    scratch_release(mark);
 }
 
 /* galois_key.rs:63-86 with the key at the ciphertext level.  ct: [2][L][n] Ntt. */
 void orc_galois_relinearize(const orc_ctx *c, const orc_ksk *k, u64 exponent, const u64 *ct, u64 *out) {
     const u64 PL = c->nmod * c->n;
-    u64 *c2 = (u64 *)malloc(sizeof(u64) * PL), *s0 = (u64 *)malloc(sizeof(u64) * PL);
+    u64 *c2 = (u64 *)scratch_alloc(sizeof(u64) * PL), *s0 = (u64 *)scratch_alloc(sizeof(u64) * PL);
     orc_poly_substitute(c, exponent, ct + PL, c2, 1);
     orc_poly_ntt_backward(c, c2);
     orc_key_switch(c, c, k, c2, out, out + PL);
     orc_poly_substitute(c, exponent, ct, s0, 1);
     orc_poly_add(c, out, s0);
-    free(s0);
-    free(c2);
+    scratch_free(s0);
+    scratch_free(c2);
 }
 
 /* -------------------------------------------------------------- timing ---- */
@@ -534,7 +556,13 @@ double orc_time_multiply(const orc_mul *m, const u64 *lhs, const u64 *rhs, u64 n
 #pragma omp parallel num_threads(threads)
 #endif
     {
-        u64 *out = (u64 *)malloc(sizeof(u64) * 3 * L * n);
+        const size_t cap = (size_t)40 * m->mul_ctx->nmod * n * sizeof(u64) + (1 << 20);
+        char *arena = (char *)malloc(cap);
+        memset(arena, 0, cap);
+        g_arena = arena;
+        g_arena_off = 0;
+        g_arena_cap = cap;
+        u64 *out = (u64 *)scratch_alloc(sizeof(u64) * 3 * L * n);
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif
@@ -543,7 +571,9 @@ double orc_time_multiply(const orc_mul *m, const u64 *lhs, const u64 *rhs, u64 n
             orc_bfv_multiply(m, lhs + pi * CT, rhs + pi * CT, out);
             if ((u64)it == count - 1 && out_last) memcpy(out_last, out, sizeof(u64) * 2 * L * n);
         }
-        free(out);
+        g_arena = 0;
+        g_arena_cap = g_arena_off = 0;
+        free(arena);
     }
     (void)threads;
     return now_s() - t0;

@@ -337,22 +337,30 @@ inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 inline unsigned blocks_for(u64 total, unsigned threads) { return (unsigned)((total + threads - 1) / threads); }
 constexpr unsigned EW_THREADS = 256;
 
-// Threads per NTT workgroup: one radix-16 group per thread per pass by default.  The
-// FHE_NTT_ELEMS_PER_THREAD environment variable (8/16/32/64) is a tuning knob for experiments.
-inline unsigned ntt_threads(size_t m) {
-    static const size_t ept = [] {
-        const char *e = std::getenv("FHE_NTT_ELEMS_PER_THREAD");
-        size_t v = e ? (size_t)std::atoi(e) : 16;
-        return (v == 8 || v == 16 || v == 32 || v == 64) ? v : (size_t)16;
-    }();
-    return (unsigned)std::min<size_t>(1024, std::max<size_t>(64, m / ept));
-}
-
 template <class K>
 inline void allow_big_lds(K kernel, size_t bytes) {
     if (bytes > 48 * 1024)
         FHE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+template <bool INV>
+inline void launch_ntt_lds(const char *name, uint32_t logm, unsigned grid, hipStream_t s, const u64 *in, u64 *out,
+                           const k::RowMap &map, const DevMod *mods, const k::u64x2 *tw, const k::u64x2 *ninv,
+                           uint32_t logn, uint32_t prologue) {
+    const size_t lds = k::lds_words(1u << logm) * sizeof(u64);
+#define FHE_NTT_CASE(LM)                                                                                        \
+    case LM:                                                                                                    \
+        allow_big_lds(k::ntt_kernel<INV, LM>, lds);                                                             \
+        FHE_LAUNCH(name, (k::ntt_kernel<INV, LM>), dim3(grid), dim3(k::ntt_threads_c(LM)), lds, s, in, out, map, \
+                   mods, tw, ninv, logn, prologue);                                                             \
+        break;
+    switch (logm) {
+        FHE_NTT_CASE(3) FHE_NTT_CASE(4) FHE_NTT_CASE(5) FHE_NTT_CASE(6) FHE_NTT_CASE(7) FHE_NTT_CASE(8)
+        FHE_NTT_CASE(9) FHE_NTT_CASE(10) FHE_NTT_CASE(11) FHE_NTT_CASE(12) FHE_NTT_CASE(13) FHE_NTT_CASE(14)
+        default: throw StatusError(E_ARG, "unsupported NTT tile size");
+    }
+#undef FHE_NTT_CASE
 }
 
 // Forward / inverse NTT of `npolys * map.rows` residue rows.  N <= 16384: one LDS-resident
@@ -363,22 +371,15 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     const uint32_t logn = (uint32_t)c.logn;
     const unsigned rows_total = (unsigned)(npolys * map.rows);
     if (logn <= 14) {
-        const size_t lds = k::lds_words((uint32_t)c.n) * sizeof(u64);
-        const unsigned th = ntt_threads(c.n);
-        if (!inverse) {
-            allow_big_lds(k::ntt_kernel<false>, lds);
-            FHE_LAUNCH("ntt_fwd", (k::ntt_kernel<false>), dim3(rows_total), dim3(th), lds, s, in, out, map,
-                       c.dmods(), c.dtw(), c.dninv(), logn, logn, prologue);
-        } else {
-            allow_big_lds(k::ntt_kernel<true>, lds);
-            FHE_LAUNCH("ntt_inv", (k::ntt_kernel<true>), dim3(rows_total), dim3(th), lds, s, in, out, map,
-                       c.dmods(), c.ditw(), c.dninv(), logn, logn, prologue);
-        }
+        if (!inverse)
+            launch_ntt_lds<false>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(), logn,
+                                  prologue);
+        else
+            launch_ntt_lds<true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn,
+                                 prologue);
         return;
     }
     const uint32_t logm = 13, g0 = logn - logm, m = 1u << logm;
-    const size_t lds = k::lds_words(m) * sizeof(u64);
-    const unsigned th = ntt_threads(m);
     const unsigned gth = 256, gblocks = rows_total * (m / gth);
     k::RowMap inplace = map;
     inplace.src_poly_stride = map.dst_poly_stride;
@@ -390,13 +391,11 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
         else
             FHE_LAUNCH("ntt_fwd_global", (k::ntt_global_kernel<false, 3>), dim3(gblocks), dim3(gth), 0, s, in, out,
                        map, c.dmods(), c.dtw(), c.dninv(), logn, prologue);
-        allow_big_lds(k::ntt_kernel<false>, lds);
-        FHE_LAUNCH("ntt_fwd", (k::ntt_kernel<false>), dim3(rows_total << g0), dim3(th), lds, s, out, out, inplace,
-                   c.dmods(), c.dtw(), c.dninv(), logn, logm, (uint32_t)k::PRO_NONE);
+        launch_ntt_lds<false>("ntt_fwd", logm, rows_total << g0, s, out, out, inplace, c.dmods(), c.dtw(), c.dninv(),
+                              logn, (uint32_t)k::PRO_NONE);
     } else {
-        allow_big_lds(k::ntt_kernel<true>, lds);
-        FHE_LAUNCH("ntt_inv", (k::ntt_kernel<true>), dim3(rows_total << g0), dim3(th), lds, s, in, out, map,
-                   c.dmods(), c.ditw(), c.dninv(), logn, logm, prologue);
+        launch_ntt_lds<true>("ntt_inv", logm, rows_total << g0, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn,
+                             prologue);
         if (g0 == 2)
             FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 2>), dim3(gblocks), dim3(gth), 0, s, out, out,
                        inplace, c.dmods(), c.ditw(), c.dninv(), logn, (uint32_t)k::PRO_NONE);
@@ -492,31 +491,50 @@ inline std::unique_ptr<Scaler> scaler_create(const Ctx &from, const Ctx &to, con
     return s;
 }
 
+// RnsScaler::scale over `npolys * N` coefficient columns (register-resident residues: NF >= nfrom).
+inline void launch_scale(const Scaler &sc, const u64 *in, u64 in_stride, u64 *out, u64 out_stride, size_t npolys,
+                         hipStream_t s) {
+    const Ctx &f = *sc.from, &t = *sc.to;
+    const u64 total = (u64)npolys * f.n;
+    if (!total) return;
+    const dim3 grid(blocks_for(total, EW_THREADS)), block(EW_THREADS);
+#define FHE_SCALE_CASE(NF)                                                                                   \
+    FHE_LAUNCH("scale", (k::scale_kernel<NF>), grid, block, 0, s, in, out, in_stride, out_stride, sc.dev,    \
+               t.dmods(), (uint32_t)f.logn, total)
+    if (f.L <= 4) FHE_SCALE_CASE(4);
+    else if (f.L <= 9) FHE_SCALE_CASE(9);
+    else if (f.L <= 17) FHE_SCALE_CASE(17);
+    else if (f.L <= 33) FHE_SCALE_CASE(33);
+    else if (f.L <= 64) FHE_SCALE_CASE(64);
+    else throw StatusError(E_ARG, "RNS scaler supports at most 64 source moduli");
+#undef FHE_SCALE_CASE
+}
+
 // Scaler::scale (M/rq/scaler.rs:55-127) on npolys polynomials.
-inline void scale_polys(const Scaler &sc, const u64 *in, u64 *out, size_t npolys, bool repr_is_ntt, hipStream_t s) {
+// `copy_common = false` leaves rows [0, ncommon) of `out` untouched (callers that read those
+// rows from the source instead, see bfv_mul).
+inline void scale_polys(const Scaler &sc, const u64 *in, u64 *out, size_t npolys, bool repr_is_ntt, hipStream_t s,
+                        bool copy_common = true) {
     const Ctx &f = *sc.from, &t = *sc.to;
     f.need_device();
     if (!npolys) return;
     const u64 in_stride = (u64)f.L * f.n, out_stride = (u64)t.L * t.n;
-    if (sc.ncommon > 0) {
+    if (sc.ncommon > 0 && copy_common) {
         const u64 per = (u64)sc.ncommon * f.n, total = per * npolys;
         FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in,
                    out, in_stride, out_stride, per, total);
     }
     if (sc.ncommon >= t.L) return;
-    const u64 total = (u64)npolys * f.n;
     if (repr_is_ntt) {
         WsGuard pb(npolys * in_stride * sizeof(u64), s);
         launch_ntt(f, true, in, pb.u(), full_map(f, f.L), npolys, k::PRO_NONE, s);
-        FHE_LAUNCH("scale", k::scale_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, pb.u(), out,
-                   in_stride, out_stride, sc.dev, t.dmods(), (uint32_t)f.logn, total);
+        launch_scale(sc, pb.u(), in_stride, out, out_stride, npolys, s);
         k::RowMap m = full_map(t, t.L);
         m.rows = (uint32_t)(t.L - sc.ncommon);
         m.row_begin = (uint32_t)sc.ncommon;
         launch_ntt(t, false, out, out, m, npolys, k::PRO_NONE, s);
     } else {
-        FHE_LAUNCH("scale", k::scale_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in, out,
-                   in_stride, out_stride, sc.dev, t.dmods(), (uint32_t)f.logn, total);
+        launch_scale(sc, in, in_stride, out, out_stride, npolys, s);
     }
 }
 
@@ -565,15 +583,15 @@ inline void ksk_validate(const Ctx &ct_ctx, const Ctx &ksk_ctx, size_t ndigits, 
     }
 }
 
-template <int EPT>
+template <int LOGN>
 inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
-                            const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, unsigned th, size_t lds,
-                            hipStream_t s) {
+                            const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s) {
     const Ctx &kc = *k_.ksk_ctx;
-    allow_big_lds(k::ks_fused_kernel<EPT>, lds);
-    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<EPT>), dim3((unsigned)(npolys * kc.L)), dim3(th), lds, s, p,
-               p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p,
-               kc.dmods(), kc.dtw(), (uint32_t)kc.logn, (uint32_t)k_.ndigits, (uint32_t)kc.L,
+    const size_t lds = k::lds_words(1u << LOGN) * sizeof(u64);
+    allow_big_lds(k::ks_fused_kernel<LOGN>, lds);
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN>), dim3((unsigned)(npolys * kc.L)),
+               dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,
+               k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
                (uint32_t)k_.log_base);
 }
 
@@ -586,17 +604,14 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     kc.need_device();
     if (!npolys) return;
     if (kc.logn <= 14) {
-        const unsigned th = ntt_threads(kc.n);
-        const size_t lds = k::lds_words((uint32_t)kc.n) * sizeof(u64);
-        const size_t ept = (kc.n + th - 1) / th;
-        require(ept <= 16, E_ARG, "fused key switch supports at most 16 coefficients per thread");
-        switch (ept) {
-            case 1: launch_ks_fused<1>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
-            case 2: launch_ks_fused<2>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
-            case 4: launch_ks_fused<4>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
-            case 8: launch_ks_fused<8>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
-            default: launch_ks_fused<16>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, th, lds, s); break;
+#define FHE_KS_CASE(LN) \
+    case LN: launch_ks_fused<LN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s); break;
+        switch (kc.logn) {
+            FHE_KS_CASE(3) FHE_KS_CASE(4) FHE_KS_CASE(5) FHE_KS_CASE(6) FHE_KS_CASE(7) FHE_KS_CASE(8)
+            FHE_KS_CASE(9) FHE_KS_CASE(10) FHE_KS_CASE(11) FHE_KS_CASE(12) FHE_KS_CASE(13) FHE_KS_CASE(14)
+            default: throw StatusError(E_ARG, "unsupported key-switch row size");
         }
+#undef FHE_KS_CASE
         return;
     }
     // Unfused path for rows that do not fit LDS: per digit, lift + NTT into scratch, then MAC.
@@ -701,12 +716,13 @@ inline size_t &chunk_setting() {
     static size_t chunk = 0;
     return chunk;
 }
-inline size_t default_chunk(const Ctx &mulc) {
+inline size_t default_chunk(const Ctx &base, const Ctx &mulc) {
     if (chunk_setting()) return chunk_setting();
-    // keep the per-chunk working set (~11 extended polys) inside the 256 MiB Infinity Cache
-    const size_t ext_poly_bytes = mulc.L * mulc.n * sizeof(u64);
-    size_t c = (160u << 20) / (11 * ext_poly_bytes);
-    return std::max<size_t>(1, std::min<size_t>(c, 256));
+    // The path is integer-issue bound, not HBM bound, so launches are made as
+    // large as a bounded workspace allows (every launch should cover >> 512 workgroup slots).
+    const size_t per_ct = (7 * mulc.L + 7 * base.L) * mulc.n * sizeof(u64);
+    const size_t budget = (size_t)8 << 30;
+    return std::max<size_t>(1, std::min<size_t>(budget / per_ct, 4096));
 }
 
 // Ciphertext::switch_down (F/bfv/ciphertext.rs:148-161): ct [b][nparts][L][N] Ntt -> [b][nparts][L-1][N] Ntt
@@ -717,89 +733,54 @@ inline void bfv_switch_down(const Ctx &c, size_t nparts, const u64 *ct, u64 *out
 }
 
 // Multiplicator::multiply (F/bfv/ops/mul.rs:165-243) on `batch` ciphertext pairs.
+// Workspace per chunk of nb pairs (all slot-major so that every step is ONE launch over
+// nb * {2,3} polynomials):  extL/extR [nb][2][K][N] extended operands,  ten [3][nb][K][N]
+// tensor,  d [3][nb][L][N] down-scaled parts (c0, c1 Ntt; c2 PowerBasis for the key switch).
 inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size_t batch, hipStream_t s) {
     const Ctx &b = *m.base, &e = *m.mulc;
     b.need_device();
     const size_t L = b.L, K = e.L, N = b.n;
     const u64 PL = (u64)L * N, PK = (u64)K * N;
     const size_t parts = m.out_parts();
-    const size_t chunk = std::min(batch, default_chunk(e));
     if (!batch) return;
-    WsGuard ext(chunk * 4 * PK * sizeof(u64), s), ten(chunk * 3 * PK * sizeof(u64), s);
-    WsGuard d(chunk * 3 * PL * sizeof(u64), s);
+    const size_t chunk = std::min(batch, default_chunk(b, e));
+    // the extenders copy the shared prefix rows verbatim; when both share all L rows the tensor
+    // kernel reads those rows from the inputs directly and the copy is skipped
+    const bool skip_copy = m.ext_lhs->ncommon == L && m.ext_rhs->ncommon == L;
+    WsGuard extL(chunk * 2 * PK * sizeof(u64), s), extR(chunk * 2 * PK * sizeof(u64), s);
+    WsGuard ten(chunk * 3 * PK * sizeof(u64), s), d(chunk * 3 * PL * sizeof(u64), s);
     WsGuard pre(m.mod_switch ? chunk * parts * PL * sizeof(u64) : 8, s);
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = std::min(chunk, batch - b0);
         const u64 *l = lhs + b0 * 2 * PL, *r = rhs + b0 * 2 * PL;
-        // EXTEND (mul.rs:192-195): ext[b][0..1] = lhs parts, ext[b][2..3] = rhs parts, K rows each.
-        // Two polys of one ciphertext are `PL` apart in the input and `PK` apart in ext; the
-        // scaler works on [npolys] with fixed strides, so run it per input part.
-        for (int part = 0; part < 2; part++) {
-            // lhs part -> ext slot `part`, rhs part -> ext slot 2 + part
-            struct {
-                const Scaler *sc;
-                const u64 *src;
-                int slot;
-            } jobs[2] = {{m.ext_lhs, l + (u64)part * PL, part}, {m.ext_rhs, r + (u64)part * PL, 2 + part}};
-            for (auto &jb : jobs) {
-                const Scaler &sc = *jb.sc;
-                u64 *dst = ext.u() + (u64)jb.slot * PK;
-                // strided variant of scale_polys: input poly stride 2*PL, output poly stride 4*PK
-                const u64 in_stride = 2 * PL, out_stride = 4 * PK;
-                if (sc.ncommon > 0) {
-                    const u64 per = (u64)sc.ncommon * N, total = per * nb;
-                    FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)),
-                               dim3(EW_THREADS), 0, s, jb.src, dst, in_stride, out_stride, per, total);
-                }
-                if (sc.ncommon < K) {
-                    WsGuard pb(nb * PL * sizeof(u64), s);
-                    k::RowMap im = full_map(b, L);
-                    im.src_poly_stride = in_stride;
-                    im.dst_poly_stride = PL;
-                    launch_ntt(b, true, jb.src, pb.u(), im, nb, k::PRO_NONE, s);
-                    const u64 total = (u64)nb * N;
-                    FHE_LAUNCH("scale", k::scale_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s,
-                               pb.u(), dst, PL, out_stride, sc.dev, e.dmods(), (uint32_t)b.logn, total);
-                    k::RowMap fm = full_map(e, K);
-                    fm.rows = (uint32_t)(K - sc.ncommon);
-                    fm.row_begin = (uint32_t)sc.ncommon;
-                    fm.src_poly_stride = fm.dst_poly_stride = out_stride;
-                    launch_ntt(e, false, dst, dst, fm, nb, k::PRO_NONE, s);
-                }
-            }
-        }
+        // EXTEND (mul.rs:192-195): both parts of every lhs (rhs) ciphertext in one go
+        scale_polys(*m.ext_lhs, l, extL.u(), nb * 2, true, s, !skip_copy);
+        scale_polys(*m.ext_rhs, r, extR.u(), nb * 2, true, s, !skip_copy);
         // TENSOR (mul.rs:198-201)
         {
             const u64 total = (u64)nb * PK;
-            FHE_LAUNCH("tensor", k::tensor_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, ext.u(),
-                       ten.u(), e.dmods(), (uint32_t)K, (uint32_t)e.logn, total);
+            FHE_LAUNCH("tensor", k::tensor_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s,
+                       extL.u(), extR.u(), skip_copy ? l : nullptr, skip_copy ? r : nullptr, ten.u(), e.dmods(),
+                       (uint32_t)K, (uint32_t)L, (uint32_t)L, (uint32_t)e.logn, (u64)nb, total);
         }
-        // DOWN-SCALE (mul.rs:204-206): 3 polys per ciphertext, K -> L rows
         u64 *dst = m.mod_switch ? pre.u() : out + b0 * parts * PL;
         if (m.rk) {
-            // c0, c1 are needed in Ntt form, c2 in PowerBasis (the reference converts c2 back with
-            // an exact inverse NTT, mul.rs:212; skipping NTT(iNTT(x)) = x keeps the same values).
+            // DOWN-SCALE (mul.rs:204-206) to PowerBasis; c0, c1 go back to Ntt, c2 stays in
+            // PowerBasis for the key switch (the reference transforms c2 forward and, at mul.rs:212,
+            // back again; iNTT(NTT(x)) = x exactly, so the values are the same).
             launch_ntt(e, true, ten.u(), ten.u(), full_map(e, K), nb * 3, k::PRO_NONE, s);
-            const u64 total = (u64)nb * 3 * N;
-            FHE_LAUNCH("scale", k::scale_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, ten.u(),
-                       d.u(), PK, PL, m.down->dev, b.dmods(), (uint32_t)b.logn, total);
-            // NTT of c0, c1 (poly index 0,1 of every triple) in place in d
-            k::RowMap fm = full_map(b, L);
-            fm.src_poly_stride = fm.dst_poly_stride = PL;
-            // polys are [nb][3]; transform slots 0 and 1 of each triple: two launches with stride 3*PL
-            for (int slot = 0; slot < 2; slot++) {
-                k::RowMap sm = fm;
-                sm.src_poly_stride = sm.dst_poly_stride = 3 * PL;
-                launch_ntt(b, false, d.u() + (u64)slot * PL, d.u() + (u64)slot * PL, sm, nb, k::PRO_NONE, s);
-            }
-            // RELINEARIZE (mul.rs:211-227): (c0, c1) += key_switch(c2)
-            const Ksk &rk = *m.rk;
-            const long iters = rk.ksk_ctx->niterations_to(b);
-            (void)iters;
-            key_switch_add(rk, d.u() + 2 * PL, 3 * PL, d.u(), d.u() + PL, 3 * PL, dst, dst + PL, 2 * PL, nb, s);
+            launch_scale(*m.down, ten.u(), PK, d.u(), PL, nb * 3, s);
+            launch_ntt(b, false, d.u(), d.u(), full_map(b, L), nb * 2, k::PRO_NONE, s);
+            // RELINEARIZE (mul.rs:211-227): (c0, c1) += key_switch(c2), written to the output layout
+            key_switch_add(*m.rk, d.u() + 2 * nb * PL, PL, d.u(), d.u() + nb * PL, PL, dst, dst + PL, 2 * PL, nb, s);
         } else {
-            // no relinearisation: all three parts are returned in Ntt form
-            scale_polys(*m.down, ten.u(), dst, nb * 3, true, s);
+            // no relinearisation: three Ntt parts, slot-major scratch -> [b][3][L][N]
+            scale_polys(*m.down, ten.u(), d.u(), nb * 3, true, s);
+            for (size_t slot = 0; slot < 3; slot++) {
+                const u64 total = (u64)nb * PL;
+                FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0,
+                           s, d.u() + slot * nb * PL, dst + slot * PL, PL, 3 * PL, PL, total);
+            }
         }
         if (m.mod_switch) bfv_switch_down(b, parts, pre.u(), out + b0 * parts * (PL - N), nb, s);
     }

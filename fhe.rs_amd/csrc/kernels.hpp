@@ -50,35 +50,91 @@ FHE_HD uint32_t lds_words(uint32_t n) { return n + (n >> 4) + 2; }
 
 constexpr int GMAX = 4;  // radix-16: up to four butterfly stages per LDS round trip
 
+// A wave-uniform value moved to a scalar register so that table addresses derived from it are
+// scalar and the twiddle loads become s_load (no VGPRs, no per-lane address math).
+// Compiler scheduling fence: keeps a batch of loads (and the registers they pin) from being
+// hoisted across it.  No instruction is emitted.
+__device__ __forceinline__ void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// Makes a per-lane value opaque to loop-invariant code motion: address arithmetic derived from
+// it is recomputed per iteration (a few integer ops) instead of being hoisted and spilled.
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
+#endif
+}
+
+// ------------------------------------------------------------------ tile geometry ----
+// A tile of M = 2^LOGM coefficients is processed by T threads; every radix pass handles groups
+// of 2^G coefficients per thread.  NTT: 16 coefficients per thread (one radix-16 group);
+// key switch: 8 per thread (leaves registers for the two accumulator sets).
+constexpr int ntt_threads_c(int logm) { return (1 << logm) / 16 > 64 ? ((1 << logm) / 16 > 1024 ? 1024 : (1 << logm) / 16) : 64; }
+constexpr int KS_GMAX = 3;  // radix-8 passes inside the key switch: room for the accumulators
+constexpr int ks_threads_c(int logn) { return (1 << logn) / 8 > 64 ? ((1 << logn) / 8 > 1024 ? 1024 : (1 << logn) / 8) : 64; }
+// 16-byte chunks per thread (0: tile smaller than one chunk per thread -> scalar loop)
+constexpr int tile_chunks_c(int logm, int threads) { return (1 << logm) >= 2 * threads ? (1 << logm) / (2 * threads) : 0; }
+// pass plan: NP = ceil(LOGM / GMAX) passes of BASE or BASE+1 stages
+constexpr int plan_np(int logm, int gmax) { return (logm + gmax - 1) / gmax; }
+constexpr int plan_base(int logm, int gmax) { return logm / plan_np(logm, gmax); }
+constexpr int plan_rem(int logm, int gmax) { return logm % plan_np(logm, gmax); }
+
 // ---------------------------------------------------------------- forward passes ----
-// Stages [s0, s0+G) of the size-(1<<logm) Cooley-Tukey transform held in `lds`.
+// Stages [S0, S0+G) of the size-2^LOGM Cooley-Tukey transform held in `lds`.
 // A group = 2^G elements {base + e*lo_count}; all G stages stay in registers.
 // Twiddle of (stage st, block i) is tw[(kbase << st) + i]  (kbase = 1 for a whole row;
 // (2^G0 + sub) when this LDS tile is sub-block `sub` after G0 global stages).
-template <int G>
-__device__ __forceinline__ void fwd_pass(u64 *lds, uint32_t logm, uint32_t s0, const u64x2 *tw, uint32_t kbase,
-                                         u64 p, u64 p2, uint32_t tid, uint32_t nthreads) {
+// UNIFORM (64 consecutive groups share the block index, i.e. lo_bits >= 6): the twiddles are
+// wave-uniform and come through the scalar cache.  Otherwise all 2^G - 1 twiddles of a group
+// are fetched up front, one batch of loads in flight instead of a dependent load per stage.
+template <int G, int LOGM, int S0, int T>
+__device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, u64 p, u64 p2,
+                                         uint32_t tid) {
     constexpr uint32_t R = 1u << G;
-    const uint32_t lo_bits = logm - s0 - G;
-    const uint32_t ngroups = 1u << (logm - G);
-    for (uint32_t grp = tid; grp < ngroups; grp += nthreads) {
+    constexpr uint32_t lo_bits = LOGM - S0 - G;
+    constexpr uint32_t ngroups = 1u << (LOGM - G);
+    constexpr bool UNIFORM = lo_bits >= 6;
+#pragma unroll
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += T) {
+        const uint32_t grp = g0 + tid;
+        if (ngroups < T && grp >= ngroups) break;
         const uint32_t lo = grp & ((1u << lo_bits) - 1);
-        const uint32_t hi = grp >> lo_bits;
-        const uint32_t base = (hi << (logm - s0)) + lo;
+        uint32_t hi = grp >> lo_bits;
+        if (UNIFORM) hi = wave_uniform(hi);
+        const uint32_t base = ((grp >> lo_bits) << (LOGM - S0)) + lo;
+        u64x2 w[UNIFORM ? 1 : R - 1];
+        if (!UNIFORM) {
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const uint32_t kst = (kbase << (S0 + u)) + (hi << u);
+#pragma unroll
+                for (uint32_t blk = 0; blk < (1u << u); blk++) w[UNIFORM ? 0 : (1u << u) - 1 + blk] = tw[kst + blk];
+            }
+        }
         u64 x[R];
 #pragma unroll
         for (uint32_t e = 0; e < R; e++) x[e] = lds[padi(base + (e << lo_bits))];
 #pragma unroll
         for (int u = 0; u < G; u++) {
             const uint32_t half = R >> (u + 1);
-            const uint32_t kst = (kbase << (s0 + u)) + (hi << u);
+            const uint32_t kst = (kbase << (S0 + u)) + (hi << u);
 #pragma unroll
             for (uint32_t blk = 0; blk < (1u << u); blk++) {
-                const u64x2 w = tw[kst + blk];
+                const u64x2 wv = UNIFORM ? tw[kst + blk] : w[UNIFORM ? 0 : (1u << u) - 1 + blk];
 #pragma unroll
                 for (uint32_t j = 0; j < half; j++) {
                     const uint32_t a = blk * 2 * half + j;
-                    fwd_butterfly(x[a], x[a + half], w.x, w.y, p, p2);
+                    fwd_butterfly(x[a], x[a + half], wv.x, wv.y, p, p2);
                 }
             }
         }
@@ -87,93 +143,139 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, uint32_t logm, uint32_t s0, c
     }
 }
 
-// All stages of a size-(1<<logm) forward transform on an LDS tile (values < 4p on exit).
-__device__ __forceinline__ void ntt_fwd_lds(u64 *lds, uint32_t logm, const u64x2 *tw, uint32_t kbase, u64 p,
-                                            u64 p2, uint32_t tid, uint32_t nthreads) {
-    const uint32_t npass = (logm + GMAX - 1) / GMAX;
-    const uint32_t basec = logm / npass, rem = logm % npass;
-    uint32_t s0 = 0;
-    for (uint32_t pass = 0; pass < npass; pass++) {
-        const uint32_t g = basec + (pass < rem ? 1 : 0);
-        switch (g) {
-            case 1: fwd_pass<1>(lds, logm, s0, tw, kbase, p, p2, tid, nthreads); break;
-            case 2: fwd_pass<2>(lds, logm, s0, tw, kbase, p, p2, tid, nthreads); break;
-            case 3: fwd_pass<3>(lds, logm, s0, tw, kbase, p, p2, tid, nthreads); break;
-            default: fwd_pass<4>(lds, logm, s0, tw, kbase, p, p2, tid, nthreads); break;
-        }
-        s0 += g;
+// All stages of a size-2^LOGM forward transform on an LDS tile (values < 4p on exit); the
+// pass plan is resolved at compile time.  Early passes (scalar twiddles) take the wider radix.
+template <int LOGM, int T, int GM = GMAX, int PASS = 0, int S0 = 0>
+__device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, u64 p, u64 p2,
+                                            uint32_t tid) {
+    if constexpr (PASS < plan_np(LOGM, GM)) {
+        constexpr int G = plan_base(LOGM, GM) + (PASS < plan_rem(LOGM, GM) ? 1 : 0);
+        fwd_pass<G, LOGM, S0, T>(lds, tw, kbase, p, p2, tid);
         __syncthreads();
+        ntt_fwd_lds<LOGM, T, GM, PASS + 1, S0 + G>(lds, tw, kbase, p, p2, tid);
     }
 }
 
 // ---------------------------------------------------------------- inverse passes ----
-// Stages [v0, v0+G) (half-lengths 2^v0 .. 2^(v0+G-1)) of the Gentleman-Sande transform.
+// Stages [V0, V0+G) (half-lengths 2^V0 .. 2^(V0+G-1)) of the Gentleman-Sande transform.
 // Twiddle of (stage v, block i) is itw[koff(v) + i], koff(v) = N - (N >> v) + sub*(M >> (v+1)).
-template <int G>
-__device__ __forceinline__ void inv_pass(u64 *lds, uint32_t logm, uint32_t v0, const u64x2 *itw, uint32_t logn,
-                                         uint32_t sub, u64 p, u64 p2, uint32_t tid, uint32_t nthreads) {
+template <int G, int LOGM, int V0, int T>
+__device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub, u64 p,
+                                         u64 p2, uint32_t tid) {
     constexpr uint32_t R = 1u << G;
-    const uint32_t ngroups = 1u << (logm - G);
+    constexpr uint32_t ngroups = 1u << (LOGM - G);
+    constexpr bool UNIFORM = V0 >= 6;
     const uint32_t n = 1u << logn;
-    for (uint32_t grp = tid; grp < ngroups; grp += nthreads) {
-        const uint32_t lo = grp & ((1u << v0) - 1);
-        const uint32_t hi = grp >> v0;
-        const uint32_t base = (hi << (v0 + G)) + lo;
+#pragma unroll
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += T) {
+        const uint32_t grp = g0 + tid;
+        if (ngroups < T && grp >= ngroups) break;
+        const uint32_t lo = grp & ((1u << V0) - 1);
+        uint32_t hi = grp >> V0;
+        if (UNIFORM) hi = wave_uniform(hi);
+        const uint32_t base = ((grp >> V0) << (V0 + G)) + lo;
+        u64x2 z[UNIFORM ? 1 : R - 1];
+        if (!UNIFORM) {
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const uint32_t nblk = R >> (u + 1);
+                const uint32_t kst = n - (n >> (V0 + u)) + (sub << (LOGM - (V0 + u) - 1)) + hi * nblk;
+#pragma unroll
+                for (uint32_t blk = 0; blk < nblk; blk++) z[UNIFORM ? 0 : R - 2 * nblk + blk] = itw[kst + blk];
+            }
+        }
         u64 x[R];
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++) x[e] = lds[padi(base + (e << v0))];
+        for (uint32_t e = 0; e < R; e++) x[e] = lds[padi(base + (e << V0))];
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            const uint32_t v = v0 + u;
             const uint32_t nblk = R >> (u + 1);
-            const uint32_t kst = n - (n >> v) + (sub << (logm - v - 1)) + hi * nblk;
+            const uint32_t kst = n - (n >> (V0 + u)) + (sub << (LOGM - (V0 + u) - 1)) + hi * nblk;
 #pragma unroll
             for (uint32_t blk = 0; blk < nblk; blk++) {
-                const u64x2 z = itw[kst + blk];
+                const u64x2 zv = UNIFORM ? itw[kst + blk] : z[UNIFORM ? 0 : R - 2 * nblk + blk];
 #pragma unroll
                 for (uint32_t j = 0; j < (1u << u); j++) {
                     const uint32_t a = blk * (2u << u) + j;
-                    inv_butterfly(x[a], x[a + (1u << u)], z.x, z.y, p, p2);
+                    inv_butterfly(x[a], x[a + (1u << u)], zv.x, zv.y, p, p2);
                 }
             }
         }
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++) lds[padi(base + (e << v0))] = x[e];
+        for (uint32_t e = 0; e < R; e++) lds[padi(base + (e << V0))] = x[e];
     }
 }
 
-__device__ __forceinline__ void ntt_inv_lds(u64 *lds, uint32_t logm, const u64x2 *itw, uint32_t logn,
-                                            uint32_t sub, u64 p, u64 p2, uint32_t tid, uint32_t nthreads) {
-    const uint32_t npass = (logm + GMAX - 1) / GMAX;
-    const uint32_t basec = logm / npass, rem = logm % npass;
-    uint32_t v0 = 0;
-    for (uint32_t pass = 0; pass < npass; pass++) {
-        const uint32_t g = basec + (pass < rem ? 1 : 0);
-        switch (g) {
-            case 1: inv_pass<1>(lds, logm, v0, itw, logn, sub, p, p2, tid, nthreads); break;
-            case 2: inv_pass<2>(lds, logm, v0, itw, logn, sub, p, p2, tid, nthreads); break;
-            case 3: inv_pass<3>(lds, logm, v0, itw, logn, sub, p, p2, tid, nthreads); break;
-            default: inv_pass<4>(lds, logm, v0, itw, logn, sub, p, p2, tid, nthreads); break;
-        }
-        v0 += g;
+// Late passes (scalar twiddles) take the wider radix.
+template <int LOGM, int T, int PASS = 0, int V0 = 0>
+__device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
+                                            u64 p, u64 p2, uint32_t tid) {
+    if constexpr (PASS < plan_np(LOGM, GMAX)) {
+        constexpr int G = plan_base(LOGM, GMAX) + (PASS >= plan_np(LOGM, GMAX) - plan_rem(LOGM, GMAX) ? 1 : 0);
+        inv_pass<G, LOGM, V0, T>(lds, itw, logn, sub, p, p2, tid);
         __syncthreads();
+        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G>(lds, itw, logn, sub, p, p2, tid);
+    }
+}
+
+// ------------------------------------------------------------- tile load / store ----
+// Thread t owns the 16-byte chunks {c*T + t}, c < CH, of the M-element tile (coalesced 16 B
+// per lane).  CH > 0: all CH loads are issued before the first LDS write (one latency, not
+// CH).  CH == 0: scalar strided loop for tiles smaller than 2*T (tiny test sizes).
+template <int CH, int M, int T, class F>
+__device__ __forceinline__ void tile_to_lds(u64 *lds, const u64 *__restrict__ src, uint32_t tid, F f) {
+    if constexpr (CH > 0) {
+        const u64x2 *s2 = reinterpret_cast<const u64x2 *>(src);
+        u64x2 v[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) v[c] = s2[c * T + tid];
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t i = 2 * (c * T + tid);
+            lds[padi(i)] = f(v[c].x);
+            lds[padi(i + 1)] = f(v[c].y);
+        }
+    } else {
+        for (uint32_t i = tid; i < M; i += T) lds[padi(i)] = f(src[i]);
+    }
+}
+template <int CH, int M, int T, class F>
+__device__ __forceinline__ void lds_to_tile(const u64 *lds, u64 *__restrict__ dst, uint32_t tid, F f) {
+    if constexpr (CH > 0) {
+        u64x2 *d2 = reinterpret_cast<u64x2 *>(dst);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t i = 2 * (c * T + tid);
+            u64x2 v;
+            v.x = f(lds[padi(i)]);
+            v.y = f(lds[padi(i + 1)]);
+            d2[c * T + tid] = v;
+        }
+    } else {
+        for (uint32_t i = tid; i < M; i += T) dst[i] = f(lds[padi(i)]);
     }
 }
 
 // ------------------------------------------------------------------- NTT kernel ----
-// One workgroup per (row, sub-block).  grid.x = npolys * map.rows * nsub, nsub = 2^(logn-logm).
-// logm == logn: whole row in LDS (N <= 16384).  logm < logn: this is the LDS half of the
-// two-kernel transform for N = 32768 (ntt_global_kernel does the other logn-logm stages).
-//   forward: canonical output (reduce3, native.rs:238-246) unless `lazy_out`
-//   inverse: multiplies by N^-1 (Shoup) when logm == logn (native.rs:229-232)
-template <bool INVERSE>
-__global__ void ntt_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map,
-                           const DevMod *__restrict__ mods, const u64x2 *__restrict__ tw,
-                           const u64x2 *__restrict__ ninv, uint32_t logn, uint32_t logm, uint32_t prologue) {
+// One workgroup (ntt_threads_c(LOGM) threads) per (row, sub-block).
+// grid.x = npolys * map.rows * nsub, nsub = 2^(logn - LOGM).
+// LOGM == logn: whole row in LDS (N <= 16384).  LOGM < logn: this is the LDS half of the
+// two-kernel transform for N >= 32768 (ntt_global_kernel does the other logn-LOGM stages).
+//   forward: canonical output (reduce3, native.rs:238-246)
+//   inverse: multiplies by N^-1 (Shoup) when LOGM == logn (native.rs:229-232)
+// Register budget 128 VGPRs = 4 waves/SIMD, which is what the LDS footprint allows anyway
+// (N = 8192: 68 KiB/workgroup -> 2 workgroups of 8 waves per CU).
+template <bool INVERSE, int LOGM>
+__global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
+    ntt_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map, const DevMod *__restrict__ mods,
+               const u64x2 *__restrict__ tw, const u64x2 *__restrict__ ninv, uint32_t logn, uint32_t prologue) {
     FHE_DYN_SMEM(u64, lds);
-    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
-    const uint32_t n = 1u << logn, m = 1u << logm;
-    const uint32_t nsub = 1u << (logn - logm);
+    constexpr int T = ntt_threads_c(LOGM);
+    constexpr int M = 1 << LOGM;
+    constexpr int CH = tile_chunks_c(LOGM, T);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = 1u << logn;
+    const uint32_t nsub = 1u << (logn - LOGM);
     const uint32_t sub = blockIdx.x % nsub;
     const uint32_t rowb = blockIdx.x / nsub;
     const uint32_t poly = rowb / map.rows;
@@ -182,26 +284,25 @@ __global__ void ntt_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, Ro
     const DevMod md = mods[mi];
     const u64 p = md.p, p2 = md.p2;
     const u64 *src = in + (u64)poly * map.src_poly_stride +
-                     (u64)(map.src_row_fixed >= 0 ? (uint32_t)map.src_row_fixed : r) * n + (u64)sub * m;
-    u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * n + (u64)sub * m;
+                     (u64)(map.src_row_fixed >= 0 ? (uint32_t)map.src_row_fixed : r) * n + (u64)sub * M;
+    u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * n + (u64)sub * M;
     const u64x2 *twr = tw + (u64)mi * n;
 
-    for (uint32_t i = tid; i < m; i += nthreads) {
-        u64 v = src[i];
-        if (prologue == PRO_REDUCE) v = reduce_u64(v, md);
-        lds[padi(i)] = v;
-    }
+    if (prologue == PRO_REDUCE)
+        tile_to_lds<CH, M, T>(lds, src, tid, [&](u64 v) { return reduce_u64(v, md); });
+    else
+        tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
     __syncthreads();
     if (!INVERSE) {
-        ntt_fwd_lds(lds, logm, twr, nsub + sub, p, p2, tid, nthreads);
-        for (uint32_t i = tid; i < m; i += nthreads) dst[i] = csub(csub(lds[padi(i)], p2), p);
+        ntt_fwd_lds<LOGM, T>(lds, twr, nsub + sub, p, p2, tid);
+        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub(csub(v, p2), p); });
     } else {
-        ntt_inv_lds(lds, logm, twr, logn, sub, p, p2, tid, nthreads);
-        if (logm == logn) {
+        ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, p, p2, tid);
+        if (logn == LOGM) {
             const u64x2 ni = ninv[mi];
-            for (uint32_t i = tid; i < m; i += nthreads) dst[i] = mul_shoup(lds[padi(i)], ni.x, ni.y, p);
+            lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return mul_shoup(v, ni.x, ni.y, p); });
         } else {
-            for (uint32_t i = tid; i < m; i += nthreads) dst[i] = lds[padi(i)];  // < 2p, finished by global pass
+            lds_to_tile<CH, M, T>(lds, dst, tid, [](u64 v) { return v; });  // < 2p, global pass finishes
         }
     }
 }
@@ -231,10 +332,10 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
     const u64x2 *twr = tw + (u64)mi * n;
     u64 x[R];
 #pragma unroll
-    for (uint32_t e = 0; e < R; e++) {
-        u64 v = src[lo + e * m];
-        if (prologue == PRO_REDUCE) v = reduce_u64(v, md);
-        x[e] = v;
+    for (uint32_t e = 0; e < R; e++) x[e] = src[lo + e * m];
+    if (prologue == PRO_REDUCE) {
+#pragma unroll
+        for (uint32_t e = 0; e < R; e++) x[e] = reduce_u64(x[e], md);
     }
     if (!INVERSE) {
 #pragma unroll
@@ -279,60 +380,94 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
 // into per-thread register accumulators; the key streams from L2/MALL (shared by the batch).
 // A non-null addend0/addend1 is added to the respective output (fused relinearisation add,
 // F/bfv/ops/mul.rs:224-225; rotation adds substitute(c0) to c0 only); canonical outputs.
-// Thread t owns coefficients {t + e*nthreads}, EPT = ceil(N / nthreads) of them.
-template <int EPT>
-__global__ void ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0,
-                                u64 *__restrict__ out1, u64 out_poly_stride, const u64 *__restrict__ addend0,
-                                const u64 *__restrict__ addend1, u64 addend_poly_stride,
-                                const u64 *__restrict__ k0, const u64 *__restrict__ k0s,
-                                const u64 *__restrict__ k1, const u64 *__restrict__ k1s,
-                                const DevMod *__restrict__ mods, const u64x2 *__restrict__ tw, uint32_t logn,
-                                uint32_t ndigits, uint32_t lk, uint32_t digit_shift_bits) {
+// ks_threads_c(LOGN) threads; thread t owns the 16-byte chunks {c*T + t}, c < CH (or the single
+// coefficient t when the row is smaller than one chunk per thread).
+template <int LOGN>
+__global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
+    ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
+                    u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
+                    u64 addend_poly_stride, const u64 *__restrict__ k0, const u64 *__restrict__ k0s,
+                    const u64 *__restrict__ k1, const u64 *__restrict__ k1s, const DevMod *__restrict__ mods,
+                    const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk, uint32_t digit_shift_bits) {
     FHE_DYN_SMEM(u64, lds);
-    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
-    const uint32_t n = 1u << logn;
+    constexpr int T = ks_threads_c(LOGN);
+    constexpr int N = 1 << LOGN;
+    constexpr int CH = tile_chunks_c(LOGN, T);
+    constexpr int NE = CH > 0 ? 2 * CH : 1;  // coefficients owned by a thread
+    const uint32_t tid0 = threadIdx.x;
     const uint32_t j = blockIdx.x % lk, b = blockIdx.x / lk;
     const DevMod md = mods[j];
     const u64 p = md.p, p2 = md.p2;
-    const u64x2 *twr = tw + (u64)j * n;
-    u64 acc0[EPT], acc1[EPT];
+    const u64x2 *twr = tw + (u64)j * N;
+    u64 acc0[NE], acc1[NE];
 #pragma unroll
-    for (int e = 0; e < EPT; e++) acc0[e] = acc1[e] = 0;
+    for (int e = 0; e < NE; e++) acc0[e] = acc1[e] = 0;
     for (uint32_t i = 0; i < ndigits; i++) {
+        const uint32_t tid = opaque(tid0);
         // digit_shift_bits == 0: digit i is residue row i of p (RNS decomposition, :256-268).
         // otherwise: base-2^bits digits of the single row 0 (key_switch_decomposition, :323-362).
-        const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * n);
-        for (uint32_t x = tid; x < n; x += nthreads) {
-            u64 v = src[x];
-            if (digit_shift_bits) v = (v >> (i * digit_shift_bits)) & ((1ull << digit_shift_bits) - 1);
-            lds[padi(x)] = reduce_u64(v, md);
-        }
+        const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N);
+        const uint32_t sh = i * digit_shift_bits;
+        const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+        tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return reduce_u64((v >> sh) & mask, md); });
         __syncthreads();
-        ntt_fwd_lds(lds, logn, twr, 1, p, p2, tid, nthreads);
-        const u64 koff = ((u64)i * lk + j) * n;
+        ntt_fwd_lds<LOGN, T, KS_GMAX>(lds, twr, 1, p, p2, tid);
+        const u64 koff = ((u64)i * lk + j) * N;
+        if constexpr (CH > 0) {
+            const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
+            const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
 #pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            const uint32_t x = tid + e * nthreads;
-            if (x < n) {
-                const u64 v = lds[padi(x)];  // < 4p: Shoup multiplication accepts any u64
-                acc0[e] = csub(acc0[e] + mul_shoup_lazy(v, k0[koff + x], k0s[koff + x], p), p2);
-                acc1[e] = csub(acc1[e] + mul_shoup_lazy(v, k1[koff + x], k1s[koff + x], p), p2);
+            for (int c = 0; c < CH; c++) {
+                const uint32_t ci = c * T + tid;
+                const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+                const u64 vx = lds[padi(2 * ci)], vy = lds[padi(2 * ci + 1)];  // < 4p: Shoup accepts any u64
+                acc0[2 * c] = csub(acc0[2 * c] + mul_shoup_lazy(vx, q0.x, q0s.x, p), p2);
+                acc0[2 * c + 1] = csub(acc0[2 * c + 1] + mul_shoup_lazy(vy, q0.y, q0s.y, p), p2);
+                acc1[2 * c] = csub(acc1[2 * c] + mul_shoup_lazy(vx, q1.x, q1s.x, p), p2);
+                acc1[2 * c + 1] = csub(acc1[2 * c + 1] + mul_shoup_lazy(vy, q1.y, q1s.y, p), p2);
+                if (c & 1) sched_fence();  // at most two chunks of key loads (32 VGPRs) in flight
             }
+        } else if (tid < N) {
+            const u64 v = lds[padi(tid)];
+            acc0[0] = csub(acc0[0] + mul_shoup_lazy(v, k0[koff + tid], k0s[koff + tid], p), p2);
+            acc1[0] = csub(acc1[0] + mul_shoup_lazy(v, k1[koff + tid], k1s[koff + tid], p), p2);
         }
         __syncthreads();
     }
-    const u64 ooff = (u64)b * out_poly_stride + (u64)j * n;
-    const u64 aoff = (u64)b * addend_poly_stride + (u64)j * n;
+    const uint32_t tid = tid0;
+    const u64 ooff = (u64)b * out_poly_stride + (u64)j * N;
+    const u64 aoff = (u64)b * addend_poly_stride + (u64)j * N;
+    if constexpr (CH > 0) {
+        u64x2 *o0 = reinterpret_cast<u64x2 *>(out0 + ooff), *o1 = reinterpret_cast<u64x2 *>(out1 + ooff);
+        const u64x2 *d0 = reinterpret_cast<const u64x2 *>(addend0 ? addend0 + aoff : nullptr);
+        const u64x2 *d1 = reinterpret_cast<const u64x2 *>(addend1 ? addend1 + aoff : nullptr);
 #pragma unroll
-    for (int e = 0; e < EPT; e++) {
-        const uint32_t x = tid + e * nthreads;
-        if (x < n) {
-            u64 r0 = csub(acc0[e], p), r1 = csub(acc1[e], p);
-            if (addend0) r0 = add_mod(r0, addend0[aoff + x], p);
-            if (addend1) r1 = add_mod(r1, addend1[aoff + x], p);
-            out0[ooff + x] = r0;
-            out1[ooff + x] = r1;
+        for (int c = 0; c < CH; c++) {
+            const uint32_t ci = c * T + tid;
+            u64x2 r0, r1;
+            r0.x = csub(acc0[2 * c], p);
+            r0.y = csub(acc0[2 * c + 1], p);
+            r1.x = csub(acc1[2 * c], p);
+            r1.y = csub(acc1[2 * c + 1], p);
+            if (d0) {
+                const u64x2 a = d0[ci];
+                r0.x = add_mod(r0.x, a.x, p);
+                r0.y = add_mod(r0.y, a.y, p);
+            }
+            if (d1) {
+                const u64x2 a = d1[ci];
+                r1.x = add_mod(r1.x, a.x, p);
+                r1.y = add_mod(r1.y, a.y, p);
+            }
+            o0[ci] = r0;
+            o1[ci] = r1;
         }
+    } else if (tid < N) {
+        u64 r0 = csub(acc0[0], p), r1 = csub(acc1[0], p);
+        if (addend0) r0 = add_mod(r0, addend0[aoff + tid], p);
+        if (addend1) r1 = add_mod(r1, addend1[aoff + tid], p);
+        out0[ooff + tid] = r0;
+        out1[ooff + tid] = r1;
     }
 }
 
@@ -385,6 +520,9 @@ struct ScalerDev {
 // y = -v*gamma (+/- w) + sum_j r_j*omega_j only matters mod q (the reference ends with
 // reduce_u128), so it is kept lazily in [0, 2q) in one word.
 // in: [npolys][nfrom][N] PowerBasis; out: rows [ncommon, nto) of [npolys][nto][N].
+// NF >= nfrom: the column's residues are loaded once, together, into registers (coalesced
+// along N; one batch of loads in flight); all scaler constants are wave-uniform scalar loads.
+template <int NF>
 __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,
                              u64 out_poly_stride, ScalerDev s, const DevMod *__restrict__ to_mods, uint32_t logn,
                              u64 total) {
@@ -393,11 +531,15 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
     const uint32_t n = 1u << logn;
     const uint32_t col = (uint32_t)(gid & (n - 1));
     const u64 poly = gid >> logn;
-    const u64 *rests = in + poly * in_poly_stride + col;
+    const u64 *src = in + poly * in_poly_stride + col;
+    u64 rests[NF];
+#pragma unroll
+    for (int i = 0; i < NF; i++) rests[i] = (uint32_t)i < s.nfrom ? src[(u64)i * n] : 0;
 
     U256 sum = {0, 0, 0, 0};
-    for (uint32_t i = 0; i < s.nfrom; i++)
-        u256_mac_64x128(sum, rests[(u64)i * n], s.theta_garner_lo[i], s.theta_garner_hi[i], false);
+#pragma unroll
+    for (int i = 0; i < NF; i++)
+        if ((uint32_t)i < s.nfrom) u256_mac_64x128(sum, rests[i], s.theta_garner_lo[i], s.theta_garner_hi[i], false);
     u64 vlo, vhi;
     u256_shr_lo128(sum, s.shift - 1, vlo, vhi);
     {  // v = div_ceil(v, 2)
@@ -411,9 +553,10 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
     bool w_sign = false;
     if (!s.is_one) {
         U256 t = {0, 0, 0, 0};
-        for (uint32_t i = 0; i < s.nfrom; i++)
-            u256_mac_64x128(t, rests[(u64)i * n], s.theta_omega_lo[i], s.theta_omega_hi[i],
-                            s.theta_omega_sign[i] != 0);
+#pragma unroll
+        for (int i = 0; i < NF; i++)
+            if ((uint32_t)i < s.nfrom)
+                u256_mac_64x128(t, rests[i], s.theta_omega_lo[i], s.theta_omega_hi[i], s.theta_omega_sign[i] != 0);
         // t -/+= v * theta_gamma  (128 x 128 -> 256 wrapping): low word then high word << 64
         const bool neg = !s.theta_gamma_sign;
         u256_mac_64x128(t, vlo, s.theta_gamma_lo, s.theta_gamma_hi, neg);
@@ -450,10 +593,10 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
         if (!s.is_one) {
             const u64 wi = reduce_u128(whi, wlo, q);  // [0, q)
             y = csub(y + (w_sign ? q.p2 - wi : wi), q.p2);
-            y = csub(y, q.p2);
         }
-        for (uint32_t i = 0; i < s.nfrom; i++)
-            y = csub(y + mul_shoup_lazy(rests[(u64)i * n], om[i], oms[i], q.p), q.p2);
+#pragma unroll
+        for (int i = 0; i < NF; i++)
+            if ((uint32_t)i < s.nfrom) y = csub(y + mul_shoup_lazy(rests[i], om[i], oms[i], q.p), q.p2);
         o[(u64)jt * n] = csub(y, q.p);
     }
 }
@@ -534,21 +677,38 @@ __global__ void mul_shoup_kernel(u64 *__restrict__ a, const u64 *__restrict__ b,
     const u64 p = mods[(gid >> logn) % nmod].p;
     a[gid] = mul_shoup(a[gid], b[gid], bs[gid], p);
 }
-// Tensor step of Multiplicator::multiply (F/bfv/ops/mul.rs:198-201) on extended polys:
-// ext [npolys][4][K][N] = (c00, c01, c10, c11) -> t [npolys][3][K][N] = (c00*c10, c00*c11 + c01*c10, c01*c11).
-__global__ void tensor_kernel(const u64 *__restrict__ ext, u64 *__restrict__ t, const DevMod *__restrict__ mods,
-                              uint32_t nmod, uint32_t logn, u64 total) {
+// Tensor step of Multiplicator::multiply (F/bfv/ops/mul.rs:198-201).  Operand polynomials
+// (c00, c01) = extL[b][0..1], (c10, c11) = extR[b][0..1], each [K][N]; rows below `ncommon`
+// are read from the original ciphertexts lhs/rhs [b][2][L][N] when those pointers are given
+// (the extender copies them verbatim, M/rq/scaler.rs:61-65, so the copy is skipped).
+// t is slot-major: t[slot][b][K][N] = (c00*c10, c00*c11 + c01*c10, c01*c11).
+__global__ void tensor_kernel(const u64 *__restrict__ extL, const u64 *__restrict__ extR,
+                              const u64 *__restrict__ lhs, const u64 *__restrict__ rhs, u64 *__restrict__ t,
+                              const DevMod *__restrict__ mods, uint32_t nmod, uint32_t ncommon, uint32_t lrows,
+                              uint32_t logn, u64 nb, u64 total) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
-    const u64 pn = (u64)nmod << logn;  // elements per polynomial
+    const u64 pn = (u64)nmod << logn;  // elements per extended polynomial
     const u64 b = gid / pn, off = gid % pn;
-    const DevMod m = mods[off >> logn];
-    const u64 *e = ext + b * 4 * pn + off;
-    const u64 c00 = e[0], c01 = e[pn], c10 = e[2 * pn], c11 = e[3 * pn];
-    u64 *o = t + b * 3 * pn + off;
+    const uint32_t row = (uint32_t)(off >> logn);
+    const DevMod m = mods[row];
+    u64 c00, c01, c10, c11;
+    if (lhs && row < ncommon) {
+        const u64 pl = (u64)lrows << logn;
+        c00 = lhs[b * 2 * pl + off];
+        c01 = lhs[b * 2 * pl + pl + off];
+        c10 = rhs[b * 2 * pl + off];
+        c11 = rhs[b * 2 * pl + pl + off];
+    } else {
+        c00 = extL[b * 2 * pn + off];
+        c01 = extL[b * 2 * pn + pn + off];
+        c10 = extR[b * 2 * pn + off];
+        c11 = extR[b * 2 * pn + pn + off];
+    }
+    u64 *o = t + b * pn + off;
     o[0] = mul_mod(c00, c10, m);
-    o[pn] = add_mod(mul_mod(c00, c11, m), mul_mod(c01, c10, m), m.p);
-    o[2 * pn] = mul_mod(c01, c11, m);
+    o[nb * pn] = add_mod(mul_mod(c00, c11, m), mul_mod(c01, c10, m), m.p);
+    o[2 * nb * pn] = mul_mod(c01, c11, m);
 }
 // Copies the first `rows` rows of each polynomial: in [npolys][in_rows][N] -> out [npolys][out_rows][N].
 __global__ void copy_rows_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,

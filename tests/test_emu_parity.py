@@ -67,6 +67,26 @@ def test_multiply(fhe, nmod, level, chunk):
     cases.case_multiply(fhe, False, nmod=nmod, level=level, chunk=chunk)
 
 
+@pytest.mark.parametrize("n", [128, 512])
+def test_multiply_vector_tile_paths(fhe, n):
+    """Sizes whose tiles take the 16-byte-chunk (CH > 0) load/MAC/store paths of the kernels."""
+    cases.case_multiply(fhe, False, nmod=2, n=n, batch=2)
+
+
+def test_galois_vector_tile_path(fhe):
+    cases.case_galois(fhe, False, nmod=3, n=128)
+
+
+@pytest.mark.parametrize("n", [32768, 65536])
+def test_ntt_split_kernels(fhe, n):
+    """N > 16384: global radix stages + LDS kernel on 8192-point sub-blocks (vs the C oracle)."""
+    from fhe_oracle import coracle
+    from fhe_oracle.rq import Context as OCtx
+    from fhe_oracle.zq import generate_prime
+    mods = [generate_prime(62, 2 * n, 1 << 62)]
+    cases.case_ntt(fhe, False, n, moduli=mods, batch=1, coracle_ctx=coracle.CCtx(OCtx(mods, n)))
+
+
 def test_multiply_custom_factors(fhe):
     cases.case_multiply_custom_factors(fhe, False)
 

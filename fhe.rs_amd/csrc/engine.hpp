@@ -37,6 +37,13 @@ inline void require(bool cond, int code, const char *msg) {
     if (!cond) throw StatusError(code, msg);
 }
 
+// FHE_DEBUG_SYNC=1 synchronises after every kernel launch (debugging aid only).
+inline bool debug_sync() {
+    static const bool on = std::getenv("FHE_DEBUG_SYNC") != nullptr;
+    return on;
+}
+inline bool debug_flag(const char *name) { return std::getenv(name) != nullptr; }
+
 // ------------------------------------------------------------------------ profiling ----
 // Optional per-kernel timing with HIP events recorded on the launching stream
 // (bench.py reads these to compute the dominant kernel's achieved bytes/s live).
@@ -117,6 +124,7 @@ private:
             hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);          \
         }                                                                                \
         FHE_HIP_CHECK(hipGetLastError());                                                \
+        if (debug_sync()) FHE_HIP_CHECK(hipStreamSynchronize(stream));                   \
     } while (0)
 
 // --------------------------------------------------------------- device allocations ----
@@ -746,7 +754,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     const size_t chunk = std::min(batch, default_chunk(b, e));
     // the extenders copy the shared prefix rows verbatim; when both share all L rows the tensor
     // kernel reads those rows from the inputs directly and the copy is skipped
-    const bool skip_copy = m.ext_lhs->ncommon == L && m.ext_rhs->ncommon == L;
+    const bool skip_copy = m.ext_lhs->ncommon == L && m.ext_rhs->ncommon == L && !debug_flag("FHE_NO_SKIP_COPY");
     WsGuard extL(chunk * 2 * PK * sizeof(u64), s), extR(chunk * 2 * PK * sizeof(u64), s);
     WsGuard ten(chunk * 3 * PK * sizeof(u64), s), d(chunk * 3 * PL * sizeof(u64), s);
     WsGuard pre(m.mod_switch ? chunk * parts * PL * sizeof(u64) : 8, s);
@@ -756,14 +764,22 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         // EXTEND (mul.rs:192-195): both parts of every lhs (rhs) ciphertext in one go
         scale_polys(*m.ext_lhs, l, extL.u(), nb * 2, true, s, !skip_copy);
         scale_polys(*m.ext_rhs, r, extR.u(), nb * 2, true, s, !skip_copy);
-        // TENSOR (mul.rs:198-201)
-        {
-            const u64 total = (u64)nb * PK;
-            FHE_LAUNCH("tensor", k::tensor_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s,
-                       extL.u(), extR.u(), skip_copy ? l : nullptr, skip_copy ? r : nullptr, ten.u(), e.dmods(),
-                       (uint32_t)K, (uint32_t)L, (uint32_t)L, (uint32_t)e.logn, (u64)nb, total);
+        // TENSOR (mul.rs:198-201); blockIdx.y = ciphertext pair (sub-chunks of <= 32768 pairs)
+        for (size_t t0 = 0; t0 < nb; t0 += 32768) {
+            const size_t tn = std::min<size_t>(32768, nb - t0);
+            for (int rep = 0; rep < (debug_flag("FHE_DEBUG_TENSOR_TWICE") ? 2 : 1); rep++)
+                FHE_LAUNCH("tensor", k::tensor_kernel, dim3(blocks_for(PK, EW_THREADS), (unsigned)tn), dim3(EW_THREADS), 0,
+                           s, extL.u() + t0 * 2 * PK, extR.u() + t0 * 2 * PK, skip_copy ? l + t0 * 2 * PL : nullptr,
+                           skip_copy ? r + t0 * 2 * PL : nullptr, ten.u() + t0 * PK, e.dmods(), (uint32_t)K, (uint32_t)L,
+                           (uint32_t)L, (uint32_t)e.logn, (u64)nb, debug_flag("FHE_DEBUG_RAW") ? 2u : debug_flag("FHE_DEBUG_ACQ") ? 1u : 0u);
         }
         u64 *dst = m.mod_switch ? pre.u() : out + b0 * parts * PL;
+        if (const char *stage = std::getenv("FHE_DEBUG_STAGE")) {  // developer aid: dump an intermediate
+            const u64 *srcp = stage[0] == '1' ? extL.u() : stage[0] == '2' ? extR.u() : ten.u();
+            if (const char *off = std::getenv("FHE_DEBUG_OFFSET")) srcp += (size_t)std::atoi(off) * N;
+            FHE_HIP_CHECK(hipMemcpyAsync(dst, srcp, (size_t)nb * parts * PL * sizeof(u64), hipMemcpyDeviceToDevice, s));
+            continue;
+        }
         if (m.rk) {
             // DOWN-SCALE (mul.rs:204-206) to PowerBasis; c0, c1 go back to Ntt, c2 stays in
             // PowerBasis for the key switch (the reference transforms c2 forward and, at mul.rs:212,

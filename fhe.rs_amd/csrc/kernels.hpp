@@ -685,11 +685,15 @@ __global__ void mul_shoup_kernel(u64 *__restrict__ a, const u64 *__restrict__ b,
 __global__ void tensor_kernel(const u64 *__restrict__ extL, const u64 *__restrict__ extR,
                               const u64 *__restrict__ lhs, const u64 *__restrict__ rhs, u64 *__restrict__ t,
                               const DevMod *__restrict__ mods, uint32_t nmod, uint32_t ncommon, uint32_t lrows,
-                              uint32_t logn, u64 nb, u64 total) {
-    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
+                              uint32_t logn, u64 nb, uint32_t debug_acquire) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (debug_acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    // grid: x = chunks of one extended polynomial, y = ciphertext pair (no runtime divisions)
     const u64 pn = (u64)nmod << logn;  // elements per extended polynomial
-    const u64 b = gid / pn, off = gid % pn;
+    const u64 off = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (off >= pn) return;
+    const u64 b = blockIdx.y;
     const uint32_t row = (uint32_t)(off >> logn);
     const DevMod m = mods[row];
     u64 c00, c01, c10, c11;
@@ -706,6 +710,12 @@ __global__ void tensor_kernel(const u64 *__restrict__ extL, const u64 *__restric
         c11 = extR[b * 2 * pn + pn + off];
     }
     u64 *o = t + b * pn + off;
+    if (debug_acquire == 2) {  // developer aid: dump the operands as read
+        o[0] = c00;
+        o[nb * pn] = c10;
+        o[2 * nb * pn] = c01;
+        return;
+    }
     o[0] = mul_mod(c00, c10, m);
     o[nb * pn] = add_mod(mul_mod(c00, c11, m), mul_mod(c01, c10, m), m.p);
     o[2 * nb * pn] = mul_mod(c01, c11, m);

@@ -449,22 +449,38 @@ struct Scaler {
 inline void scaler_upload(Scaler &s) {
     const ScalerConstants &c = s.c;
     if (s.from->device < 0) return;
+    require(c.nfrom <= 64, E_ARG, "RNS scaler supports at most 64 source moduli");
     std::vector<u64> all;
     auto push = [&](const std::vector<u64> &v) {
         size_t off = all.size();
         all.insert(all.end(), v.begin(), v.end());
         return off;
     };
+    // device-side derived tables (see scale_kernel): gamma_neg and the 16-entry fold tables
+    std::vector<u64> gneg(c.nto), vtab(c.nto * 16), c64(c.nto * 16), c128(c.nto * 16);
+    for (size_t j = 0; j < c.nto; j++) {
+        const u64 q = s.to->moduli[j];
+        gneg[j] = (q - c.gamma[j] % q) % q;
+        const u64 two64 = (u64)((((u128)1) << 64) % q);
+        const u64 two128 = mulmod(two64, two64, q);
+        const u64 g64 = mulmod(two64, gneg[j], q);
+        for (u64 k = 0; k < 16; k++) {
+            vtab[j * 16 + k] = mulmod(k % q, g64, q);
+            c64[j * 16 + k] = mulmod(k % q, two64, q);
+            c128[j * 16 + k] = mulmod(k % q, two128, q);
+        }
+    }
     std::vector<u64> sign64(c.theta_omega_sign.begin(), c.theta_omega_sign.end());
-    size_t o_gamma = push(c.gamma), o_gs = push(c.gamma_shoup), o_om = push(c.omega), o_oms = push(c.omega_shoup);
+    size_t o_gn = push(gneg), o_om = push(c.omega), o_vt = push(vtab), o_c64 = push(c64), o_c128 = push(c128);
     size_t o_tol = push(c.theta_omega_lo), o_toh = push(c.theta_omega_hi), o_tos = push(sign64);
     size_t o_tgl = push(c.theta_garner_lo), o_tgh = push(c.theta_garner_hi);
     s.d_all.upload(all);
     u64 *b = s.d_all.p;
-    s.dev.gamma = b + o_gamma;
-    s.dev.gamma_shoup = b + o_gs;
+    s.dev.gamma_neg = b + o_gn;
     s.dev.omega = b + o_om;
-    s.dev.omega_shoup = b + o_oms;
+    s.dev.vhi_tab = b + o_vt;
+    s.dev.c64_tab = b + o_c64;
+    s.dev.c128_tab = b + o_c128;
     s.dev.theta_omega_lo = b + o_tol;
     s.dev.theta_omega_hi = b + o_toh;
     s.dev.theta_omega_sign = b + o_tos;

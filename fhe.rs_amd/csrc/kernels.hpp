@@ -506,8 +506,11 @@ __global__ void digit_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
 
 // ------------------------------------------------------------------ RNS scaler ----
 struct ScalerDev {
-    const u64 *gamma, *gamma_shoup;                      // [nto]
-    const u64 *omega, *omega_shoup;                      // [nto][nfrom]
+    const u64 *gamma_neg;                                // [nto]      (q - gamma) mod q
+    const u64 *omega;                                    // [nto][nfrom]
+    const u64 *vhi_tab;                                  // [nto][16]  k * 2^64 * gamma_neg mod q
+    const u64 *c64_tab;                                  // [nto][16]  k * 2^64  mod q
+    const u64 *c128_tab;                                 // [nto][16]  k * 2^128 mod q
     const u64 *theta_omega_lo, *theta_omega_hi;          // [nfrom]
     const u64 *theta_omega_sign;                         // [nfrom] (0/1)
     const u64 *theta_garner_lo, *theta_garner_hi;        // [nfrom]
@@ -515,10 +518,24 @@ struct ScalerDev {
     uint32_t theta_gamma_sign, is_one, shift, nfrom, nto, ncommon;
 };
 
-// One lane per coefficient column (RnsScaler::scale, M/rns/scaler.rs:249-352): the 256-bit
-// fixed-point sums v and w are reproduced limb for limb; the per-target accumulation
-// y = -v*gamma (+/- w) + sum_j r_j*omega_j only matters mod q (the reference ends with
-// reduce_u128), so it is kept lazily in [0, 2q) in one word.
+// acc (192-bit: lo, hi, top) += a * b
+FHE_HD void mac192(u64 &lo, u64 &hi, u64 &top, u64 a, u64 b) {
+    const u64 pl = a * b, ph = mulhi64(a, b);
+    lo += pl;
+    const u64 c0 = lo < pl;
+    hi += ph;
+    const u64 c1 = hi < ph;
+    hi += c0;
+    top += c1 + (hi < c0);
+}
+
+// One lane per coefficient column (RnsScaler::scale, M/rns/scaler.rs:249-352).  The 256-bit
+// fixed-point sums v and w are reproduced limb for limb (they define the rounding).  The
+// per-target value y = -v*gamma (+/- w) + sum_j r_j*omega_j only matters mod q (the reference
+// ends with reduce_u128), so instead of one Shoup product per term it is accumulated as
+// exact 128-bit products in a 192-bit register and reduced ONCE (4 instead of 10 32-bit
+// multiplies per term); the few bits of v, w and of the accumulator above 2^64 / 2^128 are
+// folded through 16-entry tables (v, |w| < 2^68 and top < 16 for up to 64 source moduli).
 // in: [npolys][nfrom][N] PowerBasis; out: rows [ncommon, nto) of [npolys][nto][N].
 // NF >= nfrom: the column's residues are loaded once, together, into registers (coalesced
 // along N; one batch of loads in flight); all scaler constants are wave-uniform scalar loads.
@@ -584,20 +601,29 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
             whi += (wlo < odd);
         }
     }
+    const uint32_t vh = (uint32_t)vhi & 15, wh = (uint32_t)whi & 15;
     u64 *o = out + poly * out_poly_stride + col;
     for (uint32_t jt = s.ncommon; jt < s.nto; jt++) {
         const DevMod q = to_mods[jt];
-        const u64 *om = s.omega + (u64)jt * s.nfrom, *oms = s.omega_shoup + (u64)jt * s.nfrom;
-        u64 y = q.p2 - mul_shoup_lazy(reduce_u128(vhi, vlo, q), s.gamma[jt], s.gamma_shoup[jt], q.p);  // (0, 2q]
-        y = csub(y, q.p2);
+        const u64 *om = s.omega + (u64)jt * s.nfrom;
+        u64 lo = 0, hi = 0, top = 0;
+        mac192(lo, hi, top, vlo, s.gamma_neg[jt]);            // -v_lo * gamma
+        u64 small = s.vhi_tab[jt * 16 + vh];                   // -v_hi * 2^64 * gamma   (< q)
         if (!s.is_one) {
-            const u64 wi = reduce_u128(whi, wlo, q);  // [0, q)
-            y = csub(y + (w_sign ? q.p2 - wi : wi), q.p2);
+            const u64 wi = csub(reduce_u64(wlo, q) + s.c64_tab[jt * 16 + wh], q.p);  // w mod q
+            small += w_sign ? (wi ? q.p - wi : 0) : wi;        // < 2q
         }
 #pragma unroll
         for (int i = 0; i < NF; i++)
-            if ((uint32_t)i < s.nfrom) y = csub(y + mul_shoup_lazy(rests[i], om[i], oms[i], q.p), q.p2);
-        o[(u64)jt * n] = csub(y, q.p);
+            if ((uint32_t)i < s.nfrom) mac192(lo, hi, top, rests[i], om[i]);
+        // fold: + small (< 2q), top * 2^128
+        lo += small;
+        const u64 c = lo < small;
+        hi += c;
+        top += (hi < c);
+        u64 r = reduce_u128(hi, lo, q);                        // [0, q)
+        r = csub(r + s.c128_tab[jt * 16 + ((uint32_t)top & 15)], q.p);
+        o[(u64)jt * n] = r;
     }
 }
 

@@ -309,14 +309,18 @@ inline std::unique_ptr<Ctx> ctx_create(int device, size_t degree, const std::vec
         static_assert(sizeof(DevMod) == sizeof(ModConsts), "DevMod layout");
         std::memcpy(hm.data(), c->mods.data(), c->L * sizeof(DevMod));
         c->d_mods.upload(hm);
-        std::vector<k::u64x2> tw(c->L * degree), itw(c->L * degree), ninv(c->L);
+        std::vector<k::u64x2> tw(c->L * degree), itw(c->L * degree), ninv(2 * c->L);
         for (size_t i = 0; i < c->L; i++) {
             const NttTables &t = c->tabs[i];
             for (size_t j = 0; j < degree; j++) {
                 tw[i * degree + j] = k::u64x2{t.omegas[j], t.omegas_shoup[j]};
                 itw[i * degree + j] = k::u64x2{t.zetas_inv[j], t.zetas_inv_shoup[j]};
             }
-            ninv[i] = k::u64x2{t.size_inv, t.size_inv_shoup};
+            // {N^-1, shoup} and {z_last * N^-1, shoup}: the last inverse stage (one block, twiddle
+            // zetas_inv[N-2]) absorbs the N^-1 scaling
+            const u64 zn = mulmod(t.zetas_inv[degree - 2], t.size_inv, moduli[i]);
+            ninv[2 * i] = k::u64x2{t.size_inv, t.size_inv_shoup};
+            ninv[2 * i + 1] = k::u64x2{zn, shoup(zn, moduli[i])};
         }
         c->d_tw.upload(tw);
         c->d_itw.upload(itw);

@@ -121,9 +121,13 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
                 for (uint32_t blk = 0; blk < (1u << u); blk++) w[UNIFORM ? 0 : (1u << u) - 1 + blk] = tw[kst + blk];
             }
         }
+        // padi(base + off) = padi(base) + padi(off) for every element of a group (no carry out
+        // of the low four bits: a group never straddles a 16-element pad block unless off is a
+        // multiple of 16), so the per-element LDS offsets are compile-time constants.
+        u64 *const g = lds + padi(base);
         u64 x[R];
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++) x[e] = lds[padi(base + (e << lo_bits))];
+        for (uint32_t e = 0; e < R; e++) x[e] = g[padi(e << lo_bits)];
 #pragma unroll
         for (int u = 0; u < G; u++) {
             const uint32_t half = R >> (u + 1);
@@ -139,7 +143,7 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
             }
         }
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++) lds[padi(base + (e << lo_bits))] = x[e];
+        for (uint32_t e = 0; e < R; e++) g[padi(e << lo_bits)] = x[e];
     }
 }
 
@@ -159,9 +163,12 @@ __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ 
 // ---------------------------------------------------------------- inverse passes ----
 // Stages [V0, V0+G) (half-lengths 2^V0 .. 2^(V0+G-1)) of the Gentleman-Sande transform.
 // Twiddle of (stage v, block i) is itw[koff(v) + i], koff(v) = N - (N >> v) + sub*(M >> (v+1)).
+// `fold` (only meaningful for the pass that contains the last stage of a whole-row transform):
+// the N^-1 scaling of native.rs:229-232 is folded into the last stage -- x' = (x + y) * N^-1,
+// y' = (x - y) * (z * N^-1) -- which saves half a Shoup multiplication per coefficient.
 template <int G, int LOGM, int V0, int T>
 __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub, u64 p,
-                                         u64 p2, uint32_t tid) {
+                                         u64 p2, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv) {
     constexpr uint32_t R = 1u << G;
     constexpr uint32_t ngroups = 1u << (LOGM - G);
     constexpr bool UNIFORM = V0 >= 6;
@@ -184,9 +191,10 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
                 for (uint32_t blk = 0; blk < nblk; blk++) z[UNIFORM ? 0 : R - 2 * nblk + blk] = itw[kst + blk];
             }
         }
+        u64 *const g = lds + padi(base);  // see fwd_pass: constant per-element offsets
         u64 x[R];
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++) x[e] = lds[padi(base + (e << V0))];
+        for (uint32_t e = 0; e < R; e++) x[e] = g[padi(e << V0)];
 #pragma unroll
         for (int u = 0; u < G; u++) {
             const uint32_t nblk = R >> (u + 1);
@@ -196,25 +204,31 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
                 const u64x2 zv = UNIFORM ? itw[kst + blk] : z[UNIFORM ? 0 : R - 2 * nblk + blk];
 #pragma unroll
                 for (uint32_t j = 0; j < (1u << u); j++) {
-                    const uint32_t a = blk * (2u << u) + j;
-                    inv_butterfly(x[a], x[a + (1u << u)], zv.x, zv.y, p, p2);
+                    const uint32_t a = blk * (2u << u) + j, b = a + (1u << u);
+                    if (V0 + G == LOGM && u == G - 1 && fold) {
+                        const u64 t = x[a], y = x[b];
+                        x[a] = mul_shoup_lazy(y + t, ninv.x, ninv.y, p);
+                        x[b] = mul_shoup_lazy(p2 + t - y, zninv.x, zninv.y, p);
+                    } else {
+                        inv_butterfly(x[a], x[b], zv.x, zv.y, p, p2);
+                    }
                 }
             }
         }
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++) lds[padi(base + (e << V0))] = x[e];
+        for (uint32_t e = 0; e < R; e++) g[padi(e << V0)] = x[e];
     }
 }
 
 // Late passes (scalar twiddles) take the wider radix.
 template <int LOGM, int T, int PASS = 0, int V0 = 0>
 __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
-                                            u64 p, u64 p2, uint32_t tid) {
+                                            u64 p, u64 p2, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv) {
     if constexpr (PASS < plan_np(LOGM, GMAX)) {
         constexpr int G = plan_base(LOGM, GMAX) + (PASS >= plan_np(LOGM, GMAX) - plan_rem(LOGM, GMAX) ? 1 : 0);
-        inv_pass<G, LOGM, V0, T>(lds, itw, logn, sub, p, p2, tid);
+        inv_pass<G, LOGM, V0, T>(lds, itw, logn, sub, p, p2, tid, fold, ninv, zninv);
         __syncthreads();
-        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G>(lds, itw, logn, sub, p, p2, tid);
+        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G>(lds, itw, logn, sub, p, p2, tid, fold, ninv, zninv);
     }
 }
 
@@ -297,13 +311,12 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         ntt_fwd_lds<LOGM, T>(lds, twr, nsub + sub, p, p2, tid);
         lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub(csub(v, p2), p); });
     } else {
-        ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, p, p2, tid);
-        if (logn == LOGM) {
-            const u64x2 ni = ninv[mi];
-            lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return mul_shoup(v, ni.x, ni.y, p); });
-        } else {
+        const bool whole = logn == LOGM;  // ninv[2*mi] = {N^-1, shoup}, ninv[2*mi+1] = {z_last * N^-1, shoup}
+        ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, p, p2, tid, whole, ninv[2 * mi], ninv[2 * mi + 1]);
+        if (whole)
+            lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub(v, p); });
+        else
             lds_to_tile<CH, M, T>(lds, dst, tid, [](u64 v) { return v; });  // < 2p, global pass finishes
-        }
     }
 }
 
@@ -368,7 +381,7 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
                 }
             }
         }
-        const u64x2 ni = ninv[mi];
+        const u64x2 ni = ninv[2 * mi];
 #pragma unroll
         for (uint32_t e = 0; e < R; e++) dst[lo + e * m] = mul_shoup(x[e], ni.x, ni.y, p);
     }
@@ -518,15 +531,10 @@ struct ScalerDev {
     uint32_t theta_gamma_sign, is_one, shift, nfrom, nto, ncommon;
 };
 
-// acc (192-bit: lo, hi, top) += a * b
-FHE_HD void mac192(u64 &lo, u64 &hi, u64 &top, u64 a, u64 b) {
-    const u64 pl = a * b, ph = mulhi64(a, b);
-    lo += pl;
-    const u64 c0 = lo < pl;
-    hi += ph;
-    const u64 c1 = hi < ph;
-    hi += c0;
-    top += c1 + (hi < c0);
+// acc (192-bit: 128-bit low part + top word) += a * b
+FHE_HD void mac192(u128_t &acc, u64 &top, u64 a, u64 b) {
+    const bool c = __builtin_add_overflow(acc, (u128_t)a * b, &acc);
+    top += c ? 1 : 0;
 }
 
 // One lane per coefficient column (RnsScaler::scale, M/rns/scaler.rs:249-352).  The 256-bit
@@ -553,7 +561,7 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
 #pragma unroll
     for (int i = 0; i < NF; i++) rests[i] = (uint32_t)i < s.nfrom ? src[(u64)i * n] : 0;
 
-    U256 sum = {0, 0, 0, 0};
+    U256 sum = {0, 0};
 #pragma unroll
     for (int i = 0; i < NF; i++)
         if ((uint32_t)i < s.nfrom) u256_mac_64x128(sum, rests[i], s.theta_garner_lo[i], s.theta_garner_hi[i], false);
@@ -569,25 +577,23 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
     u64 wlo = 0, whi = 0;
     bool w_sign = false;
     if (!s.is_one) {
-        U256 t = {0, 0, 0, 0};
+        U256 t = {0, 0};
 #pragma unroll
         for (int i = 0; i < NF; i++)
             if ((uint32_t)i < s.nfrom)
                 u256_mac_64x128(t, rests[i], s.theta_omega_lo[i], s.theta_omega_hi[i], s.theta_omega_sign[i] != 0);
-        // t -/+= v * theta_gamma  (128 x 128 -> 256 wrapping): low word then high word << 64
+        // t -/+= v * theta_gamma  (128 x 128 -> 256 wrapping): low word of v, then high word << 64
         const bool neg = !s.theta_gamma_sign;
         u256_mac_64x128(t, vlo, s.theta_gamma_lo, s.theta_gamma_hi, neg);
         {
-            U256 sh = {t.w1, t.w2, t.w3, 0};
+            U256 sh = {(t.lo >> 64) | (t.hi << 64), t.hi >> 64};  // t >> 64
             u256_mac_64x128(sh, vhi, s.theta_gamma_lo, s.theta_gamma_hi, neg);
-            t.w1 = sh.w0;
-            t.w2 = sh.w1;
-            t.w3 = sh.w2;
+            t.hi = (sh.lo >> 64) | (sh.hi << 64);
+            t.lo = (t.lo & (u128_t)~0ull) | (sh.lo << 64);
         }
-        w_sign = ((t.w2 >> 63) | t.w3) != 0;
+        w_sign = u256_ge_2_191(t);
         if (w_sign) {
-            U256 nt = {~t.w0, ~t.w1, ~t.w2, ~t.w3};
-            u256_shr_lo128(nt, 126, wlo, whi);
+            u256_shr_lo128(u256_not(t), 126, wlo, whi);
             wlo += 1;
             whi += (wlo == 0);
             wlo = (wlo >> 1) | (whi << 63);
@@ -606,8 +612,9 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
     for (uint32_t jt = s.ncommon; jt < s.nto; jt++) {
         const DevMod q = to_mods[jt];
         const u64 *om = s.omega + (u64)jt * s.nfrom;
-        u64 lo = 0, hi = 0, top = 0;
-        mac192(lo, hi, top, vlo, s.gamma_neg[jt]);            // -v_lo * gamma
+        u128_t acc = 0;
+        u64 top = 0;
+        mac192(acc, top, vlo, s.gamma_neg[jt]);               // -v_lo * gamma
         u64 small = s.vhi_tab[jt * 16 + vh];                   // -v_hi * 2^64 * gamma   (< q)
         if (!s.is_one) {
             const u64 wi = csub(reduce_u64(wlo, q) + s.c64_tab[jt * 16 + wh], q.p);  // w mod q
@@ -615,13 +622,9 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
         }
 #pragma unroll
         for (int i = 0; i < NF; i++)
-            if ((uint32_t)i < s.nfrom) mac192(lo, hi, top, rests[i], om[i]);
-        // fold: + small (< 2q), top * 2^128
-        lo += small;
-        const u64 c = lo < small;
-        hi += c;
-        top += (hi < c);
-        u64 r = reduce_u128(hi, lo, q);                        // [0, q)
+            if ((uint32_t)i < s.nfrom) mac192(acc, top, rests[i], om[i]);
+        top += __builtin_add_overflow(acc, (u128_t)small, &acc) ? 1 : 0;
+        u64 r = reduce_u128((u64)(acc >> 64), (u64)acc, q);    // [0, q)
         r = csub(r + s.c128_tab[jt * 16 + ((uint32_t)top & 15)], q.p);
         o[(u64)jt * n] = r;
     }

@@ -113,63 +113,33 @@ FHE_HD u64 splitmix64(u64 x) {
 }
 
 // 256-bit wrap-around accumulator == ethnum::U256 as used by RnsScaler::scale
-// (M/rns/scaler.rs:260-313).
+// (M/rns/scaler.rs:260-313), held as two 128-bit halves so that additions compile to
+// hardware carry chains (v_add_co / v_addc) instead of compare-and-select sequences.
 struct U256 {
-    u64 w0, w1, w2, w3;
+    u128_t lo, hi;
 };
 // acc +/-= r * (lo | hi << 64)   (mod 2^256)
 FHE_HD void u256_mac_64x128(U256 &acc, u64 r, u64 lo, u64 hi, bool negate) {
-    u64 p0l = r * lo, p0h = mulhi64(r, lo);
-    u64 p1l = r * hi, p1h = mulhi64(r, hi);
-    u64 t0 = p0l;
-    u64 t1 = p0h + p1l;
-    u64 c = t1 < p0h;
-    u64 t2 = p1h + c;
+    const u128_t p0 = (u128_t)r * lo, p1 = (u128_t)r * hi;  // product = p0 + (p1 << 64), < 2^192
+    u128_t t_lo;
+    const bool c = __builtin_add_overflow(p0, p1 << 64, &t_lo);
+    const u128_t t_hi = (p1 >> 64) + (c ? 1 : 0);
     if (!negate) {
-        u64 s0 = acc.w0 + t0;
-        u64 c0 = s0 < t0;
-        u64 s1 = acc.w1 + t1;
-        u64 c1 = s1 < t1;
-        s1 += c0;
-        c1 += s1 < c0;
-        u64 s2 = acc.w2 + t2;
-        u64 c2 = s2 < t2;
-        s2 += c1;
-        c2 += s2 < c1;
-        acc.w0 = s0;
-        acc.w1 = s1;
-        acc.w2 = s2;
-        acc.w3 += c2;
+        const bool c2 = __builtin_add_overflow(acc.lo, t_lo, &acc.lo);
+        acc.hi += t_hi + (c2 ? 1 : 0);
     } else {
-        u64 d0 = acc.w0 - t0;
-        u64 b0 = acc.w0 < t0;
-        u64 d1 = acc.w1 - t1;
-        u64 b1 = acc.w1 < t1;
-        u64 d1b = d1 - b0;
-        b1 += d1 < b0;
-        u64 d2 = acc.w2 - t2;
-        u64 b2 = acc.w2 < t2;
-        u64 d2b = d2 - b1;
-        b2 += d2 < b1;
-        acc.w0 = d0;
-        acc.w1 = d1b;
-        acc.w2 = d2b;
-        acc.w3 -= b2;
+        const bool b2 = __builtin_sub_overflow(acc.lo, t_lo, &acc.lo);
+        acc.hi -= t_hi + (b2 ? 1 : 0);
     }
 }
 // bits [s, s+128) of a, for 1 <= s <= 127
 FHE_HD void u256_shr_lo128(const U256 &a, uint32_t s, u64 &lo, u64 &hi) {
-    if (s < 64) {
-        lo = (a.w0 >> s) | (a.w1 << (64 - s));
-        hi = (a.w1 >> s) | (a.w2 << (64 - s));
-    } else if (s == 64) {
-        lo = a.w1;
-        hi = a.w2;
-    } else {
-        uint32_t t = s - 64;
-        lo = (a.w1 >> t) | (a.w2 << (64 - t));
-        hi = (a.w2 >> t) | (a.w3 << (64 - t));
-    }
+    const u128_t v = (a.lo >> s) | (a.hi << (128 - s));
+    lo = (u64)v;
+    hi = (u64)(v >> 64);
 }
+FHE_HD U256 u256_not(const U256 &a) { return U256{~a.lo, ~a.hi}; }
+// any bit at position >= 191 set (the reference's sign test, scaler.rs:303)
+FHE_HD bool u256_ge_2_191(const U256 &a) { return (a.hi >> 63) != 0; }
 
 }  // namespace fhe

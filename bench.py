@@ -94,12 +94,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+        # RCCL ("nccl") on the GPU box; BENCH_DIST_BACKEND=gloo lets several ranks share one GPU in tests
+        dist.init_process_group(backend=os.environ.get("BENCH_DIST_BACKEND", "nccl"))
         world = dist.get_world_size()
         rank = dist.get_rank()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = local_rank
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
 
     # ---- setup (untimed): parameters, device tables, synthetic key + inputs in HBM ----------
     n, batch = N_DEGREE, args.batch

@@ -417,6 +417,23 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     }
 }
 
+// Fused tensor + inverse NTT over the extended basis (rows fit LDS: logn <= 14).
+inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s) {
+    const size_t lds = k::lds_words((uint32_t)e.n) * sizeof(u64);
+#define FHE_TI_CASE(LM)                                                                                       \
+    case LM:                                                                                                  \
+        allow_big_lds(k::tensor_intt_kernel<LM>, lds);                                                        \
+        FHE_LAUNCH("tensor_intt", (k::tensor_intt_kernel<LM>), dim3((unsigned)e.L, (unsigned)nb, 3),          \
+                   dim3(k::ntt_threads_c(LM)), lds, s, ts, out, e.dmods(), e.ditw(), e.dninv(), (uint32_t)e.L); \
+        break;
+    switch (e.logn) {
+        FHE_TI_CASE(3) FHE_TI_CASE(4) FHE_TI_CASE(5) FHE_TI_CASE(6) FHE_TI_CASE(7) FHE_TI_CASE(8)
+        FHE_TI_CASE(9) FHE_TI_CASE(10) FHE_TI_CASE(11) FHE_TI_CASE(12) FHE_TI_CASE(13) FHE_TI_CASE(14)
+        default: throw StatusError(E_ARG, "unsupported tensor tile size");
+    }
+#undef FHE_TI_CASE
+}
+
 // all rows of [npolys][rows_in_poly][N], modulus = row index
 inline k::RowMap full_map(const Ctx &c, size_t rows_in_poly) {
     k::RowMap m{};
@@ -784,34 +801,37 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         // EXTEND (mul.rs:192-195): both parts of every lhs (rhs) ciphertext in one go
         scale_polys(*m.ext_lhs, l, extL.u(), nb * 2, true, s, !skip_copy);
         scale_polys(*m.ext_rhs, r, extR.u(), nb * 2, true, s, !skip_copy);
-        // TENSOR (mul.rs:198-201); blockIdx.y = ciphertext pair (sub-chunks of <= 32768 pairs)
-        for (size_t t0 = 0; t0 < nb; t0 += 32768) {
-            const size_t tn = std::min<size_t>(32768, nb - t0);
-            for (int rep = 0; rep < (debug_flag("FHE_DEBUG_TENSOR_TWICE") ? 2 : 1); rep++)
+        // TENSOR (mul.rs:198-201) + the inverse NTT of the down-scaler (M/rq/scaler.rs:69-79):
+        // ten [3][nb][K][N] ends up in PowerBasis.  Rows that fit LDS: one fused kernel;
+        // larger rows: element-wise tensor kernel, then the two-kernel inverse NTT.
+        const bool fused_tensor = e.logn <= 14 && !debug_flag("FHE_NO_TENSOR_FUSION");
+        if (fused_tensor) {
+            require(nb <= 32768, E_ARG, "chunk too large for the fused tensor kernel");  // grid.y limit
+            k::TensorSrc ts{extL.u(), extR.u(), skip_copy ? l : nullptr, skip_copy ? r : nullptr, (uint32_t)L,
+                            (uint32_t)L};
+            launch_tensor_intt(e, ts, ten.u(), nb, s);
+        } else {
+            for (size_t t0 = 0; t0 < nb; t0 += 32768) {  // grid.y limit
+                const size_t tn = std::min<size_t>(32768, nb - t0);
                 FHE_LAUNCH("tensor", k::tensor_kernel, dim3(blocks_for(PK, EW_THREADS), (unsigned)tn), dim3(EW_THREADS), 0,
                            s, extL.u() + t0 * 2 * PK, extR.u() + t0 * 2 * PK, skip_copy ? l + t0 * 2 * PL : nullptr,
                            skip_copy ? r + t0 * 2 * PL : nullptr, ten.u() + t0 * PK, e.dmods(), (uint32_t)K, (uint32_t)L,
-                           (uint32_t)L, (uint32_t)e.logn, (u64)nb, debug_flag("FHE_DEBUG_RAW") ? 2u : debug_flag("FHE_DEBUG_ACQ") ? 1u : 0u);
+                           (uint32_t)L, (uint32_t)e.logn, (u64)nb, 0u);
+            }
         }
+        if (!fused_tensor) launch_ntt(e, true, ten.u(), ten.u(), full_map(e, K), nb * 3, k::PRO_NONE, s);
         u64 *dst = m.mod_switch ? pre.u() : out + b0 * parts * PL;
-        if (const char *stage = std::getenv("FHE_DEBUG_STAGE")) {  // developer aid: dump an intermediate
-            const u64 *srcp = stage[0] == '1' ? extL.u() : stage[0] == '2' ? extR.u() : ten.u();
-            if (const char *off = std::getenv("FHE_DEBUG_OFFSET")) srcp += (size_t)std::atoi(off) * N;
-            FHE_HIP_CHECK(hipMemcpyAsync(dst, srcp, (size_t)nb * parts * PL * sizeof(u64), hipMemcpyDeviceToDevice, s));
-            continue;
-        }
+        // DOWN-SCALE (mul.rs:204-206) to PowerBasis rows of d [3][nb][L][N]
+        launch_scale(*m.down, ten.u(), PK, d.u(), PL, nb * 3, s);
         if (m.rk) {
-            // DOWN-SCALE (mul.rs:204-206) to PowerBasis; c0, c1 go back to Ntt, c2 stays in
-            // PowerBasis for the key switch (the reference transforms c2 forward and, at mul.rs:212,
-            // back again; iNTT(NTT(x)) = x exactly, so the values are the same).
-            launch_ntt(e, true, ten.u(), ten.u(), full_map(e, K), nb * 3, k::PRO_NONE, s);
-            launch_scale(*m.down, ten.u(), PK, d.u(), PL, nb * 3, s);
+            // c0, c1 go back to Ntt; c2 stays in PowerBasis for the key switch (the reference
+            // transforms c2 forward and, at mul.rs:212, back again; iNTT(NTT(x)) = x exactly).
             launch_ntt(b, false, d.u(), d.u(), full_map(b, L), nb * 2, k::PRO_NONE, s);
             // RELINEARIZE (mul.rs:211-227): (c0, c1) += key_switch(c2), written to the output layout
             key_switch_add(*m.rk, d.u() + 2 * nb * PL, PL, d.u(), d.u() + nb * PL, PL, dst, dst + PL, 2 * PL, nb, s);
         } else {
             // no relinearisation: three Ntt parts, slot-major scratch -> [b][3][L][N]
-            scale_polys(*m.down, ten.u(), d.u(), nb * 3, true, s);
+            launch_ntt(b, false, d.u(), d.u(), full_map(b, L), nb * 3, k::PRO_NONE, s);
             for (size_t slot = 0; slot < 3; slot++) {
                 const u64 total = (u64)nb * PL;
                 FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0,

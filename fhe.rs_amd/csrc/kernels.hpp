@@ -320,6 +320,79 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     }
 }
 
+// ------------------------------------------------ fused tensor + inverse NTT ----
+// The tensor step of Multiplicator::multiply (F/bfv/ops/mul.rs:198-201) fused into the loader of
+// the inverse NTT that Scaler::scale applies next (M/rq/scaler.rs:69-79): the products
+//   slot 0: c00*c10   slot 1: c00*c11 + c01*c10   slot 2: c01*c11
+// are formed while the row is staged into LDS, so the Ntt-domain tensor never touches HBM.
+// Operands: (c00, c01) = extL[b][0..1], (c10, c11) = extR[b][0..1], each [K][N]; rows below
+// `ncommon` come straight from the input ciphertexts lhs/rhs [b][2][lrows][N] when given.
+// grid = (K rows, nb ciphertext pairs, 3 slots); out is slot-major [3][nb][K][N] PowerBasis.
+struct TensorSrc {
+    const u64 *extL, *extR, *lhs, *rhs;
+    uint32_t ncommon, lrows;
+};
+template <int LOGM>
+__global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
+    tensor_intt_kernel(TensorSrc ts, u64 *__restrict__ out, const DevMod *__restrict__ mods,
+                       const u64x2 *__restrict__ itw, const u64x2 *__restrict__ ninv, uint32_t nrows) {
+    FHE_DYN_SMEM(u64, lds);
+    constexpr int T = ntt_threads_c(LOGM);
+    constexpr int M = 1 << LOGM;
+    constexpr int CH = tile_chunks_c(LOGM, T);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t r = blockIdx.x, b = blockIdx.y, slot = blockIdx.z, nb = gridDim.y;
+    const DevMod md = mods[r];
+    const u64 p = md.p, p2 = md.p2;
+    const u64 pk = (u64)nrows << LOGM;
+    const u64 *a0, *a1, *b0, *b1;  // rows of c00, c01, c10, c11
+    if (ts.lhs && r < ts.ncommon) {
+        const u64 pl = (u64)ts.lrows << LOGM;
+        a0 = ts.lhs + (u64)b * 2 * pl + (u64)r * M;
+        a1 = a0 + pl;
+        b0 = ts.rhs + (u64)b * 2 * pl + (u64)r * M;
+        b1 = b0 + pl;
+    } else {
+        a0 = ts.extL + (u64)b * 2 * pk + (u64)r * M;
+        a1 = a0 + pk;
+        b0 = ts.extR + (u64)b * 2 * pk + (u64)r * M;
+        b1 = b0 + pk;
+    }
+    auto prod = [&](u64 x00, u64 x01, u64 x10, u64 x11) -> u64 {
+        if (slot == 0) return mul_mod(x00, x10, md);
+        if (slot == 2) return mul_mod(x01, x11, md);
+        return add_mod(mul_mod(x00, x11, md), mul_mod(x01, x10, md), p);
+    };
+    if constexpr (CH > 0) {
+        constexpr int HALF = CH > 1 ? CH / 2 : 1;  // loads of at most HALF chunks x 4 operands in flight
+#pragma unroll
+        for (int h = 0; h < CH; h += HALF) {
+            u64x2 v00[HALF], v01[HALF], v10[HALF], v11[HALF];
+#pragma unroll
+            for (int c = 0; c < HALF; c++) {
+                const uint32_t ci = (h + c) * T + tid;
+                if (slot != 2) v00[c] = reinterpret_cast<const u64x2 *>(a0)[ci];
+                if (slot != 0) v01[c] = reinterpret_cast<const u64x2 *>(a1)[ci];
+                if (slot != 2) v10[c] = reinterpret_cast<const u64x2 *>(b0)[ci];
+                if (slot != 0) v11[c] = reinterpret_cast<const u64x2 *>(b1)[ci];
+            }
+#pragma unroll
+            for (int c = 0; c < HALF; c++) {
+                const uint32_t i = 2 * ((h + c) * T + tid);
+                lds[padi(i)] = prod(v00[c].x, v01[c].x, v10[c].x, v11[c].x);
+                lds[padi(i + 1)] = prod(v00[c].y, v01[c].y, v10[c].y, v11[c].y);
+            }
+            sched_fence();
+        }
+    } else {
+        for (uint32_t i = tid; i < M; i += T) lds[padi(i)] = prod(a0[i], a1[i], b0[i], b1[i]);
+    }
+    __syncthreads();
+    ntt_inv_lds<LOGM, T>(lds, itw + (u64)r * M, LOGM, 0, p, p2, tid, true, ninv[2 * r], ninv[2 * r + 1]);
+    u64 *dst = out + ((u64)slot * nb + b) * pk + (u64)r * M;
+    lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub(v, p); });
+}
+
 // Radix stages that span sub-blocks, done straight on global memory (coalesced along the
 // low index).  Forward: stages [0, G0) before the LDS kernel (output < 4p, the LDS kernel's
 // loader accepts that range).  Inverse: stages [logm, logn) after it, then N^-1.

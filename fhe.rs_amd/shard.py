@@ -30,7 +30,8 @@ def timed_steps(step, steps, sync, dist=None, device=None):
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        on_gpu = device is not None and dist.get_backend() == "nccl"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed

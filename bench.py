@@ -148,10 +148,11 @@ def main():
     # each row-NTT reads and writes its row once (2R); the fused key switch reads L rows, writes
     # 2*Lk rows and reads 2 addend rows per key modulus (the key itself is cache resident).
     alg_rows = {
-        "ntt_inv": 2 * (4 * L + 3 * K),
-        "ntt_fwd": 2 * (4 * (K - L) + 2 * L),
-        "key_switch_fused": L * L + 4 * L,
-        "scale": (4 * (L + (K - L))) + 3 * (K + L),
+        "ntt_inv": 2 * (4 * L),                       # extend: inverse NTT of the 4 input polynomials
+        "tensor_intt": 8 * K + 3 * K,                 # fused tensor + inverse NTT: reads 2+4+2, writes 3 rows per modulus
+        "ntt_fwd": 2 * (4 * (K - L) + 2 * L),         # new rows of the 4 extended polys + (c0, c1)
+        "key_switch_fused": L * L + 4 * L,            # L digit rows per key modulus, 2 addend rows + 2 output rows
+        "scale": (4 * (L + (K - L))) + 3 * (K + L),   # extend 4 polys (L in, K-L out), down-scale 3 polys (K in, L out)
         "tensor": 7 * K,
         "copy_rows": 2 * 4 * L,
     }

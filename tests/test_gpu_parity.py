@@ -142,3 +142,45 @@ def test_config_c5_chain_n32768(fhe):
     first levels of the chain (RNS basis-conversion stress; the row does not fit LDS)."""
     import full_size
     full_size.check_chain(fhe, n=32768, sizes=[60] * 16, batch=2, levels=2, cfg=5)
+
+
+def test_max_degree_n65536(fhe):
+    """Largest degree the reference accepts (parameters.rs MAX_DEGREE = 65536): ct x ct + relin,
+    rows go through the two-kernel NTT and the unfused key switch."""
+    import full_size
+    full_size.check_mul(fhe, n=65536, sizes=[60, 60], batch=2, relin=True, cfg=6)
+
+
+def test_concurrent_streams_share_handles(fhe):
+    """Handles are immutable and may be shared by concurrent callers working on different
+    buffers (one HIP stream per calling thread) -- SURVEY.md 8(b) threading contract."""
+    import threading
+    import torch
+    import full_size
+    from fhe_oracle import bfv as obfv, synth
+    n, sizes = 4096, [60, 60, 60]
+    q = obfv.generate_moduli(sizes, n)
+    par = fhe.BfvParameters(n, full_size.plaintext_modulus(n), moduli=q)
+    ctx = par.context_at_level(0)
+    c0, c1 = full_size.device_key(ctx, 77, len(q))
+    m = fhe.Multiplicator.default(par, fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1)), 0)
+    ins = [(ctx.synth_uniform(100 + i, 0, 0, 2, 24), ctx.synth_uniform(100 + i, 0, 2, 2, 24)) for i in range(4)]
+    want = [m.multiply(a, b) for a, b in ins]
+    torch.cuda.synchronize()
+    got, errs = [None] * 4, []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    got[i] = m.multiply(*ins[i])
+            st.synchronize()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for i in range(4):
+        assert torch.equal(got[i], want[i])

@@ -75,6 +75,14 @@ SIGNATURES = {
     "fhe_bfv_galois_dev": (i32, [vp, sz, vp, vp, sz, vp]),
     "fhe_bfv_switch_down": (i32, [vp, sz, u64p, u64p, sz]),
     "fhe_bfv_switch_down_dev": (i32, [vp, sz, vp, vp, sz, vp]),
+    "fhe_bfv_dot_product_scalar": (i32, [vp, sz, sz, u64p, i32, u64p, i32, u64p, sz]),
+    "fhe_bfv_dot_product_scalar_dev": (i32, [vp, sz, sz, vp, i32, vp, i32, vp, sz, vp]),
+    "fhe_bfv_mul_plain": (i32, [vp, sz, u64p, u64p, i32, u64p, sz]),
+    "fhe_bfv_mul_plain_dev": (i32, [vp, sz, vp, vp, i32, vp, sz, vp]),
+    "fhe_bfv_rgsw_mul": (i32, [vp, vp, u64p, u64p, sz]),
+    "fhe_bfv_rgsw_mul_dev": (i32, [vp, vp, vp, vp, sz, vp]),
+    "fhe_bfv_inner_sum": (i32, [C.POINTER(vp), szp, sz, u64p, u64p, sz]),
+    "fhe_bfv_inner_sum_dev": (i32, [C.POINTER(vp), szp, sz, vp, vp, sz, vp]),
     "fhe_mul_create": (i32, [vp, vp, vp, vp, i32, C.POINTER(vp)]),
     "fhe_mul_destroy": (None, [vp]),
     "fhe_mul_out_shape": (i32, [vp, szp, szp]),

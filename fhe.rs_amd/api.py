@@ -216,6 +216,49 @@ class Context:
         check(L.fhe_bfv_switch_down(self._h, parts, _ptr(x), _ptr(out), b))
         return out
 
+    def dot_product_scalar(self, cts, pts):
+        """bfv::dot_product_scalar (crates/fhe/src/bfv/ops/dot_product.rs:54-180):
+        cts [..., count, parts, L, N] and pts [..., count, L, N] (`Plaintext::poly_ntt`), or either
+        without the leading batch dims (then shared by the batch) -> [..., parts, L, N].
+        With parts == 1 this is fhe_math::rq::dot_product (rq/ops.rs:449-570)."""
+        L = _lib.lib()
+        cb, pb = tuple(cts.shape[:-4]), tuple(pts.shape[:-3])
+        count, parts = cts.shape[-4], cts.shape[-3]
+        if pts.shape[-3] != count:
+            raise FheError(-1, "DotProductLengthMismatch")
+        bshape = cb if len(cb) >= len(pb) else pb
+        batch = 1
+        for d in bshape:
+            batch *= d
+        cts_shared = 1 if (cb != bshape) else 0
+        pts_shared = 1 if (pb != bshape) else 0
+        oshape = bshape + (parts, self.nmoduli, self.degree)
+        if _is_dev(cts):
+            out = torch.empty(oshape, dtype=cts.dtype, device=cts.device)
+            check(L.fhe_bfv_dot_product_scalar_dev(self._h, parts, count, _dptr(cts), cts_shared, _dptr(pts), pts_shared,
+                                                   _dptr(out), batch, _stream()))
+            return out
+        x, y = _np(cts), _np(pts)
+        out = np.zeros(oshape, dtype=np.uint64)
+        check(L.fhe_bfv_dot_product_scalar(self._h, parts, count, _ptr(x), cts_shared, _ptr(y), pts_shared, _ptr(out), batch))
+        return out
+
+    def mul_plain(self, ct, pt):
+        """`&Ciphertext * &Plaintext` (ops/mod.rs:229-257): ct [..., parts, L, N] times pt [..., L, N]
+        (or [L, N] shared by the batch)."""
+        L = _lib.lib()
+        parts = ct.shape[-3]
+        batch = self._batch(ct) // parts
+        shared = 1 if len(pt.shape) == 2 and len(ct.shape) > 3 else 0
+        if _is_dev(ct):
+            out = torch.empty_like(ct)
+            check(L.fhe_bfv_mul_plain_dev(self._h, parts, _dptr(ct), _dptr(pt), shared, _dptr(out), batch, _stream()))
+            return out
+        x, y = _np(ct), _np(pt)
+        out = np.zeros_like(x)
+        check(L.fhe_bfv_mul_plain(self._h, parts, _ptr(x), _ptr(y), shared, _ptr(out), batch))
+        return out
+
     def synth_uniform(self, seed, ct0, part0, nparts, batch):
         """Device-side synthetic residues [batch, nparts, L, N] (bench / parity inputs)."""
         out = torch.empty((batch, nparts, self.nmoduli, self.degree), dtype=torch.int64, device=f"cuda:{self.device}")
@@ -400,6 +443,30 @@ class EvaluationKey:
             raise FheError(-11, "EvaluationKeyError::Unsupported(RowRotation)")
         return self.gk[e].relinearize(ct)
 
+    def computes_inner_sum(self, ct):
+        """EvaluationKey::computes_inner_sum (evaluation_key.rs:56-100)."""
+        n = self.degree
+        seq, i = [], 1
+        while i < n // 2:
+            seq.append(pow(3, i, 2 * n))
+            i *= 2
+        seq.append(2 * n - 1)
+        if any(e not in self.gk for e in seq):
+            raise FheError(-11, "EvaluationKeyError::Unsupported(InnerSum)")
+        L = _lib.lib()
+        handles = (C.c_void_p * len(seq))(*[self.gk[e].ksk._h for e in seq])
+        exps = (C.c_size_t * len(seq))(*seq)
+        ctx = self.gk[seq[0]].ksk.ctx_ciphertext
+        b = ctx._batch(ct) // 2
+        if _is_dev(ct):
+            out = torch.empty_like(ct)
+            check(L.fhe_bfv_inner_sum_dev(handles, exps, len(seq), _dptr(ct), _dptr(out), b, _stream()))
+            return out
+        x = _np(ct)
+        out = np.zeros_like(x)
+        check(L.fhe_bfv_inner_sum(handles, exps, len(seq), _ptr(x), _ptr(out), b))
+        return out
+
     def rotates_columns_by(self, ct, i):
         if not (1 <= i < self.degree // 2):
             raise FheError(-1, "InvalidRotationStep")
@@ -407,6 +474,29 @@ class EvaluationKey:
         if e not in self.gk:
             raise FheError(-11, "EvaluationKeyError::Unsupported(ColumnRotation)")
         return self.gk[e].relinearize(ct)
+
+
+class RGSWCiphertext:
+    """bfv::RGSWCiphertext{ksk0, ksk1} (crates/fhe/src/bfv/rgsw_ciphertext.rs:19-156)."""
+
+    def __init__(self, ksk0: KeySwitchingKey, ksk1: KeySwitchingKey):
+        self.ksk0, self.ksk1 = ksk0, ksk1
+
+    def external_product(self, ct):
+        """`&Ciphertext * &RGSWCiphertext`: ct, result [..., 2, L, N] Ntt."""
+        L = _lib.lib()
+        ctx = self.ksk0.ctx_ciphertext
+        if ct.shape[-3] != 2:
+            raise FheError(-13, "Ciphertext must have two parts")
+        b = ctx._batch(ct) // 2
+        if _is_dev(ct):
+            out = torch.empty_like(ct)
+            check(L.fhe_bfv_rgsw_mul_dev(self.ksk0._h, self.ksk1._h, _dptr(ct), _dptr(out), b, _stream()))
+            return out
+        x = _np(ct)
+        out = np.zeros_like(x)
+        check(L.fhe_bfv_rgsw_mul(self.ksk0._h, self.ksk1._h, _ptr(x), _ptr(out), b))
+        return out
 
 
 class BfvParameters:

@@ -23,7 +23,7 @@ enum : int {
     E_CONTEXT_MISMATCH = -6, E_DEGREE_MISMATCH = -7, E_NO_MORE_CONTEXT = -8, E_CONTEXT_NOT_REACHABLE = -9,
     E_INVALID_SUBST = -10, E_PARAMETER_MISMATCH = -11, E_INVALID_LEVEL = -12, E_MUL_POLY_COUNT = -13,
     E_EMPTY_MODULI = -14, E_NON_COPRIME = -15, E_NOT_ENOUGH_PRIMES = -16, E_KEYSWITCH_UNSUPPORTED = -17,
-    E_NO_DEVICE = -18
+    E_NO_DEVICE = -18, E_EMPTY_DOT = -19
 };
 
 #define FHE_HIP_CHECK(expr)                                                                        \
@@ -222,12 +222,13 @@ struct Ctx {
     std::unique_ptr<Ctx> next;                  // next_context
     // device tables (owned by root; children alias them)
     DevBuf<DevMod> d_mods;
-    DevBuf<k::u64x2> d_tw, d_itw, d_ninv, d_inv_last;
+    DevBuf<k::u64x2> d_tw, d_itw, d_ninv, d_inv_last, d_pow2;
 
     const DevMod *dmods() const { return root->d_mods.p; }
     const k::u64x2 *dtw() const { return root->d_tw.p; }
     const k::u64x2 *ditw() const { return root->d_itw.p; }
     const k::u64x2 *dninv() const { return root->d_ninv.p; }
+    const k::u64x2 *dpow2() const { return root->d_pow2.p; }
     const NttTables &tab(size_t i) const { return root->tabs[i]; }
     size_t poly_elems() const { return L * n; }
     void need_device() const { require(device >= 0, E_NO_DEVICE, "handle was created host-only (device = -1)"); }
@@ -325,6 +326,12 @@ inline std::unique_ptr<Ctx> ctx_create(int device, size_t degree, const std::vec
         c->d_tw.upload(tw);
         c->d_itw.upload(itw);
         c->d_ninv.upload(ninv);
+        std::vector<k::u64x2> pow2(c->L);
+        for (size_t i = 0; i < c->L; i++) {
+            const u64 two64 = (u64)((((u128)1) << 64) % moduli[i]);
+            pow2[i] = k::u64x2{two64, mulmod(two64, two64, moduli[i])};
+        }
+        c->d_pow2.upload(pow2);
     }
     ctx_fill_inv_last(*c);
     // next_context chain (M/rq/context.rs:75-79): prefixes sharing the root's tables
@@ -744,6 +751,82 @@ inline void key_switch_add(const Ksk &k_, const u64 *p, u64 p_stride, const u64 
             FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s,
                        jb.d, jb.o, cstride, out_stride, per, total);
         }
+    }
+}
+
+// --------------------------------------------------- PIR / RGSW / inner sum ----
+// dot_product_scalar (F/bfv/ops/dot_product.rs:54-180) / rq::dot_product (M/rq/ops.rs:449-570)
+inline void dot_product_scalar(const Ctx &c, size_t nparts, size_t count, const u64 *cts, bool cts_shared,
+                               const u64 *pts, bool pts_shared, u64 *out, size_t batch, hipStream_t s) {
+    c.need_device();
+    require(count > 0, E_EMPTY_DOT, "EmptyDotProduct: no operands");
+    if (!batch || !nparts) return;
+    const u64 pl = (u64)c.L * c.n;
+    require(batch <= 65535 && nparts <= 65535, E_ARG, "dot product: batch / parts exceed the grid limits");
+    FHE_LAUNCH("dot_product", k::dot_kernel, dim3(blocks_for(pl / 2, EW_THREADS), (unsigned)nparts, (unsigned)batch),
+               dim3(EW_THREADS), 0, s, cts, cts_shared ? (u64)0 : (u64)count * nparts * pl, pts,
+               pts_shared ? (u64)0 : (u64)count * pl, out, c.dmods(), c.dpow2(), (uint32_t)nparts, (uint32_t)count,
+               (uint32_t)c.logn, pl);
+}
+
+// `Ciphertext * Plaintext` (F/bfv/ops/mod.rs:229-257)
+inline void mul_plain(const Ctx &c, size_t nparts, const u64 *ct, const u64 *pt, bool pt_shared, u64 *out,
+                      size_t batch, hipStream_t s) {
+    c.need_device();
+    if (!batch || !nparts) return;
+    const u64 pl = (u64)c.L * c.n;
+    require(batch <= 65535 && nparts <= 65535, E_ARG, "mul_plain: batch / parts exceed the grid limits");
+    FHE_LAUNCH("mul_plain", k::mul_plain_kernel, dim3(blocks_for(pl, EW_THREADS), (unsigned)nparts, (unsigned)batch),
+               dim3(EW_THREADS), 0, s, ct, pt, pt_shared ? (u64)0 : pl, out, c.dmods(), (uint32_t)nparts,
+               (uint32_t)c.logn, pl);
+}
+
+// GaloisKey::relinearize (F/bfv/keys/galois_key.rs:63-86): ct, out [batch][2][L][N] Ntt
+inline void galois_apply(const Ksk &ks, size_t exponent, const u64 *ct, u64 *out, size_t batch, hipStream_t s) {
+    const Ctx &cc = *ks.ct_ctx;
+    const u64 PL = (u64)cc.L * cc.n;
+    if (!batch) return;
+    // substitute both parts at once: sub [b][2][L][N]; c2 = PowerBasis(substitute(c1))
+    WsGuard sub(batch * 2 * PL * sizeof(u64), s), c2(batch * PL * sizeof(u64), s);
+    substitute_polys(cc, exponent, ct, sub.u(), batch * 2, true, s);
+    k::RowMap m = full_map(cc, cc.L);
+    m.src_poly_stride = 2 * PL;
+    m.dst_poly_stride = PL;
+    launch_ntt(cc, true, sub.u() + PL, c2.u(), m, batch, k::PRO_NONE, s);
+    // out0 = key_switch0 + substitute(c0) ; out1 = key_switch1   (galois_key.rs:66-79)
+    key_switch_add(ks, c2.u(), PL, sub.u(), nullptr, 2 * PL, out, out + PL, 2 * PL, batch, s);
+}
+
+// `&Ciphertext * &RGSWCiphertext` (F/bfv/rgsw_ciphertext.rs:122-156)
+inline void rgsw_mul(const Ksk &k0, const Ksk &k1, const u64 *ct, u64 *out, size_t batch, hipStream_t s) {
+    const Ctx &cc = *k0.ct_ctx;
+    require(k0.ct_ctx->same_ring(*k1.ct_ctx) && k0.ksk_ctx->same_ring(*k0.ct_ctx) &&
+                k1.ksk_ctx->same_ring(*k1.ct_ctx),
+            E_PARAMETER_MISMATCH, "RGSW: both key-switching keys must live at the ciphertext level");
+    cc.need_device();
+    if (!batch) return;
+    const u64 PL = (u64)cc.L * cc.n;
+    WsGuard pb(batch * 2 * PL * sizeof(u64), s), t(batch * 2 * PL * sizeof(u64), s);
+    launch_ntt(cc, true, ct, pb.u(), full_map(cc, cc.L), batch * 2, k::PRO_NONE, s);   // ct0, ct1 -> PowerBasis
+    // (c0, c1) = ksk0.key_switch(ct0);  out = (c0, c1) + ksk1.key_switch(ct1)
+    key_switch_polys(k0, pb.u(), 2 * PL, t.u(), t.u() + PL, 2 * PL, nullptr, nullptr, 0, batch, s);
+    key_switch_polys(k1, pb.u() + PL, 2 * PL, out, out + PL, 2 * PL, t.u(), t.u() + PL, 2 * PL, batch, s);
+}
+
+// EvaluationKey::computes_inner_sum (F/bfv/keys/evaluation_key.rs:56-100)
+inline void inner_sum(const Ksk *const *gks, const size_t *exps, size_t ngk, const u64 *ct, u64 *out, size_t batch,
+                      hipStream_t s) {
+    require(ngk > 0, E_ARG, "inner sum needs at least one Galois key");
+    const Ctx &cc = *gks[0]->ct_ctx;
+    cc.need_device();
+    if (!batch) return;
+    const u64 total = (u64)batch * 2 * cc.L * cc.n;
+    WsGuard tmp(total * sizeof(u64), s);
+    FHE_HIP_CHECK(hipMemcpyAsync(out, ct, total * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    for (size_t i = 0; i < ngk; i++) {
+        require(gks[i]->ct_ctx->same_ring(cc), E_PARAMETER_MISMATCH, "inner sum: Galois keys of different levels");
+        galois_apply(*gks[i], exps[i], out, tmp.u(), batch, s);
+        ew_op(cc, out, tmp.u(), batch * 2, k::EW_ADD, s);
     }
 }
 

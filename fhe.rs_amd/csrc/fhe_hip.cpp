@@ -692,20 +692,8 @@ fhe_status fhe_bfv_relinearize(const fhe_ksk *rk, const uint64_t *ct3, uint64_t 
     });
 }
 
-// GaloisKey::relinearize: ct [b][2][L][N] -> out [b][2][L][N]
 static void galois_run(const Ksk &ks, size_t exponent, const u64 *ct, u64 *out, size_t batch, hipStream_t s) {
-    const Ctx &cc = *ks.ct_ctx;
-    const u64 PL = (u64)cc.L * cc.n;
-    if (!batch) return;
-    // substitute both parts at once: sub [b][2][L][N]; c2 = PowerBasis(substitute(c1))
-    WsGuard sub(batch * 2 * PL * sizeof(u64), s), c2(batch * PL * sizeof(u64), s);
-    substitute_polys(cc, exponent, ct, sub.u(), batch * 2, true, s);
-    k::RowMap m = full_map(cc, cc.L);
-    m.src_poly_stride = 2 * PL;
-    m.dst_poly_stride = PL;
-    launch_ntt(cc, true, sub.u() + PL, c2.u(), m, batch, k::PRO_NONE, s);
-    // out0 = key_switch0 + substitute(c0) ; out1 = key_switch1   (galois_key.rs:66-79)
-    key_switch_add(ks, c2.u(), PL, sub.u(), nullptr, 2 * PL, out, out + PL, 2 * PL, batch, s);
+    galois_apply(ks, exponent, ct, out, batch, s);
 }
 fhe_status fhe_bfv_galois_dev(const fhe_ksk *gk, size_t exponent, const uint64_t *ct, uint64_t *out, size_t batch,
                               void *stream) {
@@ -761,6 +749,139 @@ fhe_status fhe_bfv_switch_down(const fhe_ctx *ctx, size_t nparts, const uint64_t
         u64 *di = io.in(ct, batch * nparts * pe), *dout = io.out(batch * nparts * (pe - c.n));
         bfv_switch_down(c, nparts, di, dout, batch, nullptr);
         io.back(out, dout, batch * nparts * (pe - c.n));
+    });
+}
+
+// ------------------------------------------------------ PIR / RGSW / inner sum ----
+fhe_status fhe_bfv_dot_product_scalar_dev(const fhe_ctx *ctx, size_t nparts, size_t count, const uint64_t *cts,
+                                          int cts_shared, const uint64_t *pts, int pts_shared, uint64_t *out,
+                                          size_t batch, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        if (batch && nparts && count) {
+            need(cts, "cts");
+            need(pts, "pts");
+            need(out, "out");
+        }
+        dot_product_scalar(c, nparts, count, cts, cts_shared != 0, pts, pts_shared != 0, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_dot_product_scalar(const fhe_ctx *ctx, size_t nparts, size_t count, const uint64_t *cts,
+                                      int cts_shared, const uint64_t *pts, int pts_shared, uint64_t *out,
+                                      size_t batch) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (count == 0) throw StatusError(FHE_E_EMPTY_DOT_PRODUCT, "EmptyDotProduct: no operands");
+        if (batch && nparts) {
+            need(cts, "cts");
+            need(pts, "pts");
+            need(out, "out");
+        }
+        HostIO io;
+        u64 *dc = io.in(cts, (cts_shared ? 1 : batch) * count * nparts * pe);
+        u64 *dp = io.in(pts, (pts_shared ? 1 : batch) * count * pe);
+        u64 *dout = io.out(batch * nparts * pe);
+        dot_product_scalar(c, nparts, count, dc, cts_shared != 0, dp, pts_shared != 0, dout, batch, nullptr);
+        io.back(out, dout, batch * nparts * pe);
+    });
+}
+fhe_status fhe_bfv_mul_plain_dev(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, const uint64_t *pt,
+                                 int pt_shared, uint64_t *out, size_t batch, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        if (batch && nparts) {
+            need(ct, "ct");
+            need(pt, "pt");
+            need(out, "out");
+        }
+        mul_plain(c, nparts, ct, pt, pt_shared != 0, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_mul_plain(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, const uint64_t *pt, int pt_shared,
+                             uint64_t *out, size_t batch) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch && nparts) {
+            need(ct, "ct");
+            need(pt, "pt");
+            need(out, "out");
+        }
+        HostIO io;
+        u64 *dc = io.in(ct, batch * nparts * pe), *dp = io.in(pt, (pt_shared ? 1 : batch) * pe);
+        u64 *dout = io.out(batch * nparts * pe);
+        mul_plain(c, nparts, dc, dp, pt_shared != 0, dout, batch, nullptr);
+        io.back(out, dout, batch * nparts * pe);
+    });
+}
+fhe_status fhe_bfv_rgsw_mul_dev(const fhe_ksk *ksk0, const fhe_ksk *ksk1, const uint64_t *ct, uint64_t *out,
+                                size_t batch, void *stream) {
+    return guard([&] {
+        need(ksk0, "ksk0");
+        need(ksk1, "ksk1");
+        if (batch) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        set_device(*ksk0->k->ksk_ctx);
+        rgsw_mul(*ksk0->k, *ksk1->k, ct, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_rgsw_mul(const fhe_ksk *ksk0, const fhe_ksk *ksk1, const uint64_t *ct, uint64_t *out, size_t batch) {
+    return guard([&] {
+        need(ksk0, "ksk0");
+        need(ksk1, "ksk1");
+        if (batch) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        const Ksk &k0 = *ksk0->k;
+        set_device(*k0.ksk_ctx);
+        const size_t pe = k0.ct_ctx->L * k0.ct_ctx->n;
+        HostIO io;
+        u64 *di = io.in(ct, batch * 2 * pe), *dout = io.out(batch * 2 * pe);
+        rgsw_mul(k0, *ksk1->k, di, dout, batch, nullptr);
+        io.back(out, dout, batch * 2 * pe);
+    });
+}
+static void inner_sum_args(const fhe_ksk *const *gks, const size_t *exponents, size_t ngk, std::vector<const Ksk *> &v) {
+    need(gks, "gks");
+    need(exponents, "exponents");
+    if (ngk == 0) throw StatusError(FHE_E_ARG, "inner sum needs at least one Galois key");
+    for (size_t i = 0; i < ngk; i++) {
+        need(gks[i], "gks[i]");
+        v.push_back(gks[i]->k.get());
+    }
+}
+fhe_status fhe_bfv_inner_sum_dev(const fhe_ksk *const *gks, const size_t *exponents, size_t ngk, const uint64_t *ct,
+                                 uint64_t *out, size_t batch, void *stream) {
+    return guard([&] {
+        std::vector<const Ksk *> v;
+        inner_sum_args(gks, exponents, ngk, v);
+        if (batch) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        set_device(*v[0]->ksk_ctx);
+        inner_sum(v.data(), exponents, ngk, ct, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_inner_sum(const fhe_ksk *const *gks, const size_t *exponents, size_t ngk, const uint64_t *ct,
+                             uint64_t *out, size_t batch) {
+    return guard([&] {
+        std::vector<const Ksk *> v;
+        inner_sum_args(gks, exponents, ngk, v);
+        if (batch) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        set_device(*v[0]->ksk_ctx);
+        const size_t pe = v[0]->ct_ctx->L * v[0]->ct_ctx->n;
+        HostIO io;
+        u64 *di = io.in(ct, batch * 2 * pe), *dout = io.out(batch * 2 * pe);
+        inner_sum(v.data(), exponents, ngk, di, dout, batch, nullptr);
+        io.back(out, dout, batch * 2 * pe);
     });
 }
 

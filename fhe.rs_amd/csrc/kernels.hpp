@@ -822,6 +822,55 @@ __global__ void tensor_kernel(const u64 *__restrict__ extL, const u64 *__restric
     o[nb * pn] = add_mod(mul_mod(c00, c11, m), mul_mod(c01, c10, m), m.p);
     o[2 * nb * pn] = mul_mod(c01, c11, m);
 }
+// dot_product_scalar / rq::dot_product (F/bfv/ops/dot_product.rs:54-180, M/rq/ops.rs:449-570):
+// out[b][part][row][c] = sum_k cts[b][k][part][row][c] * pts[b][k][row][c]  mod q_row.
+// One lane per pair of coefficients; exact 128-bit products accumulated in 192 bits and reduced
+// once (the reference's periodic reduce_u128 gives the same canonical sum).  Streaming, HBM bound.
+__global__ void dot_kernel(const u64 *__restrict__ cts, u64 ct_batch_stride, const u64 *__restrict__ pts,
+                           u64 pt_batch_stride, u64 *__restrict__ out, const DevMod *__restrict__ mods,
+                           const u64x2 *__restrict__ pow2 /* {2^64, 2^128} mod q */, uint32_t nparts, uint32_t count,
+                           uint32_t logn, u64 pl /* L*N */) {
+    // grid: x = pairs of coefficients of one polynomial, y = part, z = batch
+    const u64 pair = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * pair >= pl) return;
+    const u64 off = 2 * pair;
+    const uint32_t part = blockIdx.y, b = blockIdx.z;
+    const uint32_t row = (uint32_t)(off >> logn);
+    const DevMod m = mods[row];
+    const u64 *cp = cts + (u64)b * ct_batch_stride + (u64)part * pl + off;
+    const u64 *pp = pts + (u64)b * pt_batch_stride + off;
+    u128_t a0 = 0, a1 = 0;
+    u64 t0 = 0, t1 = 0;
+    for (uint32_t k = 0; k < count; k++) {
+        const u64x2 x = *reinterpret_cast<const u64x2 *>(cp + (u64)k * nparts * pl);
+        const u64x2 y = *reinterpret_cast<const u64x2 *>(pp + (u64)k * pl);
+        mac192(a0, t0, x.x, y.x);
+        mac192(a1, t1, x.y, y.y);
+    }
+    // value = top * 2^128 + a: reduce a, then add (top mod q) * (2^128 mod q)
+    const u64 c128 = pow2[row].y;
+    auto fold = [&](u128_t a, u64 top) -> u64 {
+        const u64 r = reduce_u128((u64)(a >> 64), (u64)a, m);
+        return top ? add_mod(r, mul_mod(reduce_u64(top, m), c128, m), m.p) : r;
+    };
+    u64x2 o;
+    o.x = fold(a0, t0);
+    o.y = fold(a1, t1);
+    *reinterpret_cast<u64x2 *>(out + ((u64)b * nparts + part) * pl + off) = o;
+}
+
+// `Ciphertext * Plaintext` (F/bfv/ops/mod.rs:229-257): out[b][part] = ct[b][part] (.) pt[b].
+__global__ void mul_plain_kernel(const u64 *__restrict__ ct, const u64 *__restrict__ pt, u64 pt_batch_stride,
+                                 u64 *__restrict__ out, const DevMod *__restrict__ mods, uint32_t nparts, uint32_t logn,
+                                 u64 pl) {
+    const u64 off = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (off >= pl) return;
+    const uint32_t part = blockIdx.y, b = blockIdx.z;
+    const DevMod m = mods[off >> logn];
+    const u64 idx = ((u64)b * nparts + part) * pl + off;
+    out[idx] = mul_mod(ct[idx], pt[(u64)b * pt_batch_stride + off], m);
+}
+
 // Copies the first `rows` rows of each polynomial: in [npolys][in_rows][N] -> out [npolys][out_rows][N].
 __global__ void copy_rows_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,
                                  u64 out_poly_stride, u64 per_poly, u64 total) {

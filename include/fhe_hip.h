@@ -50,7 +50,8 @@ enum {
     FHE_E_NON_COPRIME = -15,                  /* Error::NonCoprimeModuli                          */
     FHE_E_NOT_ENOUGH_PRIMES = -16,            /* ParametersError::NotEnoughPrimes                 */
     FHE_E_KEYSWITCH_UNSUPPORTED = -17,        /* EvaluationKeyError::KeySwitchingNotSupported     */
-    FHE_E_NO_DEVICE = -18                     /* compute call on a host-only (device = -1) handle */
+    FHE_E_NO_DEVICE = -18,                    /* compute call on a host-only (device = -1) handle */
+    FHE_E_EMPTY_DOT_PRODUCT = -19             /* Error::EmptyDotProduct / DotProductError::EmptyInput */
 };
 
 typedef struct fhe_ctx fhe_ctx;       /* == rq::Context on one device   (M/rq/context.rs:9-19)        */
@@ -188,6 +189,36 @@ fhe_status fhe_bfv_galois_dev(const fhe_ksk *gk, size_t exponent, const uint64_t
 fhe_status fhe_bfv_switch_down(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, uint64_t *out, size_t batch);
 fhe_status fhe_bfv_switch_down_dev(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, uint64_t *out,
                                    size_t batch, void *stream);
+
+/* ------------------------------------ PIR / RGSW / inner sum ("next" rows) ---- */
+/* fhe_math::rq::dot_product (M/rq/ops.rs:449-570) and bfv::dot_product_scalar
+ * (F/bfv/ops/dot_product.rs:54-180): out[b][part] = sum_k cts[b][k][part] (.) pts[b][k], all Ntt.
+ * cts: [batch][count][nparts][L][N] (or [count][nparts][L][N] shared by the batch when cts_shared != 0);
+ * pts: [batch][count][L][N] (`Plaintext::poly_ntt`; shared when pts_shared != 0); out: [batch][nparts][L][N].
+ * nparts = 1 is the polynomial dot product.  count == 0 -> FHE_E_EMPTY_DOT_PRODUCT. */
+fhe_status fhe_bfv_dot_product_scalar(const fhe_ctx *ctx, size_t nparts, size_t count, const uint64_t *cts,
+                                      int cts_shared, const uint64_t *pts, int pts_shared, uint64_t *out,
+                                      size_t batch);
+fhe_status fhe_bfv_dot_product_scalar_dev(const fhe_ctx *ctx, size_t nparts, size_t count, const uint64_t *cts,
+                                          int cts_shared, const uint64_t *pts, int pts_shared, uint64_t *out,
+                                          size_t batch, void *stream);
+/* `Ciphertext * Plaintext` (F/bfv/ops/mod.rs:229-257): out[b][part] = ct[b][part] (.) pt[b] (pt shared if pt_shared). */
+fhe_status fhe_bfv_mul_plain(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, const uint64_t *pt, int pt_shared,
+                             uint64_t *out, size_t batch);
+fhe_status fhe_bfv_mul_plain_dev(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, const uint64_t *pt,
+                                 int pt_shared, uint64_t *out, size_t batch, void *stream);
+/* `&Ciphertext * &RGSWCiphertext` (F/bfv/rgsw_ciphertext.rs:122-156), RGSWCiphertext{ksk0, ksk1}:
+ * ct, out [batch][2][L][N] Ntt; both keys at the ciphertext level. */
+fhe_status fhe_bfv_rgsw_mul(const fhe_ksk *ksk0, const fhe_ksk *ksk1, const uint64_t *ct, uint64_t *out, size_t batch);
+fhe_status fhe_bfv_rgsw_mul_dev(const fhe_ksk *ksk0, const fhe_ksk *ksk1, const uint64_t *ct, uint64_t *out,
+                                size_t batch, void *stream);
+/* EvaluationKey::computes_inner_sum (F/bfv/keys/evaluation_key.rs:56-100): out = ct; for every
+ * (gks[i], exponents[i]) in order: out += GaloisKey::relinearize(out).  The caller passes the keys for
+ * 3^(2^j) mod 2N, j = 0 .. log2(N/2)-1, then 2N-1 (exactly the reference's sequence). */
+fhe_status fhe_bfv_inner_sum(const fhe_ksk *const *gks, const size_t *exponents, size_t ngk, const uint64_t *ct,
+                             uint64_t *out, size_t batch);
+fhe_status fhe_bfv_inner_sum_dev(const fhe_ksk *const *gks, const size_t *exponents, size_t ngk, const uint64_t *ct,
+                                 uint64_t *out, size_t batch, void *stream);
 
 /* ------------------------------------------------------------- Multiplicator ---- */
 /* Multiplicator::new_leveled_internal + enable_relinearization + enable_mod_switching

@@ -549,3 +549,95 @@ class Multiplicator:
         if self.mod_switch:
             out.switch_down()
         return out
+
+
+# --------------------------------------------------------------------------------------
+# "next" rows of SURVEY.md 8(f): PIR server inner loop, RGSW external product, inner sum
+# --------------------------------------------------------------------------------------
+def poly_dot_product(ps, qs):
+    """rq/ops.rs:449-570 (`dot_product`): sum_k p_k (.) q_k over Ntt polynomials; the u128
+    lazy accumulation with periodic reduce_u128 yields the canonical sum of products."""
+    ps, qs = list(ps), list(qs)
+    if not ps or not qs:
+        raise ValueError("EmptyDotProduct")
+    if len(ps) != len(qs):
+        raise ValueError("DotProductLengthMismatch")
+    ctx = ps[0].ctx
+    if any(p.ctx != ctx for p in ps) or any(q.ctx != ctx for q in qs):
+        raise ValueError("PolynomialContextMismatch")
+    rows = []
+    for r, qi in enumerate(ctx.q):
+        max_acc = 1 << (2 * qi.leading_zeros)
+        acc = [0] * ctx.degree
+        num_acc = 1
+        for p, q in zip(ps, qs):
+            pr, qr = p.coefficients[r], q.coefficients[r]
+            acc = [a + x * y for a, x, y in zip(acc, pr, qr)]
+            num_acc += 1
+            if len(ps) > max_acc and num_acc == max_acc:
+                acc = [qi.reduce_u128(a) for a in acc]
+                num_acc = 1
+        rows.append([qi.reduce_u128(a) for a in acc])
+    return Poly(ctx, NTT, rows)
+
+
+def dot_product_scalar(cts, pts):
+    """ops/dot_product.rs:54-180: sum_k ct_k * pt_k with pt_k given as Ntt polynomials
+    (`Plaintext::poly_ntt`)."""
+    cts, pts = list(cts), list(pts)
+    if not cts or not pts:
+        raise ValueError("EmptyInput")
+    if len(cts) != len(pts):
+        raise ValueError("OperandCountMismatch")
+    nparts = len(cts[0])
+    if any(len(c) != nparts for c in cts):
+        raise ValueError("CiphertextPolynomialCountMismatch")
+    c = [poly_dot_product([ct[i] for ct in cts], pts) for i in range(nparts)]
+    return Ciphertext(cts[0].par, c, cts[0].level)
+
+
+def plaintext_poly_ntt(par, values, level=0):
+    """Plaintext::poly_ntt for Encoding::poly (plaintext_vec.rs:70-102): the values as
+    coefficients (zero padded), reduced mod every q_i, in Ntt form -- NOT scaled by delta."""
+    ctx = par.context_at_level(level)
+    return Poly.from_u64(ctx, [v % par.plaintext for v in values]).into_ntt()
+
+
+def mul_plain(ct, pt_poly_ntt):
+    """ops/mod.rs:229-257: every part times pt.poly_ntt."""
+    return Ciphertext(ct.par, [ci.mul(pt_poly_ntt) for ci in ct.c], ct.level)
+
+
+class RGSWCiphertext:
+    """rgsw_ciphertext.rs:19-156."""
+
+    def __init__(self, sk=None, values=None, rng=None, level=0, ksk0=None, ksk1=None):
+        if ksk0 is not None:
+            self.ksk0, self.ksk1 = ksk0, ksk1
+            return
+        par = sk.par
+        ctx = par.context_at_level(level)
+        pt_poly_ntt = plaintext_poly_ntt(par, values, level)  # Plaintext::poly_ntt (unscaled)
+        m = pt_poly_ntt.into_power_basis()
+        m_s = Poly.from_i64(ctx, sk.coeffs).into_ntt().mul(pt_poly_ntt).into_power_basis()
+        self.ksk0 = KeySwitchingKey(sk, m, level, level, rng)
+        self.ksk1 = KeySwitchingKey(sk, m_s, level, level, rng)
+
+    def external_product(self, ct: Ciphertext):
+        """`&Ciphertext * &RGSWCiphertext` (rgsw_ciphertext.rs:122-156)."""
+        assert len(ct) == 2 and ct.level == self.ksk0.ciphertext_level
+        c0, c1 = self.ksk0.key_switch(ct[0].into_power_basis())
+        c0p, c1p = self.ksk1.key_switch(ct[1].into_power_basis())
+        return Ciphertext(ct.par, [c0.add(c0p), c1.add(c1p)], ct.level)
+
+
+def inner_sum(ct, galois_keys, degree):
+    """evaluation_key.rs:56-100 (`computes_inner_sum`): galois_keys maps exponent -> GaloisKey."""
+    out = ct
+    i = 1
+    while i < degree // 2:
+        tmp = galois_keys[rot_to_gk_exponent(degree, i)].relinearize(out)
+        out = out.add(tmp)
+        i *= 2
+    tmp = galois_keys[2 * degree - 1].relinearize(out)
+    return out.add(tmp)

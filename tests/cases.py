@@ -376,6 +376,86 @@ def case_multiply_custom_factors(fhe, dev, n=16):
     del basis
 
 
+def case_dot_product_and_mul_plain(fhe, dev, n=16, count=7):
+    """ops/dot_product.rs tests + rq/ops.rs:880-939 (`dot_product` == sum of products) and
+    ops/mod.rs `ct * pt`: bit-exact vs the oracle and decrypts to sum_k m_k * p_k."""
+    x = Xfer(dev)
+    rng = random.Random(19)
+    opar, par = _params(fhe, 3, n)
+    sk = obfv.SecretKey.random(opar, rng)
+    t = opar.plaintext
+    ctx = par.context_at_level(0)
+    cts = [sk.encrypt([rng.randrange(t) for _ in range(n)], rng) for _ in range(count)]
+    pts = [obfv.plaintext_poly_ntt(opar, [rng.randrange(t) for _ in range(n)]) for _ in range(count)]
+    want = obfv.dot_product_scalar(cts, pts)
+    C = np.stack([ct_arr(c) for c in cts])            # [count, 2, L, N]
+    P = np.stack([arr(p) for p in pts])               # [count, L, N]
+    got = x.back(ctx.dot_product_scalar(x.to(C), x.to(P)))
+    assert np.array_equal(got, ct_arr(want))
+    # batched: two dot products sharing the ciphertexts (the MulPIR server loop shape)
+    P2 = np.stack([P, P[::-1].copy()])
+    got2 = x.back(ctx.dot_product_scalar(x.to(C), x.to(P2)))
+    assert np.array_equal(got2[0], ct_arr(want))
+    assert np.array_equal(got2[1], ct_arr(obfv.dot_product_scalar(cts, pts[::-1])))
+    # polynomial dot product (parts == 1)
+    pp = x.back(ctx.dot_product_scalar(x.to(C[:, :1].copy()), x.to(P)))
+    assert np.array_equal(pp[0], arr(obfv.poly_dot_product([c[0] for c in cts], pts)))
+    # ct * pt, per-ciphertext and shared plaintext
+    got3 = x.back(ctx.mul_plain(x.to(C), x.to(P)))
+    for k in range(count):
+        assert np.array_equal(got3[k], ct_arr(obfv.mul_plain(cts[k], pts[k])))
+    got4 = x.back(ctx.mul_plain(x.to(C), x.to(P[0])))
+    assert np.array_equal(got4[3], ct_arr(obfv.mul_plain(cts[3], pts[0])))
+    try:
+        ctx.dot_product_scalar(x.to(C[:0].copy()), x.to(P[:0].copy()))
+        raise AssertionError("empty dot product accepted")
+    except fhe.FheError as err:
+        assert err.code == -19
+
+
+def case_rgsw_and_inner_sum(fhe, dev, n=16):
+    """rgsw_ciphertext.rs:122-156 (+ its tests :190-245) and evaluation_key.rs:56-100."""
+    x = Xfer(dev)
+    rng = random.Random(20)
+    opar, par = _params(fhe, 3, n)
+    sk = obfv.SecretKey.random(opar, rng)
+    t = opar.plaintext
+    for level in (0, 1):
+        ctx = par.context_at_level(level)
+        org = obfv.RGSWCiphertext(sk, [rng.randrange(t) for _ in range(n)], rng, level)
+        ks = []
+        for oksk in (org.ksk0, org.ksk1):
+            c0, c0s, c1, c1s = ksk_arrays(oksk)
+            ks.append(fhe.KeySwitchingKey(ctx, ctx, c0, c1))
+        rg = fhe.RGSWCiphertext(*ks)
+        cts = [sk.encrypt([rng.randrange(t) for _ in range(n)], rng, level) for _ in range(3)]
+        got = x.back(rg.external_product(x.to(np.stack([ct_arr(c) for c in cts]))))
+        for i, c in enumerate(cts):
+            assert np.array_equal(got[i], ct_arr(org.external_product(c)))
+    # inner sum at level 0
+    ogks, gks, i = {}, [], 1
+    seq = []
+    while i < n // 2:
+        seq.append(obfv.rot_to_gk_exponent(n, i))
+        i *= 2
+    seq.append(2 * n - 1)
+    ctx = par.context_at_level(0)
+    for e in seq:
+        ogks[e] = obfv.GaloisKey(sk, e, 0, 0, rng)
+        c0, c0s, c1, c1s = ksk_arrays(ogks[e].ksk)
+        gks.append(fhe.GaloisKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1), e))
+    ek = fhe.EvaluationKey(n, gks)
+    cts = [sk.encrypt([rng.randrange(t) for _ in range(n)], rng) for _ in range(2)]
+    got = x.back(ek.computes_inner_sum(x.to(np.stack([ct_arr(c) for c in cts]))))
+    for i, c in enumerate(cts):
+        assert np.array_equal(got[i], ct_arr(obfv.inner_sum(c, ogks, n)))
+    try:
+        fhe.EvaluationKey(n, gks[:-1]).computes_inner_sum(x.to(ct_arr(cts[0])))
+        raise AssertionError("inner sum without the row-rotation key accepted")
+    except fhe.FheError as err:
+        assert err.code == -11
+
+
 def case_errors(fhe):
     """Error conventions (include/fhe_hip.h status codes <-> fhe_math::Error variants)."""
     def code(fn):

@@ -91,5 +91,13 @@ def test_multiply_custom_factors(fhe):
     cases.case_multiply_custom_factors(fhe, False)
 
 
+def test_dot_product_and_mul_plain(fhe):
+    cases.case_dot_product_and_mul_plain(fhe, False)
+
+
+def test_rgsw_and_inner_sum(fhe):
+    cases.case_rgsw_and_inner_sum(fhe, False)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)

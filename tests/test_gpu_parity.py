@@ -99,6 +99,16 @@ def test_multiply_custom_factors(fhe):
     cases.case_multiply_custom_factors(fhe, True)
 
 
+@pytest.mark.parametrize("dev", [False, True])
+def test_dot_product_and_mul_plain(fhe, dev):
+    cases.case_dot_product_and_mul_plain(fhe, dev)
+
+
+@pytest.mark.parametrize("dev", [False, True])
+def test_rgsw_and_inner_sum(fhe, dev):
+    cases.case_rgsw_and_inner_sum(fhe, dev)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 

@@ -63,6 +63,13 @@ def main():
     rec("key_switch [B,4,8192]", ms, B * (L * L + 2 * L) * R, B, "poly/s")
     ms = timeit(lambda: mul.multiply(x, x))
     rec("multiply+relin", ms, B * (22 * K + 7 * L + L * L + 4 * L) * R, B, "ops/s")
+    # PIR server inner loop (dot_product_scalar): 256 query ciphertexts shared by 32 database rows
+    count, rowsdb = 256, 32
+    q = ctx.synth_uniform(SEED, 0, 0, 2, count)                       # [count,2,L,N]
+    db = ctx.synth_uniform(SEED, 1000, 0, count, rowsdb).reshape(rowsdb, count, L, N)
+    ms = timeit(lambda: ctx.dot_product_scalar(q, db))
+    rec("dot_product_scalar 256 cts x 32 db rows", ms, (rowsdb * count * L + count * 2 * L + rowsdb * 2 * L) * R,
+        rowsdb * count, "ct*pt MAC/s")
     for r in res:
         print(json.dumps(r))
 

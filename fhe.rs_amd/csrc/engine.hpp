@@ -763,10 +763,18 @@ inline void dot_product_scalar(const Ctx &c, size_t nparts, size_t count, const 
     if (!batch || !nparts) return;
     const u64 pl = (u64)c.L * c.n;
     require(batch <= 65535 && nparts <= 65535, E_ARG, "dot product: batch / parts exceed the grid limits");
-    FHE_LAUNCH("dot_product", k::dot_kernel, dim3(blocks_for(pl / 2, EW_THREADS), (unsigned)nparts, (unsigned)batch),
-               dim3(EW_THREADS), 0, s, cts, cts_shared ? (u64)0 : (u64)count * nparts * pl, pts,
-               pts_shared ? (u64)0 : (u64)count * pl, out, c.dmods(), c.dpow2(), (uint32_t)nparts, (uint32_t)count,
-               (uint32_t)c.logn, pl);
+    const u64 cstride = cts_shared ? (u64)0 : (u64)count * nparts * pl, pstride = pts_shared ? (u64)0 : (u64)count * pl;
+    const dim3 block(EW_THREADS);
+    if (nparts == 1) {
+        FHE_LAUNCH("dot_product", (k::dot_kernel<1>), dim3(blocks_for(pl / 2, EW_THREADS), 1, (unsigned)batch), block, 0, s,
+                   cts, cstride, pts, pstride, out, c.dmods(), c.dpow2(), (uint32_t)nparts, (uint32_t)count,
+                   (uint32_t)c.logn, pl);
+    } else {  // two parts per lane (a ciphertext), further parts in extra grid rows
+        FHE_LAUNCH("dot_product", (k::dot_kernel<2>), dim3(blocks_for(pl / 2, EW_THREADS), (unsigned)((nparts + 1) / 2),
+                                                          (unsigned)batch),
+                   block, 0, s, cts, cstride, pts, pstride, out, c.dmods(), c.dpow2(), (uint32_t)nparts, (uint32_t)count,
+                   (uint32_t)c.logn, pl);
+    }
 }
 
 // `Ciphertext * Plaintext` (F/bfv/ops/mod.rs:229-257)

@@ -824,28 +824,39 @@ __global__ void tensor_kernel(const u64 *__restrict__ extL, const u64 *__restric
 }
 // dot_product_scalar / rq::dot_product (F/bfv/ops/dot_product.rs:54-180, M/rq/ops.rs:449-570):
 // out[b][part][row][c] = sum_k cts[b][k][part][row][c] * pts[b][k][row][c]  mod q_row.
-// One lane per pair of coefficients; exact 128-bit products accumulated in 192 bits and reduced
-// once (the reference's periodic reduce_u128 gives the same canonical sum).  Streaming, HBM bound.
+// One lane per pair of coefficients and ALL `NP` parts of the group starting at blockIdx.y*NP
+// (each plaintext word is loaded once); exact 128-bit products accumulated in 192 bits and
+// reduced once (the reference's periodic reduce_u128 gives the same canonical sum).
+// Streaming, HBM bound.
+template <int NP>
 __global__ void dot_kernel(const u64 *__restrict__ cts, u64 ct_batch_stride, const u64 *__restrict__ pts,
                            u64 pt_batch_stride, u64 *__restrict__ out, const DevMod *__restrict__ mods,
                            const u64x2 *__restrict__ pow2 /* {2^64, 2^128} mod q */, uint32_t nparts, uint32_t count,
                            uint32_t logn, u64 pl /* L*N */) {
-    // grid: x = pairs of coefficients of one polynomial, y = part, z = batch
+    // grid: x = pairs of coefficients of one polynomial, y = group of NP parts, z = batch
     const u64 pair = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (2 * pair >= pl) return;
     const u64 off = 2 * pair;
-    const uint32_t part = blockIdx.y, b = blockIdx.z;
+    const uint32_t part0 = blockIdx.y * NP, b = blockIdx.z;
     const uint32_t row = (uint32_t)(off >> logn);
     const DevMod m = mods[row];
-    const u64 *cp = cts + (u64)b * ct_batch_stride + (u64)part * pl + off;
+    const u64 *cp = cts + (u64)b * ct_batch_stride + (u64)part0 * pl + off;
     const u64 *pp = pts + (u64)b * pt_batch_stride + off;
-    u128_t a0 = 0, a1 = 0;
-    u64 t0 = 0, t1 = 0;
+    u128_t a0[NP], a1[NP];
+    u64 t0[NP], t1[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) a0[q] = a1[q] = 0, t0[q] = t1[q] = 0;
+#pragma unroll 2
     for (uint32_t k = 0; k < count; k++) {
-        const u64x2 x = *reinterpret_cast<const u64x2 *>(cp + (u64)k * nparts * pl);
         const u64x2 y = *reinterpret_cast<const u64x2 *>(pp + (u64)k * pl);
-        mac192(a0, t0, x.x, y.x);
-        mac192(a1, t1, x.y, y.y);
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            if (part0 + q < nparts) {
+                const u64x2 x = *reinterpret_cast<const u64x2 *>(cp + ((u64)k * nparts + q) * pl);
+                mac192(a0[q], t0[q], x.x, y.x);
+                mac192(a1[q], t1[q], x.y, y.y);
+            }
+        }
     }
     // value = top * 2^128 + a: reduce a, then add (top mod q) * (2^128 mod q)
     const u64 c128 = pow2[row].y;
@@ -853,10 +864,15 @@ __global__ void dot_kernel(const u64 *__restrict__ cts, u64 ct_batch_stride, con
         const u64 r = reduce_u128((u64)(a >> 64), (u64)a, m);
         return top ? add_mod(r, mul_mod(reduce_u64(top, m), c128, m), m.p) : r;
     };
-    u64x2 o;
-    o.x = fold(a0, t0);
-    o.y = fold(a1, t1);
-    *reinterpret_cast<u64x2 *>(out + ((u64)b * nparts + part) * pl + off) = o;
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        if (part0 + q < nparts) {
+            u64x2 o;
+            o.x = fold(a0[q], t0[q]);
+            o.y = fold(a1[q], t1[q]);
+            *reinterpret_cast<u64x2 *>(out + ((u64)b * nparts + part0 + q) * pl + off) = o;
+        }
+    }
 }
 
 // `Ciphertext * Plaintext` (F/bfv/ops/mod.rs:229-257): out[b][part] = ct[b][part] (.) pt[b].

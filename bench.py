@@ -152,7 +152,8 @@ def main():
         "tensor_intt": 8 * K + 3 * K,                 # fused tensor + inverse NTT: reads 2+4+2, writes 3 rows per modulus
         "ntt_fwd": 2 * (4 * (K - L) + 2 * L),         # new rows of the 4 extended polys + (c0, c1)
         "key_switch_fused": L * L + 4 * L,            # L digit rows per key modulus, 2 addend rows + 2 output rows
-        "scale": (4 * (L + (K - L))) + 3 * (K + L),   # extend 4 polys (L in, K-L out), down-scale 3 polys (K in, L out)
+        "scale_extend": 4 * (L + (K - L)),            # extend 4 polys: L rows in, K-L new rows out
+        "scale_down": 3 * (K + L),                    # down-scale 3 polys: K rows in, L rows out
         "tensor": 7 * K,
         "copy_rows": 2 * 4 * L,
     }

@@ -550,8 +550,10 @@ inline void launch_scale(const Scaler &sc, const u64 *in, u64 in_stride, u64 *ou
     const u64 total = (u64)npolys * f.n;
     if (!total) return;
     const dim3 grid(blocks_for(total, EW_THREADS)), block(EW_THREADS);
+    // profiler label: basis extension (more output rows than input) vs down-scaling
+    const char *label = t.L > f.L ? "scale_extend" : "scale_down";
 #define FHE_SCALE_CASE(NF)                                                                                   \
-    FHE_LAUNCH("scale", (k::scale_kernel<NF>), grid, block, 0, s, in, out, in_stride, out_stride, sc.dev,    \
+    FHE_LAUNCH(label, (k::scale_kernel<NF>), grid, block, 0, s, in, out, in_stride, out_stride, sc.dev,      \
                t.dmods(), (uint32_t)f.logn, total)
     if (f.L <= 4) FHE_SCALE_CASE(4);
     else if (f.L <= 9) FHE_SCALE_CASE(9);
@@ -639,7 +641,7 @@ template <int LOGN>
 inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
                             const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s) {
     const Ctx &kc = *k_.ksk_ctx;
-    const size_t lds = k::lds_words(1u << LOGN) * sizeof(u64);
+    const size_t lds = (k::lds_words(1u << LOGN) + (k::ks_acc1_in_lds_c(LOGN) ? (size_t)1 << LOGN : 0)) * sizeof(u64);
     allow_big_lds(k::ks_fused_kernel<LOGN>, lds);
     FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN>), dim3((unsigned)(npolys * kc.L)),
                dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,

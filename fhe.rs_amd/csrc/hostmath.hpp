@@ -141,6 +141,8 @@ struct ModConsts {
     u64 brt_lo;
     uint32_t k;      // bit length of p
     uint32_t pad;
+    u64 np;          // 2^64 - p and 2^64 - 2p: the device adds these instead of subtracting p / 2p
+    u64 np2;         // (gfx950 has a one-instruction 64-bit add but no one-instruction 64-bit subtract)
 };
 
 inline ModConsts make_mod_consts(u64 p) {
@@ -148,6 +150,8 @@ inline ModConsts make_mod_consts(u64 p) {
     ModConsts m{};
     m.p = p;
     m.p2 = 2 * p;
+    m.np = 0 - p;
+    m.np2 = 0 - 2 * p;
     m.k = 64 - (uint32_t)__builtin_clzll(p);
     BigUint mu = BigUint::pow2(2 * m.k) / BigUint(p);  // < 2^(k+1)
     m.mu = (mu << (63 - m.k)).to_u64();

@@ -67,6 +67,21 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v) {
 #endif
     return v;
 }
+// A block-uniform value the compiler computed on the VALU (integer division has no scalar
+// form) stays in a VGPR, and so does all address arithmetic derived from it; the builtin
+// readfirstlane is folded away for provably uniform inputs, so this goes through asm.
+__device__ __forceinline__ uint32_t to_sgpr(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_DIAG_NO_SGPR_ASM)
+    uint32_t r;
+    // The hazard recognizer does not look inside asm: gfx950 needs a wait state between the VALU
+    // write of a VGPR and a readlane of it (leading s_nop), and 5 wait states before a VMEM
+    // instruction may use the VALU-written SGPR as an address (trailing s_nop).
+    asm("s_nop 1\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(r) : "v"(v));
+    return r;
+#else
+    return v;
+#endif
+}
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
@@ -81,6 +96,9 @@ __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) {
 // key switch: 8 per thread (leaves registers for the two accumulator sets).
 constexpr int ntt_threads_c(int logm) { return (1 << logm) / 16 > 64 ? ((1 << logm) / 16 > 1024 ? 1024 : (1 << logm) / 16) : 64; }
 constexpr int KS_GMAX = 3;  // radix-8 passes inside the key switch: room for the accumulators
+// fused key switch: c1 accumulators in LDS (see ks_fused_kernel) exactly when a thread is capped at 128 VGPRs
+// and the row tile leaves room for them
+constexpr bool ks_acc1_in_lds_c(int logn) { return logn == 13; }
 constexpr int ks_threads_c(int logn) { return (1 << logn) / 8 > 64 ? ((1 << logn) / 8 > 1024 ? 1024 : (1 << logn) / 8) : 64; }
 // 16-byte chunks per thread (0: tile smaller than one chunk per thread -> scalar loop)
 constexpr int tile_chunks_c(int logm, int threads) { return (1 << logm) >= 2 * threads ? (1 << logm) / (2 * threads) : 0; }
@@ -98,7 +116,7 @@ constexpr int plan_rem(int logm, int gmax) { return logm % plan_np(logm, gmax); 
 // wave-uniform and come through the scalar cache.  Otherwise all 2^G - 1 twiddles of a group
 // are fetched up front, one batch of loads in flight instead of a dependent load per stage.
 template <int G, int LOGM, int S0, int T>
-__device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, u64 p, u64 p2,
+__device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                          uint32_t tid) {
     constexpr uint32_t R = 1u << G;
     constexpr uint32_t lo_bits = LOGM - S0 - G;
@@ -138,7 +156,7 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
 #pragma unroll
                 for (uint32_t j = 0; j < half; j++) {
                     const uint32_t a = blk * 2 * half + j;
-                    fwd_butterfly(x[a], x[a + half], wv.x, wv.y, p, p2);
+                    fwd_butterfly(x[a], x[a + half], wv.x, wv.y, pm);
                 }
             }
         }
@@ -150,13 +168,13 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
 // All stages of a size-2^LOGM forward transform on an LDS tile (values < 4p on exit); the
 // pass plan is resolved at compile time.  Early passes (scalar twiddles) take the wider radix.
 template <int LOGM, int T, int GM = GMAX, int PASS = 0, int S0 = 0>
-__device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, u64 p, u64 p2,
+__device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                             uint32_t tid) {
     if constexpr (PASS < plan_np(LOGM, GM)) {
         constexpr int G = plan_base(LOGM, GM) + (PASS < plan_rem(LOGM, GM) ? 1 : 0);
-        fwd_pass<G, LOGM, S0, T>(lds, tw, kbase, p, p2, tid);
+        fwd_pass<G, LOGM, S0, T>(lds, tw, kbase, pm, tid);
         __syncthreads();
-        ntt_fwd_lds<LOGM, T, GM, PASS + 1, S0 + G>(lds, tw, kbase, p, p2, tid);
+        ntt_fwd_lds<LOGM, T, GM, PASS + 1, S0 + G>(lds, tw, kbase, pm, tid);
     }
 }
 
@@ -167,8 +185,8 @@ __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ 
 // the N^-1 scaling of native.rs:229-232 is folded into the last stage -- x' = (x + y) * N^-1,
 // y' = (x - y) * (z * N^-1) -- which saves half a Shoup multiplication per coefficient.
 template <int G, int LOGM, int V0, int T>
-__device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub, u64 p,
-                                         u64 p2, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv) {
+__device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
+                                         const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv) {
     constexpr uint32_t R = 1u << G;
     constexpr uint32_t ngroups = 1u << (LOGM - G);
     constexpr bool UNIFORM = V0 >= 6;
@@ -207,10 +225,10 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
                     const uint32_t a = blk * (2u << u) + j, b = a + (1u << u);
                     if (V0 + G == LOGM && u == G - 1 && fold) {
                         const u64 t = x[a], y = x[b];
-                        x[a] = mul_shoup_lazy(y + t, ninv.x, ninv.y, p);
-                        x[b] = mul_shoup_lazy(p2 + t - y, zninv.x, zninv.y, p);
+                        x[a] = mul_shoup_lazy_n(y + t, ninv.x, ninv.y, pm.np);
+                        x[b] = mul_shoup_lazy_n(pm.p2 + t - y, zninv.x, zninv.y, pm.np);
                     } else {
-                        inv_butterfly(x[a], x[b], zv.x, zv.y, p, p2);
+                        inv_butterfly(x[a], x[b], zv.x, zv.y, pm);
                     }
                 }
             }
@@ -223,12 +241,12 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
 // Late passes (scalar twiddles) take the wider radix.
 template <int LOGM, int T, int PASS = 0, int V0 = 0>
 __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
-                                            u64 p, u64 p2, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv) {
+                                            const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv) {
     if constexpr (PASS < plan_np(LOGM, GMAX)) {
         constexpr int G = plan_base(LOGM, GMAX) + (PASS >= plan_np(LOGM, GMAX) - plan_rem(LOGM, GMAX) ? 1 : 0);
-        inv_pass<G, LOGM, V0, T>(lds, itw, logn, sub, p, p2, tid, fold, ninv, zninv);
+        inv_pass<G, LOGM, V0, T>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv);
         __syncthreads();
-        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G>(lds, itw, logn, sub, p, p2, tid, fold, ninv, zninv);
+        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv);
     }
 }
 
@@ -290,13 +308,14 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     const uint32_t tid = threadIdx.x;
     const uint32_t n = 1u << logn;
     const uint32_t nsub = 1u << (logn - LOGM);
-    const uint32_t sub = blockIdx.x % nsub;
-    const uint32_t rowb = blockIdx.x / nsub;
-    const uint32_t poly = rowb / map.rows;
-    const uint32_t r = map.row_begin + rowb % map.rows;
+    const uint32_t sub = blockIdx.x & (nsub - 1);
+    const uint32_t rowb = blockIdx.x >> (logn - LOGM);
+    const uint32_t poly = to_sgpr(rowb / map.rows);
+    const uint32_t r = map.row_begin + (rowb - poly * map.rows);
     const uint32_t mi = (uint32_t)(map.mod_offset + (int32_t)r);
     const DevMod md = mods[mi];
     const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
     const u64 *src = in + (u64)poly * map.src_poly_stride +
                      (u64)(map.src_row_fixed >= 0 ? (uint32_t)map.src_row_fixed : r) * n + (u64)sub * M;
     u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * n + (u64)sub * M;
@@ -308,13 +327,13 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
     __syncthreads();
     if (!INVERSE) {
-        ntt_fwd_lds<LOGM, T>(lds, twr, nsub + sub, p, p2, tid);
-        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub(csub(v, p2), p); });
+        ntt_fwd_lds<LOGM, T>(lds, twr, nsub + sub, pm, tid);
+        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(csub_n(v, p2, pm.np2), p, pm.np); });
     } else {
         const bool whole = logn == LOGM;  // ninv[2*mi] = {N^-1, shoup}, ninv[2*mi+1] = {z_last * N^-1, shoup}
-        ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, p, p2, tid, whole, ninv[2 * mi], ninv[2 * mi + 1]);
+        ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1]);
         if (whole)
-            lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub(v, p); });
+            lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
         else
             lds_to_tile<CH, M, T>(lds, dst, tid, [](u64 v) { return v; });  // < 2p, global pass finishes
     }
@@ -344,6 +363,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     const uint32_t r = blockIdx.x, b = blockIdx.y, slot = blockIdx.z, nb = gridDim.y;
     const DevMod md = mods[r];
     const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
     const u64 pk = (u64)nrows << LOGM;
     const u64 *a0, *a1, *b0, *b1;  // rows of c00, c01, c10, c11
     if (ts.lhs && r < ts.ncommon) {
@@ -361,7 +381,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     auto prod = [&](u64 x00, u64 x01, u64 x10, u64 x11) -> u64 {
         if (slot == 0) return mul_mod(x00, x10, md);
         if (slot == 2) return mul_mod(x01, x11, md);
-        return add_mod(mul_mod(x00, x11, md), mul_mod(x01, x10, md), p);
+        return add_mod_n(mul_mod(x00, x11, md), mul_mod(x01, x10, md), pm);
     };
     if constexpr (CH > 0) {
         constexpr int HALF = CH > 1 ? CH / 2 : 1;  // loads of at most HALF chunks x 4 operands in flight
@@ -388,9 +408,9 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         for (uint32_t i = tid; i < M; i += T) lds[padi(i)] = prod(a0[i], a1[i], b0[i], b1[i]);
     }
     __syncthreads();
-    ntt_inv_lds<LOGM, T>(lds, itw + (u64)r * M, LOGM, 0, p, p2, tid, true, ninv[2 * r], ninv[2 * r + 1]);
+    ntt_inv_lds<LOGM, T>(lds, itw + (u64)r * M, LOGM, 0, pm, tid, true, ninv[2 * r], ninv[2 * r + 1]);
     u64 *dst = out + ((u64)slot * nb + b) * pk + (u64)r * M;
-    lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub(v, p); });
+    lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
 }
 
 // Radix stages that span sub-blocks, done straight on global memory (coalesced along the
@@ -412,6 +432,7 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
     const uint32_t mi = (uint32_t)(map.mod_offset + (int32_t)r);
     const DevMod md = mods[mi];
     const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
     const u64 *src = in + (u64)poly * map.src_poly_stride +
                      (u64)(map.src_row_fixed >= 0 ? (uint32_t)map.src_row_fixed : r) * n;
     u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * n;
@@ -433,7 +454,7 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
 #pragma unroll
                 for (uint32_t j = 0; j < half; j++) {
                     const uint32_t a = blk * 2 * half + j;
-                    fwd_butterfly(x[a], x[a + half], w.x, w.y, p, p2);
+                    fwd_butterfly(x[a], x[a + half], w.x, w.y, pm);
                 }
             }
         }
@@ -450,7 +471,7 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
 #pragma unroll
                 for (uint32_t j = 0; j < (1u << u); j++) {
                     const uint32_t a = blk * (2u << u) + j;
-                    inv_butterfly(x[a], x[a + (1u << u)], z.x, z.y, p, p2);
+                    inv_butterfly(x[a], x[a + (1u << u)], z.x, z.y, pm);
                 }
             }
         }
@@ -481,13 +502,26 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     constexpr int CH = tile_chunks_c(LOGN, T);
     constexpr int NE = CH > 0 ? 2 * CH : 1;  // coefficients owned by a thread
     const uint32_t tid0 = threadIdx.x;
-    const uint32_t j = blockIdx.x % lk, b = blockIdx.x / lk;
+    const uint32_t b = to_sgpr(blockIdx.x / lk), j = blockIdx.x - b * lk;
     const DevMod md = mods[j];
     const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
     const u64x2 *twr = tw + (u64)j * N;
-    u64 acc0[NE], acc1[NE];
+    // N = 8192: 1024 threads cap a thread at 128 VGPRs, which 2 x 16 accumulators plus a radix-8
+    // pass do not fit; the c1 accumulators live in LDS behind the row tile instead (each thread
+    // only ever touches its own 16-byte chunks, so no extra barrier).
+    constexpr bool ACC1_LDS = ks_acc1_in_lds_c(LOGN);
+    u64 acc0[NE], acc1[ACC1_LDS ? 1 : NE];
+    u64x2 *const acc1_lds = reinterpret_cast<u64x2 *>(lds + lds_words(N));
 #pragma unroll
-    for (int e = 0; e < NE; e++) acc0[e] = acc1[e] = 0;
+    for (int e = 0; e < NE; e++) acc0[e] = 0;
+    if constexpr (ACC1_LDS) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) acc1_lds[c * T + tid0] = u64x2{0, 0};
+    } else {
+#pragma unroll
+        for (int e = 0; e < NE; e++) acc1[e] = 0;
+    }
     for (uint32_t i = 0; i < ndigits; i++) {
         const uint32_t tid = opaque(tid0);
         // digit_shift_bits == 0: digit i is residue row i of p (RNS decomposition, :256-268).
@@ -497,7 +531,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
         const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
         tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return reduce_u64((v >> sh) & mask, md); });
         __syncthreads();
-        ntt_fwd_lds<LOGN, T, KS_GMAX>(lds, twr, 1, p, p2, tid);
+        ntt_fwd_lds<LOGN, T, KS_GMAX>(lds, twr, 1, pm, tid);
         const u64 koff = ((u64)i * lk + j) * N;
         if constexpr (CH > 0) {
             const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
@@ -507,20 +541,27 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                 const uint32_t ci = c * T + tid;
                 const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
                 const u64 vx = lds[padi(2 * ci)], vy = lds[padi(2 * ci + 1)];  // < 4p: Shoup accepts any u64
-                acc0[2 * c] = csub(acc0[2 * c] + mul_shoup_lazy(vx, q0.x, q0s.x, p), p2);
-                acc0[2 * c + 1] = csub(acc0[2 * c + 1] + mul_shoup_lazy(vy, q0.y, q0s.y, p), p2);
-                acc1[2 * c] = csub(acc1[2 * c] + mul_shoup_lazy(vx, q1.x, q1s.x, p), p2);
-                acc1[2 * c + 1] = csub(acc1[2 * c + 1] + mul_shoup_lazy(vy, q1.y, q1s.y, p), p2);
+                acc0[2 * c] = csub_n(acc0[2 * c] + mul_shoup_lazy_n(vx, q0.x, q0s.x, pm.np), p2, pm.np2);
+                acc0[2 * c + 1] = csub_n(acc0[2 * c + 1] + mul_shoup_lazy_n(vy, q0.y, q0s.y, pm.np), p2, pm.np2);
+                if constexpr (ACC1_LDS) {
+                    u64x2 a = acc1_lds[ci];
+                    a.x = csub_n(a.x + mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np), p2, pm.np2);
+                    a.y = csub_n(a.y + mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np), p2, pm.np2);
+                    acc1_lds[ci] = a;
+                } else {
+                    acc1[2 * c] = csub_n(acc1[2 * c] + mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np), p2, pm.np2);
+                    acc1[2 * c + 1] = csub_n(acc1[2 * c + 1] + mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np), p2, pm.np2);
+                }
                 if (c & 1) sched_fence();  // at most two chunks of key loads (32 VGPRs) in flight
             }
         } else if (tid < N) {
             const u64 v = lds[padi(tid)];
-            acc0[0] = csub(acc0[0] + mul_shoup_lazy(v, k0[koff + tid], k0s[koff + tid], p), p2);
-            acc1[0] = csub(acc1[0] + mul_shoup_lazy(v, k1[koff + tid], k1s[koff + tid], p), p2);
+            acc0[0] = csub_n(acc0[0] + mul_shoup_lazy_n(v, k0[koff + tid], k0s[koff + tid], pm.np), p2, pm.np2);
+            acc1[0] = csub_n(acc1[0] + mul_shoup_lazy_n(v, k1[koff + tid], k1s[koff + tid], pm.np), p2, pm.np2);
         }
         __syncthreads();
     }
-    const uint32_t tid = tid0;
+    const uint32_t tid = opaque(tid0);  // keeps the epilogue's address arithmetic below the digit loop
     const u64 ooff = (u64)b * out_poly_stride + (u64)j * N;
     const u64 aoff = (u64)b * addend_poly_stride + (u64)j * N;
     if constexpr (CH > 0) {
@@ -531,19 +572,20 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
         for (int c = 0; c < CH; c++) {
             const uint32_t ci = c * T + tid;
             u64x2 r0, r1;
-            r0.x = csub(acc0[2 * c], p);
-            r0.y = csub(acc0[2 * c + 1], p);
-            r1.x = csub(acc1[2 * c], p);
-            r1.y = csub(acc1[2 * c + 1], p);
+            r0.x = csub_n(acc0[2 * c], p, pm.np);
+            r0.y = csub_n(acc0[2 * c + 1], p, pm.np);
+            const u64x2 a1 = ACC1_LDS ? acc1_lds[ci] : u64x2{acc1[ACC1_LDS ? 0 : 2 * c], acc1[ACC1_LDS ? 0 : 2 * c + 1]};
+            r1.x = csub_n(a1.x, p, pm.np);
+            r1.y = csub_n(a1.y, p, pm.np);
             if (d0) {
                 const u64x2 a = d0[ci];
-                r0.x = add_mod(r0.x, a.x, p);
-                r0.y = add_mod(r0.y, a.y, p);
+                r0.x = add_mod_n(r0.x, a.x, pm);
+                r0.y = add_mod_n(r0.y, a.y, pm);
             }
             if (d1) {
                 const u64x2 a = d1[ci];
-                r1.x = add_mod(r1.x, a.x, p);
-                r1.y = add_mod(r1.y, a.y, p);
+                r1.x = add_mod_n(r1.x, a.x, pm);
+                r1.y = add_mod_n(r1.y, a.y, pm);
             }
             o0[ci] = r0;
             o1[ci] = r1;
@@ -690,7 +732,7 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
         mac192(acc, top, vlo, s.gamma_neg[jt]);               // -v_lo * gamma
         u64 small = s.vhi_tab[jt * 16 + vh];                   // -v_hi * 2^64 * gamma   (< q)
         if (!s.is_one) {
-            const u64 wi = csub(reduce_u64(wlo, q) + s.c64_tab[jt * 16 + wh], q.p);  // w mod q
+            const u64 wi = csub_n(reduce_u64(wlo, q) + s.c64_tab[jt * 16 + wh], q.p, q.np);  // w mod q
             small += w_sign ? (wi ? q.p - wi : 0) : wi;        // < 2q
         }
 #pragma unroll
@@ -698,7 +740,7 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
             if ((uint32_t)i < s.nfrom) mac192(acc, top, rests[i], om[i]);
         top += __builtin_add_overflow(acc, (u128_t)small, &acc) ? 1 : 0;
         u64 r = reduce_u128((u64)(acc >> 64), (u64)acc, q);    // [0, q)
-        r = csub(r + s.c128_tab[jt * 16 + ((uint32_t)top & 15)], q.p);
+        r = csub_n(r + s.c128_tab[jt * 16 + ((uint32_t)top & 15)], q.p, q.np);
         o[(u64)jt * n] = r;
     }
 }
@@ -819,7 +861,7 @@ __global__ void tensor_kernel(const u64 *__restrict__ extL, const u64 *__restric
         return;
     }
     o[0] = mul_mod(c00, c10, m);
-    o[nb * pn] = add_mod(mul_mod(c00, c11, m), mul_mod(c01, c10, m), m.p);
+    o[nb * pn] = csub_n(mul_mod(c00, c11, m) + mul_mod(c01, c10, m), m.p, m.np);
     o[2 * nb * pn] = mul_mod(c01, c11, m);
 }
 // dot_product_scalar / rq::dot_product (F/bfv/ops/dot_product.rs:54-180, M/rq/ops.rs:449-570):

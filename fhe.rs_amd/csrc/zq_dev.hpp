@@ -28,6 +28,7 @@ typedef unsigned __int128 u128_t;
 struct DevMod {  // layout == hostmath.hpp ModConsts
     u64 p, p2, mu, brt_hi, brt_lo;
     uint32_t k, pad;
+    u64 np, np2;  // 2^64 - p, 2^64 - 2p (loaded, so the compiler cannot fold x + np back into x - p)
 };
 
 FHE_HD u64 mulhi64(u64 a, u64 b) {
@@ -40,6 +41,11 @@ FHE_HD u64 mulhi64(u64 a, u64 b) {
 
 // x in [0, 2m) -> [0, m)
 FHE_HD u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
+// same with nm = 2^64 - m supplied: gfx950 has a one-instruction 64-bit add (v_lshl_add_u64) but
+// subtracts through a v_sub_co/v_subb pair plus a VCC wait state, so hot loops add -m instead.
+FHE_HD u64 csub_n(u64 x, u64 m, u64 nm) {
+    return x + (x >= m ? nm : 0);
+}
 
 // M/zq/mod.rs:224-234: any a < 2^64, b < p, bs = floor(b * 2^64 / p); result in [0, 2p).
 FHE_HD u64 mul_shoup_lazy(u64 a, u64 b, u64 bs, u64 p) {
@@ -54,9 +60,9 @@ FHE_HD u64 barrett_reduce_wide(u64 hi, u64 lo, const DevMod &m) {
     const uint32_t s = m.k - 1;
     u64 xs = (s == 0) ? lo : ((lo >> s) | (hi << (64 - s)));  // x >> (k-1), < 2^(k+1)
     u64 q = mulhi64(xs, m.mu);
-    u64 r = lo - q * m.p;  // < 3p < 2^64
-    r = csub(r, m.p2);
-    return csub(r, m.p);
+    u64 r = lo + q * m.np;  // lo - q*p < 3p < 2^64
+    r = csub_n(r, m.p2, m.np2);
+    return csub_n(r, m.p, m.np);
 }
 FHE_HD u64 mul_mod(u64 a, u64 b, const DevMod &m) {  // a, b < p
     u64 lo = a * b, hi = mulhi64(a, b);
@@ -68,9 +74,9 @@ FHE_HD u64 mul_mod(u64 a, u64 b, const DevMod &m) {  // a, b < p
 // costs at most one extra conditional subtraction).
 FHE_HD u64 reduce_u64(u64 a, const DevMod &m) {
     u64 q = mulhi64(a, m.brt_hi);
-    u64 r = a - q * m.p;  // < 3p
-    r = csub(r, m.p2);
-    return csub(r, m.p);
+    u64 r = a + q * m.np;  // a - q*p < 3p
+    r = csub_n(r, m.p2, m.np2);
+    return csub_n(r, m.p, m.np);
 }
 
 // Full 128-bit reduction, M/zq/mod.rs:693-707 (needed only for the scaler's v and w words).
@@ -84,25 +90,34 @@ FHE_HD u64 reduce_u128(u64 hi, u64 lo, const DevMod &m) {
     u64 s0b = s0 + p_lo_lo;
     u64 c1 = s0b < s0;
     u64 q = a1 + b1 + c0 + c1 + hi * m.brt_hi;
-    u64 r = lo - q * m.p;  // < 2p
-    return csub(r, m.p);
+    u64 r = lo + q * m.np;  // lo - q*p < 2p
+    return csub_n(r, m.p, m.np);
 }
 
 FHE_HD u64 add_mod(u64 a, u64 b, u64 p) { return csub(a + b, p); }
 FHE_HD u64 sub_mod(u64 a, u64 b, u64 p) { return csub(a + p - b, p); }
 FHE_HD u64 neg_mod(u64 a, u64 p) { return csub(p - a, p); }
 
+// A (wave-uniform) modulus with its two's-complement negations, as the NTT passes carry it.
+struct PM {
+    u64 p, p2, np, np2;
+};
+FHE_HD PM make_pm(const DevMod &m) { return PM{m.p, m.p2, m.np, m.np2}; }
+// mul_shoup_lazy with a*b - q*p written as a*b + q*(2^64 - p)  (mod 2^64)
+FHE_HD u64 mul_shoup_lazy_n(u64 a, u64 b, u64 bs, u64 np) { return a * b + mulhi64(a, bs) * np; }
+FHE_HD u64 add_mod_n(u64 a, u64 b, const PM &m) { return csub_n(a + b, m.p, m.np); }
+
 // Harvey lazy butterflies, M/ntt/native.rs:256-269 / 288-300.
-FHE_HD void fwd_butterfly(u64 &x, u64 &y, u64 w, u64 ws, u64 p, u64 p2) {
-    x = csub(x, p2);
-    u64 t = mul_shoup_lazy(y, w, ws, p);
-    y = x + p2 - t;
+FHE_HD void fwd_butterfly(u64 &x, u64 &y, u64 w, u64 ws, const PM &m) {
+    x = csub_n(x, m.p2, m.np2);
+    u64 t = mul_shoup_lazy_n(y, w, ws, m.np);
+    y = x + m.p2 - t;
     x = x + t;
 }
-FHE_HD void inv_butterfly(u64 &x, u64 &y, u64 z, u64 zs, u64 p, u64 p2) {
+FHE_HD void inv_butterfly(u64 &x, u64 &y, u64 z, u64 zs, const PM &m) {
     u64 t = x;
-    x = csub(y + t, p2);
-    y = mul_shoup_lazy(p2 + t - y, z, zs, p);
+    x = csub_n(y + t, m.p2, m.np2);
+    y = mul_shoup_lazy_n(m.p2 + t - y, z, zs, m.np);
 }
 
 FHE_HD u64 splitmix64(u64 x) {

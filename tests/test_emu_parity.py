@@ -101,3 +101,25 @@ def test_rgsw_and_inner_sum(fhe):
 
 def test_errors(fhe):
     cases.case_errors(fhe)
+
+
+def test_key_switch_n8192_lds_accumulators(fhe):
+    """N = 8192: the fused key switch keeps its c1 accumulators in LDS behind the row tile
+    (1024 threads x 128 VGPRs do not hold both sets); synthetic key and input vs the C oracle."""
+    import numpy as np
+    from fhe_oracle import bfv as obfv, coracle
+    from fhe_oracle.rq import Context as OCtx
+    import full_size
+    n, seed = 8192, 0xF4E50077
+    q = obfv.generate_moduli([60, 60], n)
+    cc = coracle.CCtx(OCtx(q, n))
+    ck = full_size.host_key(cc, seed, len(q))
+    c0 = np.stack([cc.synth_poly(seed, 0, 8 + 2 * i) for i in range(len(q))])
+    c1 = np.stack([cc.synth_poly(seed, 0, 9 + 2 * i) for i in range(len(q))])
+    ctx = fhe.Context(q, n)
+    ksk = fhe.KeySwitchingKey(ctx, ctx, c0, c1)
+    p = np.stack([cc.synth_poly(seed, i, 0) for i in range(2)])     # [2][L][N], any residues < q_i
+    g0, g1 = ksk.key_switch(p)
+    for i in range(2):
+        w0, w1 = ck.key_switch(p[i])
+        assert np.array_equal(np.asarray(g0[i]), w0) and np.array_equal(np.asarray(g1[i]), w1)

@@ -83,6 +83,8 @@ SIGNATURES = {
     "fhe_bfv_rgsw_mul_dev": (i32, [vp, vp, vp, vp, sz, vp]),
     "fhe_bfv_inner_sum": (i32, [C.POINTER(vp), szp, sz, u64p, u64p, sz]),
     "fhe_bfv_inner_sum_dev": (i32, [C.POINTER(vp), szp, sz, vp, vp, sz, vp]),
+    "fhe_bfv_expand": (i32, [C.POINTER(vp), sz, u64p, u64p, sz, sz]),
+    "fhe_bfv_expand_dev": (i32, [C.POINTER(vp), sz, vp, vp, sz, sz, vp]),
     "fhe_mul_create": (i32, [vp, vp, vp, vp, i32, C.POINTER(vp)]),
     "fhe_mul_destroy": (None, [vp]),
     "fhe_mul_out_shape": (i32, [vp, szp, szp]),

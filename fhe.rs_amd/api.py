@@ -467,6 +467,34 @@ class EvaluationKey:
         check(L.fhe_bfv_inner_sum(handles, exps, len(seq), _ptr(x), _ptr(out), b))
         return out
 
+    def supports_expansion(self, level):
+        """evaluation_key.rs:174-186: the Galois keys of (N >> l) + 1, l < level, are present."""
+        return level <= self.degree.bit_length() - 1 and all((self.degree >> l) + 1 in self.gk for l in range(level))
+
+    def expands(self, ct, size):
+        """EvaluationKey::expands (evaluation_key.rs:192-256): ct [2, L, N] (or [batch, 2, L, N])
+        -> [size, 2, L, N] (or [size, batch, 2, L, N])."""
+        if size == 0 or size > self.degree:
+            raise FheError(-20, "InvalidExpansionSize")
+        level = (size - 1).bit_length()
+        if not self.supports_expansion(level):
+            raise FheError(-21, "EvaluationKeyError::Unsupported(Expansion)")
+        L = _lib.lib()
+        if level == 0:   # the reference returns vec![ct.clone()] without looking at any key
+            return (ct.clone() if _is_dev(ct) else _np(ct).copy())[None]
+        handles = (C.c_void_p * level)(*[self.gk[(self.degree >> l) + 1].ksk._h for l in range(level)])
+        ctx = self.gk[self.degree + 1].ksk.ctx_ciphertext
+        b = ctx._batch(ct) // 2
+        oshape = (size,) + tuple(ct.shape)
+        if _is_dev(ct):
+            out = torch.empty(oshape, dtype=ct.dtype, device=ct.device)
+            check(L.fhe_bfv_expand_dev(handles, level, _dptr(ct), _dptr(out), size, b, _stream()))
+            return out
+        x = _np(ct)
+        out = np.zeros(oshape, dtype=np.uint64)
+        check(L.fhe_bfv_expand(handles, level, _ptr(x), _ptr(out), size, b))
+        return out
+
     def rotates_columns_by(self, ct, i):
         if not (1 <= i < self.degree // 2):
             raise FheError(-1, "InvalidRotationStep")

@@ -23,7 +23,7 @@ enum : int {
     E_CONTEXT_MISMATCH = -6, E_DEGREE_MISMATCH = -7, E_NO_MORE_CONTEXT = -8, E_CONTEXT_NOT_REACHABLE = -9,
     E_INVALID_SUBST = -10, E_PARAMETER_MISMATCH = -11, E_INVALID_LEVEL = -12, E_MUL_POLY_COUNT = -13,
     E_EMPTY_MODULI = -14, E_NON_COPRIME = -15, E_NOT_ENOUGH_PRIMES = -16, E_KEYSWITCH_UNSUPPORTED = -17,
-    E_NO_DEVICE = -18, E_EMPTY_DOT = -19
+    E_NO_DEVICE = -18, E_EMPTY_DOT = -19, E_EXPANSION_SIZE = -20, E_EXPANSION_UNSUPPORTED = -21
 };
 
 #define FHE_HIP_CHECK(expr)                                                                        \
@@ -837,6 +837,44 @@ inline void inner_sum(const Ksk *const *gks, const size_t *exps, size_t ngk, con
         require(gks[i]->ct_ctx->same_ring(cc), E_PARAMETER_MISMATCH, "inner sum: Galois keys of different levels");
         galois_apply(*gks[i], exps[i], out, tmp.u(), batch, s);
         ew_op(cc, out, tmp.u(), batch * 2, k::EW_ADD, s);
+    }
+}
+
+// EvaluationKey::expands (F/bfv/keys/evaluation_key.rs:192-256): ct [batch][2][L][N] ->
+// out [size][batch][2][L][N] (slot-major, so that the 2^l * batch ciphertexts a level works on
+// are contiguous and go through one batched Galois key switch).
+inline void expand(const Ksk *const *gks, size_t nlevels, const u64 *ct, u64 *out, size_t size, size_t batch,
+                   hipStream_t s) {
+    require(nlevels > 0, E_ARG, "expansion needs at least one Galois key");
+    const Ctx &cc = *gks[0]->ct_ctx;
+    cc.need_device();
+    if (size < 1 || size > cc.n)
+        throw StatusError(E_EXPANSION_SIZE,
+                          "InvalidExpansionSize: size " + std::to_string(size) + ", degree " + std::to_string(cc.n));
+    size_t level = 0;
+    while (((size_t)1 << level) < size) level++;
+    if (level > nlevels)
+        throw StatusError(E_EXPANSION_UNSUPPORTED, "expansion to level " + std::to_string(level) +
+                                                       " needs the Galois keys of (N >> l) + 1, l < level");
+    if (!batch) return;
+    const u64 PL = (u64)cc.L * cc.n, CT = 2 * PL;
+    FHE_HIP_CHECK(hipMemcpyAsync(out, ct, batch * CT * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    if (level == 0) return;
+    for (size_t l = 0; l < level; l++)
+        require(gks[l]->ct_ctx->same_ring(cc), E_PARAMETER_MISMATCH, "expansion: Galois keys of different levels");
+    // monomials -x^(N - 2^l) in Ntt form (the reference keeps them in the EvaluationKey, :467-474)
+    WsGuard mono(level * PL * sizeof(u64), s), sub(((size_t)1 << (level - 1)) * batch * CT * sizeof(u64), s);
+    FHE_HIP_CHECK(hipMemsetAsync(mono.u(), 0, level * PL * sizeof(u64), s));
+    FHE_LAUNCH("monomial", k::monomial_kernel, dim3(blocks_for(level * cc.L, 64)), dim3(64), 0, s, mono.u(), cc.dmods(),
+               (uint32_t)level, (uint32_t)cc.L, (uint32_t)cc.logn);
+    launch_ntt(cc, false, mono.u(), mono.u(), full_map(cc, cc.L), level, k::PRO_NONE, s);
+    for (size_t l = 0; l < level; l++) {
+        const size_t step = (size_t)1 << l, cnt = step * batch;
+        const size_t nhigh = std::min(step, size - step) * batch;
+        galois_apply(*gks[l], (cc.n >> l) + 1, out, sub.u(), cnt, s);
+        FHE_LAUNCH("expand_step", k::expand_step_kernel, dim3(blocks_for(PL, EW_THREADS), (unsigned)(cnt * 2)),
+                   dim3(EW_THREADS), 0, s, out, sub.u(), out + step * batch * CT, mono.u() + l * PL, cc.dmods(),
+                   (uint32_t)cc.logn, PL, (uint32_t)(nhigh * 2));
     }
 }
 

@@ -885,6 +885,47 @@ fhe_status fhe_bfv_inner_sum(const fhe_ksk *const *gks, const size_t *exponents,
     });
 }
 
+static const Ctx &expand_args(const fhe_ksk *const *gks, size_t nlevels, std::vector<const Ksk *> &v) {
+    need(gks, "gks");
+    if (nlevels == 0) throw StatusError(FHE_E_ARG, "expansion needs at least one Galois key");
+    for (size_t i = 0; i < nlevels; i++) {
+        need(gks[i], "gks[i]");
+        v.push_back(gks[i]->k.get());
+    }
+    return *v[0]->ct_ctx;
+}
+fhe_status fhe_bfv_expand_dev(const fhe_ksk *const *gks, size_t nlevels, const uint64_t *ct, uint64_t *out, size_t size,
+                              size_t batch, void *stream) {
+    return guard([&] {
+        std::vector<const Ksk *> v;
+        expand_args(gks, nlevels, v);
+        if (batch && size) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        set_device(*v[0]->ksk_ctx);
+        expand(v.data(), nlevels, ct, out, size, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_expand(const fhe_ksk *const *gks, size_t nlevels, const uint64_t *ct, uint64_t *out, size_t size,
+                          size_t batch) {
+    return guard([&] {
+        std::vector<const Ksk *> v;
+        const Ctx &cc = expand_args(gks, nlevels, v);
+        if (batch && size) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        set_device(*v[0]->ksk_ctx);
+        const size_t ce = 2 * cc.L * cc.n;
+        const bool ok = size >= 1 && size <= cc.n;  // (the engine reports the error; do not size buffers from it)
+        HostIO io;
+        u64 *di = io.in(ct, batch * ce), *dout = io.out(ok ? size * batch * ce : 0);
+        expand(v.data(), nlevels, di, dout, size, batch, nullptr);
+        io.back(out, dout, size * batch * ce);
+    });
+}
+
 // ----------------------------------------------------------------------------- mul ----
 static std::unique_ptr<Mul> make_mul(const Scaler *el, const Scaler *er, const Scaler *dn, const Ksk *rk,
                                      bool mod_switch) {

@@ -929,6 +929,31 @@ __global__ void mul_plain_kernel(const u64 *__restrict__ ct, const u64 *__restri
     out[idx] = mul_mod(ct[idx], pt[(u64)b * pt_batch_stride + off], m);
 }
 
+// Oblivious expansion (F/bfv/keys/evaluation_key.rs:233-244).  monomial_kernel writes the
+// PowerBasis polynomials -x^(N - 2^l), l < nlev, into a zeroed [nlev][L][N] buffer (the forward
+// NTT follows); expand_step_kernel does, per coefficient of the polynomials of the lower half,
+// high = (low - sub) (.) monomial  (only the first nhigh polynomials of the upper half exist)
+// and low += sub.  grid = (ceil(L*N / block), npolys).
+__global__ void monomial_kernel(u64 *__restrict__ buf, const DevMod *__restrict__ mods, uint32_t nlev, uint32_t nmod,
+                                uint32_t logn) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nlev * nmod) return;
+    const uint32_t lev = gid / nmod, r = gid % nmod, n = 1u << logn;
+    buf[((u64)lev * nmod + r) * n + (n - (1u << lev))] = mods[r].p - 1;
+}
+__global__ void expand_step_kernel(u64 *__restrict__ low, const u64 *__restrict__ sub, u64 *__restrict__ high,
+                                   const u64 *__restrict__ mono, const DevMod *__restrict__ mods, uint32_t logn, u64 pl,
+                                   uint32_t nhigh) {
+    const u64 off = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (off >= pl) return;
+    const uint32_t poly = blockIdx.y;
+    const DevMod m = mods[off >> logn];
+    const u64 idx = (u64)poly * pl + off;
+    const u64 lo = low[idx], sb = sub[idx];
+    if (poly < nhigh) high[idx] = mul_mod(sub_mod(lo, sb, m.p), mono[off], m);
+    low[idx] = add_mod(lo, sb, m.p);
+}
+
 // Copies the first `rows` rows of each polynomial: in [npolys][in_rows][N] -> out [npolys][out_rows][N].
 __global__ void copy_rows_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,
                                  u64 out_poly_stride, u64 per_poly, u64 total) {

@@ -51,7 +51,9 @@ enum {
     FHE_E_NOT_ENOUGH_PRIMES = -16,            /* ParametersError::NotEnoughPrimes                 */
     FHE_E_KEYSWITCH_UNSUPPORTED = -17,        /* EvaluationKeyError::KeySwitchingNotSupported     */
     FHE_E_NO_DEVICE = -18,                    /* compute call on a host-only (device = -1) handle */
-    FHE_E_EMPTY_DOT_PRODUCT = -19             /* Error::EmptyDotProduct / DotProductError::EmptyInput */
+    FHE_E_EMPTY_DOT_PRODUCT = -19,            /* Error::EmptyDotProduct / DotProductError::EmptyInput */
+    FHE_E_INVALID_EXPANSION_SIZE = -20,       /* EvaluationKeyError::InvalidExpansionSize          */
+    FHE_E_EXPANSION_UNSUPPORTED = -21         /* EvaluationKeyError::Unsupported{Expansion} / Missing{GaloisKey} */
 };
 
 typedef struct fhe_ctx fhe_ctx;       /* == rq::Context on one device   (M/rq/context.rs:9-19)        */
@@ -219,6 +221,16 @@ fhe_status fhe_bfv_inner_sum(const fhe_ksk *const *gks, const size_t *exponents,
                              uint64_t *out, size_t batch);
 fhe_status fhe_bfv_inner_sum_dev(const fhe_ksk *const *gks, const size_t *exponents, size_t ngk, const uint64_t *ct,
                                  uint64_t *out, size_t batch, void *stream);
+/* EvaluationKey::expands (F/bfv/keys/evaluation_key.rs:192-256), the oblivious expansion of
+ * eprint 2019/1483: gks[l] is the Galois key of element (N >> l) + 1, l < nlevels; expanding to
+ * `size` outputs needs ceil(log2(size)) of them (fewer -> FHE_E_EXPANSION_UNSUPPORTED; size == 0 or
+ * size > N -> FHE_E_INVALID_EXPANSION_SIZE).  The monomials -x^(N - 2^l) of the reference's
+ * EvaluationKey are derived by the engine from the context's NTT tables.
+ * ct [batch][2][L][N] Ntt -> out [size][batch][2][L][N] Ntt (batch = 1: the reference's Vec<Ciphertext>). */
+fhe_status fhe_bfv_expand(const fhe_ksk *const *gks, size_t nlevels, const uint64_t *ct, uint64_t *out, size_t size,
+                          size_t batch);
+fhe_status fhe_bfv_expand_dev(const fhe_ksk *const *gks, size_t nlevels, const uint64_t *ct, uint64_t *out, size_t size,
+                              size_t batch, void *stream);
 
 /* ------------------------------------------------------------- Multiplicator ---- */
 /* Multiplicator::new_leveled_internal + enable_relinearization + enable_mod_switching

@@ -641,3 +641,40 @@ def inner_sum(ct, galois_keys, degree):
         i *= 2
     tmp = galois_keys[2 * degree - 1].relinearize(out)
     return out.add(tmp)
+
+
+def expansion_monomial(par, level, l):
+    """evaluation_key.rs:467-474: -x^(N - 2^l) over the ciphertext context, in Ntt form."""
+    ctx = par.context_at_level(level)
+    v = [0] * par.degree()
+    v[par.degree() - (1 << l)] = -1
+    return Poly.from_i64(ctx, v).into_ntt()
+
+
+def expands(ct, size, galois_keys):
+    """EvaluationKey::expands (evaluation_key.rs:192-256), eprint 2019/1483.
+    galois_keys: {element: GaloisKey}; needs (N >> l) + 1 for l < ceil(log2(size))."""
+    n = ct.par.degree()
+    if len(ct) != 2:
+        raise ValueError("InvalidPolynomialCount")
+    if size == 0 or size > n:
+        raise ValueError("InvalidExpansionSize")
+    level = (size - 1).bit_length()
+    if level == 0:
+        return [ct.clone()]
+    if any((n >> l) + 1 not in galois_keys for l in range(level)):
+        raise ValueError("Unsupported(Expansion)")
+    out = [None] * (1 << level)
+    out[0] = ct.clone()
+    for l in range(level):
+        monomial = expansion_monomial(ct.par, ct.level, l)
+        gk = galois_keys[(n >> l) + 1]
+        step = 1 << l
+        for i in range(step):
+            sub = gk.relinearize(out[i])
+            j = step | i
+            if j < size:
+                t = out[i].sub(sub)
+                out[j] = Ciphertext(ct.par, [t[0].mul(monomial), t[1].mul(monomial)], ct.level)
+            out[i] = out[i].add(sub)
+    return out[:size]

@@ -456,6 +456,58 @@ def case_rgsw_and_inner_sum(fhe, dev, n=16):
         assert err.code == -11
 
 
+def case_expand(fhe, dev, n=16, nmod=3):
+    """evaluation_key.rs:192-256 and its tests :798-885: oblivious expansion.  The oracle result
+    satisfies the reference test's closed form (ct_i decrypts to 2^level * v_i at x^0); the engine
+    equals the oracle bit for bit, for power-of-two and ragged sizes, batched and unbatched."""
+    x = Xfer(dev)
+    rng = random.Random(23)
+    opar, par = _params(fhe, nmod, n)
+    sk = obfv.SecretKey.random(opar, rng)
+    t = opar.plaintext
+    logn = n.bit_length() - 1
+    for level in (0, 1):
+        ctx = par.context_at_level(level)
+        ogks, gks = {}, []
+        for l in range(logn):
+            e = (n >> l) + 1
+            ogks[e] = obfv.GaloisKey(sk, e, level, level, rng)
+            c0, c0s, c1, c1s = ksk_arrays(ogks[e].ksk)
+            gks.append(fhe.GaloisKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1), e))
+        ek = fhe.EvaluationKey(n, gks)
+        assert ek.supports_expansion(logn) and not fhe.EvaluationKey(n, gks[:2]).supports_expansion(3)
+        for size in ((1, 2, 5, n) if level == 0 else (3, 8)):
+            lv = (size - 1).bit_length()
+            v = [rng.randrange(t) for _ in range(1 << lv)]
+            ct = sk.encrypt(v, rng, level)
+            want = obfv.expands(ct, size, ogks)
+            assert len(want) == size
+            for vi, c in zip(v, want):                       # the reference test's closed form
+                assert sk.decrypt(c) == [(vi << lv) % t] + [0] * (n - 1)
+            got = x.back(ek.expands(x.to(ct_arr(ct)), size))
+            assert got.shape == (size, 2, len(ctx.moduli), n)
+            for i, c in enumerate(want):
+                assert np.array_equal(got[i], ct_arr(c)), (level, size, i)
+        # batched: [batch, 2, L, N] -> [size, batch, 2, L, N]
+        cts = [sk.encrypt([rng.randrange(t) for _ in range(4)], rng, level) for _ in range(3)]
+        got = x.back(ek.expands(x.to(np.stack([ct_arr(c) for c in cts])), 3))
+        for b, c in enumerate(cts):
+            for i, w in enumerate(obfv.expands(c, 3, ogks)):
+                assert np.array_equal(got[i, b], ct_arr(w)), (level, b, i)
+    ct = x.to(ct_arr(cts[0]))
+    for size, code in ((0, -20), (n + 1, -20)):
+        try:
+            ek.expands(ct, size)
+            raise AssertionError("invalid expansion size accepted")
+        except fhe.FheError as err:
+            assert err.code == code
+    try:
+        fhe.EvaluationKey(n, gks[:1]).expands(ct, 4)
+        raise AssertionError("expansion without the needed Galois keys accepted")
+    except fhe.FheError as err:
+        assert err.code == -21
+
+
 def case_errors(fhe):
     """Error conventions (include/fhe_hip.h status codes <-> fhe_math::Error variants)."""
     def code(fn):

@@ -99,6 +99,10 @@ def test_rgsw_and_inner_sum(fhe):
     cases.case_rgsw_and_inner_sum(fhe, False)
 
 
+def test_expand(fhe):
+    cases.case_expand(fhe, False)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 

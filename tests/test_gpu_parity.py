@@ -109,6 +109,11 @@ def test_rgsw_and_inner_sum(fhe, dev):
     cases.case_rgsw_and_inner_sum(fhe, dev)
 
 
+@pytest.mark.parametrize("dev", [False, True])
+def test_expand(fhe, dev):
+    cases.case_expand(fhe, dev)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 

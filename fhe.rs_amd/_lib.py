@@ -53,6 +53,11 @@ SIGNATURES = {
     "fhe_poly_mul_shoup_dev": (i32, [vp, vp, vp, vp, sz, vp]),
     "fhe_poly_substitute": (i32, [vp, sz, u64p, u64p, sz, i32]),
     "fhe_poly_substitute_dev": (i32, [vp, sz, vp, vp, sz, i32, vp]),
+    "fhe_poly_serialized_size": (sz, [vp]),
+    "fhe_poly_serialize": (i32, [vp, u64p, u8p, sz, i32]),
+    "fhe_poly_serialize_dev": (i32, [vp, vp, vp, sz, i32, vp]),
+    "fhe_poly_deserialize": (i32, [vp, u8p, u64p, sz, i32]),
+    "fhe_poly_deserialize_dev": (i32, [vp, vp, vp, sz, i32, vp]),
     "fhe_poly_switch_down": (i32, [vp, u64p, u64p, sz]),
     "fhe_poly_switch_down_dev": (i32, [vp, vp, vp, sz, vp]),
     "fhe_scaler_create": (i32, [vp, vp, u64p, sz, u64p, sz, C.POINTER(vp)]),

@@ -45,6 +45,12 @@ def _dptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _dptr8(t):
+    if not t.is_cuda or not t.is_contiguous() or t.element_size() != 1:
+        raise ValueError("wire buffers must be contiguous uint8 CUDA tensors")
+    return C.c_void_p(t.data_ptr())
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -144,6 +150,43 @@ class Context:
 
     def ntt_backward(self, polys):
         return self._unary_inplace("fhe_ntt_backward", "fhe_ntt_backward_dev", polys)
+
+    # -- Rq wire format (rq/convert.rs:17-99, zq/mod.rs:783-793) ------------------------------
+    @property
+    def serialized_size(self):
+        return int(_lib.lib().fhe_poly_serialized_size(self._h))
+
+    def serialize(self, polys, from_ntt=False):
+        """[..., L, N] -> uint8 [..., serialized_size]: the `coefficients` payload of the Rq message."""
+        L = _lib.lib()
+        b = self._batch(polys)
+        oshape = tuple(polys.shape[:-2]) + (self.serialized_size,)
+        if _is_dev(polys):
+            out = torch.empty(oshape, dtype=torch.uint8, device=polys.device)
+            check(L.fhe_poly_serialize_dev(self._h, _dptr(polys), _dptr8(out), b, 1 if from_ntt else 0, _stream()))
+            return out
+        x = _np(polys)
+        out = np.zeros(oshape, dtype=np.uint8)
+        check(L.fhe_poly_serialize(self._h, _ptr(x), out.ctypes.data_as(_lib.u8p), b, 1 if from_ntt else 0))
+        return out
+
+    def deserialize(self, data, to_ntt=False):
+        """uint8 [..., serialized_size] -> [..., L, N]."""
+        L = _lib.lib()
+        if data.shape[-1] != self.serialized_size:
+            raise FheError(-1, "InvalidCoefficientCount")
+        oshape = tuple(data.shape[:-1]) + (self.nmoduli, self.degree)
+        b = 1
+        for d in data.shape[:-1]:
+            b *= int(d)
+        if _is_dev(data):
+            out = torch.empty(oshape, dtype=torch.int64, device=data.device)
+            check(L.fhe_poly_deserialize_dev(self._h, _dptr8(data.contiguous()), _dptr(out), b, 1 if to_ntt else 0, _stream()))
+            return out
+        x = np.ascontiguousarray(np.asarray(data, dtype=np.uint8))
+        out = np.zeros(oshape, dtype=np.uint64)
+        check(L.fhe_poly_deserialize(self._h, x.ctypes.data_as(_lib.u8p), _ptr(out), b, 1 if to_ntt else 0))
+        return out
 
     # -- rq/ops.rs ----------------------------------------------------------------------
     def add(self, a, b):

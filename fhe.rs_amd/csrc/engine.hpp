@@ -465,6 +465,43 @@ inline void ew_op(const Ctx &c, u64 *a, const u64 *b, size_t npolys, uint32_t op
                (uint32_t)c.L, (uint32_t)c.logn, op, total);
 }
 
+// ------------------------------------------------------------------ Rq wire format ----
+inline size_t wire_poly_bytes(const Ctx &c) {
+    size_t b = 0;
+    for (size_t i = 0; i < c.L; i++) b += (size_t)(64 - __builtin_clzll(c.mods[i].p - 1)) * (c.n / 8);
+    return b;
+}
+// polys [npolys][L][N] -> bytes [npolys][wire_poly_bytes]; from_ntt: inverse NTT first (into scratch).
+inline void wire_serialize(const Ctx &c, const u64 *polys, uint8_t *bytes, size_t npolys, bool from_ntt, hipStream_t s) {
+    c.need_device();
+    if (!npolys) return;
+    const u64 pe = (u64)c.L * c.n;
+    WsGuard pb(from_ntt ? npolys * pe * sizeof(u64) : 8, s);
+    if (from_ntt) {
+        launch_ntt(c, true, polys, pb.u(), full_map(c, c.L), npolys, k::PRO_NONE, s);
+        polys = pb.u();
+    }
+    const unsigned groups = (unsigned)(c.n / 8), block = groups < 256 ? 64 : 256;
+    const u64 wb = wire_poly_bytes(c);
+    for (size_t p0 = 0; p0 < npolys; p0 += 32768) {  // gridDim.z <= 65535
+        const size_t np = std::min<size_t>(32768, npolys - p0);
+        FHE_LAUNCH("wire_pack", k::wire_pack_kernel, dim3(blocks_for(groups, block), (unsigned)c.L, (unsigned)np),
+                   dim3(block), 0, s, polys + p0 * pe, bytes + p0 * wb, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, wb);
+    }
+}
+inline void wire_deserialize(const Ctx &c, const uint8_t *bytes, u64 *polys, size_t npolys, bool to_ntt, hipStream_t s) {
+    c.need_device();
+    if (!npolys) return;
+    const unsigned groups = (unsigned)(c.n / 8), block = groups < 256 ? 64 : 256;
+    const u64 wb = wire_poly_bytes(c), pe = (u64)c.L * c.n;
+    for (size_t p0 = 0; p0 < npolys; p0 += 32768) {
+        const size_t np = std::min<size_t>(32768, npolys - p0);
+        FHE_LAUNCH("wire_unpack", k::wire_unpack_kernel, dim3(blocks_for(groups, block), (unsigned)c.L, (unsigned)np),
+                   dim3(block), 0, s, bytes + p0 * wb, polys + p0 * pe, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, wb);
+    }
+    if (to_ntt) launch_ntt(c, false, polys, polys, full_map(c, c.L), npolys, k::PRO_NONE, s);
+}
+
 // ----------------------------------------------------------------------- rq::Scaler ----
 struct Scaler {
     const Ctx *from = nullptr, *to = nullptr;

@@ -365,6 +365,64 @@ fhe_status fhe_poly_substitute(const fhe_ctx *ctx, size_t exponent, const uint64
     });
 }
 
+size_t fhe_poly_serialized_size(const fhe_ctx *ctx) { return ctx ? wire_poly_bytes(*ctx->c) : 0; }
+fhe_status fhe_poly_serialize_dev(const fhe_ctx *ctx, const uint64_t *polys, uint8_t *bytes, size_t batch, int from_ntt,
+                                  void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        if (batch) {
+            need(polys, "polys");
+            need(bytes, "bytes");
+        }
+        wire_serialize(c, polys, bytes, batch, from_ntt != 0, as_stream(stream));
+    });
+}
+fhe_status fhe_poly_serialize(const fhe_ctx *ctx, const uint64_t *polys, uint8_t *bytes, size_t batch, int from_ntt) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch) {
+            need(polys, "polys");
+            need(bytes, "bytes");
+        }
+        const size_t wb = wire_poly_bytes(c);
+        HostIO io;
+        u64 *di = io.in(polys, batch * pe);
+        uint8_t *db = reinterpret_cast<uint8_t *>(io.out((batch * wb + 7) / 8));
+        wire_serialize(c, di, db, batch, from_ntt != 0, nullptr);
+        FHE_HIP_CHECK(hipStreamSynchronize(nullptr));
+        if (batch) FHE_HIP_CHECK(hipMemcpy(bytes, db, batch * wb, hipMemcpyDeviceToHost));
+    });
+}
+fhe_status fhe_poly_deserialize_dev(const fhe_ctx *ctx, const uint8_t *bytes, uint64_t *polys, size_t batch, int to_ntt,
+                                    void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        if (batch) {
+            need(polys, "polys");
+            need(bytes, "bytes");
+        }
+        wire_deserialize(c, bytes, polys, batch, to_ntt != 0, as_stream(stream));
+    });
+}
+fhe_status fhe_poly_deserialize(const fhe_ctx *ctx, const uint8_t *bytes, uint64_t *polys, size_t batch, int to_ntt) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        if (batch) {
+            need(polys, "polys");
+            need(bytes, "bytes");
+        }
+        const size_t wb = wire_poly_bytes(c);
+        HostIO io;
+        uint8_t *db = reinterpret_cast<uint8_t *>(io.out((batch * wb + 7) / 8));
+        if (batch) FHE_HIP_CHECK(hipMemcpy(db, bytes, batch * wb, hipMemcpyHostToDevice));
+        u64 *dout = io.out(batch * pe);
+        wire_deserialize(c, db, dout, batch, to_ntt != 0, nullptr);
+        io.back(polys, dout, batch * pe);
+    });
+}
+
 fhe_status fhe_poly_switch_down_dev(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, size_t batch, void *stream) {
     return guard([&] {
         FHE_POLY_IO_PROLOGUE(ctx);

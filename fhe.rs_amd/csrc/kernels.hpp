@@ -929,6 +929,59 @@ __global__ void mul_plain_kernel(const u64 *__restrict__ ct, const u64 *__restri
     out[idx] = mul_mod(ct[idx], pt[(u64)b * pt_batch_stride + off], m);
 }
 
+// Rq wire format (crates/fhe-util/src/lib.rs:71-148 via M/zq/mod.rs:783-793): a row is N
+// coefficients of nbits = bitlen(p - 1) bits, little-endian bit-packed.  Eight coefficients are
+// exactly nbits bytes, so one thread transcodes one such group with the reference's shift
+// register; grid = (ceil(N/8 / block), L, npolys).  (Boundary work: byte-granular accesses.)
+__device__ __forceinline__ uint32_t wire_bits(u64 p) { return 64u - (uint32_t)__builtin_clzll(p - 1); }
+__device__ __forceinline__ u64 wire_row_offset(const DevMod *mods, uint32_t r, uint32_t logn) {
+    u64 off = 0;
+    for (uint32_t i = 0; i < r; i++) off += (u64)wire_bits(mods[i].p) << (logn - 3);
+    return off;
+}
+__global__ void wire_pack_kernel(const u64 *__restrict__ polys, uint8_t *__restrict__ bytes,
+                                 const DevMod *__restrict__ mods, uint32_t nmod, uint32_t logn, u64 poly_bytes) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (1u << (logn - 3))) return;
+    const uint32_t r = blockIdx.y, poly = blockIdx.z;
+    const uint32_t nbits = wire_bits(mods[r].p);
+    const u64 mask = ~0ull >> (64 - nbits);
+    const u64 *src = polys + (((u64)poly * nmod + r) << logn) + 8u * g;
+    uint8_t *dst = bytes + (u64)poly * poly_bytes + wire_row_offset(mods, r, logn) + (u64)g * nbits;
+    u128_t cur = 0;
+    uint32_t have = 0, o = 0;
+    for (uint32_t e = 0; e < 8; e++) {
+        cur |= (u128_t)(src[e] & mask) << have;
+        have += nbits;
+        while (have >= 8) {
+            dst[o++] = (uint8_t)cur;
+            cur >>= 8;
+            have -= 8;
+        }
+    }
+}
+__global__ void wire_unpack_kernel(const uint8_t *__restrict__ bytes, u64 *__restrict__ polys,
+                                   const DevMod *__restrict__ mods, uint32_t nmod, uint32_t logn, u64 poly_bytes) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (1u << (logn - 3))) return;
+    const uint32_t r = blockIdx.y, poly = blockIdx.z;
+    const uint32_t nbits = wire_bits(mods[r].p);
+    const u64 mask = ~0ull >> (64 - nbits);
+    const uint8_t *src = bytes + (u64)poly * poly_bytes + wire_row_offset(mods, r, logn) + (u64)g * nbits;
+    u64 *dst = polys + (((u64)poly * nmod + r) << logn) + 8u * g;
+    u128_t cur = 0;
+    uint32_t have = 0, i = 0;
+    for (uint32_t e = 0; e < 8; e++) {
+        while (have < nbits) {
+            cur |= (u128_t)src[i++] << have;
+            have += 8;
+        }
+        dst[e] = (u64)cur & mask;
+        cur >>= nbits;
+        have -= nbits;
+    }
+}
+
 // Oblivious expansion (F/bfv/keys/evaluation_key.rs:233-244).  monomial_kernel writes the
 // PowerBasis polynomials -x^(N - 2^l), l < nlev, into a zeroed [nlev][L][N] buffer (the forward
 // NTT follows); expand_step_kernel does, per coefficient of the polynomials of the lower half,

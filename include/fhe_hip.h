@@ -127,6 +127,26 @@ fhe_status fhe_poly_switch_down(const fhe_ctx *ctx, const uint64_t *in, uint64_t
 fhe_status fhe_poly_switch_down_dev(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, size_t batch,
                                     void *stream);
 
+/* Rq wire format (`impl From<&Poly> for Rq` / parse_proto, M/rq/convert.rs:17-44, 46-99; Modulus::
+ * serialize_vec / deserialize_vec, M/zq/mod.rs:783-793; fhe-util transcode_{to,from}_bytes,
+ * crates/fhe-util/src/lib.rs:71-148): the `coefficients` bytes of the Rq message hold, per residue
+ * row i, the N PowerBasis coefficients as bitlen(q_i - 1)-bit little-endian bit-packed integers, rows
+ * concatenated (N % 8 == 0, so every row is byte aligned).  The protobuf envelope (representation tag,
+ * degree) stays on the host; these calls move its payload.
+ *   fhe_poly_serialized_size: bytes per polynomial = sum_i N * bitlen(q_i - 1) / 8.
+ *   fhe_poly_serialize:   polys [batch][L][N] -> bytes [batch][size]; from_ntt != 0: the input is in Ntt
+ *                         form and is taken to PowerBasis first (the wire is always PowerBasis).
+ *   fhe_poly_deserialize: bytes [batch][size] -> polys [batch][L][N], coefficients taken verbatim
+ *                         (TryConvertFrom<Vec<u64>>, convert.rs:148-160); to_ntt != 0: followed by
+ *                         into_ntt (representation tag Ntt / NttShoup). */
+size_t fhe_poly_serialized_size(const fhe_ctx *ctx);
+fhe_status fhe_poly_serialize(const fhe_ctx *ctx, const uint64_t *polys, uint8_t *bytes, size_t batch, int from_ntt);
+fhe_status fhe_poly_serialize_dev(const fhe_ctx *ctx, const uint64_t *polys, uint8_t *bytes, size_t batch,
+                                  int from_ntt, void *stream);
+fhe_status fhe_poly_deserialize(const fhe_ctx *ctx, const uint8_t *bytes, uint64_t *polys, size_t batch, int to_ntt);
+fhe_status fhe_poly_deserialize_dev(const fhe_ctx *ctx, const uint8_t *bytes, uint64_t *polys, size_t batch,
+                                    int to_ntt, void *stream);
+
 /* ------------------------------------------------------------------ rq::Scaler ---- */
 /* Scaler::new (M/rq/scaler.rs:27-52) + RnsScaler::new (M/rns/scaler.rs:79-175): the engine
  * derives gamma/omega/theta with its own big-integer code from the ScalingFactor

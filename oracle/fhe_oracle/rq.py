@@ -364,3 +364,83 @@ class Switcher:
 
     def switch(self, p: Poly) -> Poly:
         return self.scaler.scale(p)
+
+
+# --------------------------------------------------------------------------------------
+# Rq wire format
+# --------------------------------------------------------------------------------------
+def transcode_to_bytes(a, nbits):
+    """crates/fhe-util/src/lib.rs:71-107."""
+    assert 0 < nbits <= 64
+    mask = (1 << nbits) - 1
+    nbytes = -(-(len(a) * nbits) // 8)
+    out = bytearray()
+    cur, have, i = 0, 0, 0
+    while i < len(a):
+        if have < 8:
+            cur |= (a[i] & mask) << have
+            have += nbits
+            i += 1
+        while have >= 8:
+            out.append(cur & 0xFF)
+            cur >>= 8
+            have -= 8
+    if have > 0:
+        assert have < 8 and len(out) == nbytes - 1
+        out.append(cur & 0xFF)
+    else:
+        assert len(out) == nbytes and cur == 0
+    return bytes(out)
+
+
+def transcode_from_bytes(b, nbits):
+    """crates/fhe-util/src/lib.rs:111-146."""
+    assert 0 < nbits <= 64
+    mask = (1 << nbits) - 1
+    nelements = -(-(len(b) * 8) // nbits)
+    out = []
+    cur, have, i = 0, 0, 0
+    while i < len(b):
+        if have < nbits:
+            cur |= b[i] << have
+            have += 8
+            i += 1
+        while have >= nbits:
+            out.append(cur & mask)
+            cur >>= nbits
+            have -= nbits
+    if have > 0:
+        assert len(out) == nelements - 1
+        out.append(cur)
+    else:
+        assert len(out) == nelements and cur == 0
+    return out
+
+
+def modulus_wire_bits(p):
+    """zq/mod.rs:783-793: p_nbits = 64 - (p - 1).leading_zeros()."""
+    return (p - 1).bit_length()
+
+
+def poly_to_wire(p: Poly) -> bytes:
+    """`impl From<&Poly<R>> for Rq`, rq/convert.rs:17-44: the `coefficients` field (always the
+    PowerBasis form, one bit-packed run per residue row)."""
+    assert not p.has_lazy_coefficients
+    q = p if p.rep == POWER_BASIS else p.clone().into_power_basis()
+    return b"".join(transcode_to_bytes(row, modulus_wire_bits(m)) for row, m in zip(q.coefficients, p.ctx.moduli))
+
+
+def poly_from_wire(ctx: Context, data: bytes, rep=POWER_BASIS) -> Poly:
+    """parse_proto + TryConvertFrom<&Rq>, rq/convert.rs:46-147 (coefficients taken verbatim)."""
+    n = ctx.degree
+    if n % 8 or n < 8:
+        raise ValueError("InvalidDegree")
+    sizes = [-(-(n * modulus_wire_bits(m)) // 8) for m in ctx.moduli]
+    if len(data) != sum(sizes):
+        raise ValueError("InvalidCoefficientCount")
+    rows, idx = [], 0
+    for m, sz in zip(ctx.moduli, sizes):
+        rows.append(transcode_from_bytes(data[idx:idx + sz], modulus_wire_bits(m))[:n])
+        idx += sz
+    p = Poly(ctx, POWER_BASIS, rows)
+    return p if rep == POWER_BASIS else p.into_ntt()

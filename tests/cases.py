@@ -508,6 +508,47 @@ def case_expand(fhe, dev, n=16, nmod=3):
         assert err.code == -21
 
 
+def case_wire_format(fhe, dev, n=32):
+    """rq/convert.rs:17-147 + zq/mod.rs:783-793 + fhe-util lib.rs:71-148: bit-packed Rq payload.
+    Engine bytes == oracle bytes for 62/61/51/20-bit moduli, PowerBasis and Ntt sources; decoding
+    (incl. into_ntt on arrival) inverts it; the reference's round-trip tests (lib.rs:323-370)."""
+    from fhe_oracle.rq import poly_to_wire, poly_from_wire, transcode_to_bytes, transcode_from_bytes
+    x = Xfer(dev)
+    rng = random.Random(29)
+    assert transcode_from_bytes(transcode_to_bytes([1, 2, 3, 4], 4), 4)[:4] == [1, 2, 3, 4]   # lib.rs:357-362
+    assert transcode_to_bytes([], 8) == b"" and transcode_from_bytes(b"", 8) == []             # lib.rs:365-371
+    moduli = [obfv.generate_moduli([b], n)[0] for b in (62, 61, 51, 20)]
+    o = OCtx(moduli, n)
+    c = fhe.Context(moduli, n)
+    assert c.serialized_size == sum(((m - 1).bit_length() * n) // 8 for m in moduli)
+    polys = [rand_poly(o, POWER_BASIS, rng) for _ in range(3)]
+    polys[0].coefficients = [[m - 1] * n for m in moduli]                 # all-ones bit patterns
+    polys[1].coefficients = [[0] * n for _ in moduli]
+    want = [poly_to_wire(p) for p in polys]
+    pb = np.stack([arr(p) for p in polys])
+    got = x.back_bytes(c.serialize(x.to(pb)))
+    for g, w in zip(got, want):
+        assert g.tobytes() == w
+    ntt = [p.clone().into_ntt() for p in polys]
+    got2 = x.back_bytes(c.serialize(x.to(np.stack([arr(p) for p in ntt])), from_ntt=True))
+    assert all(g.tobytes() == w for g, w in zip(got2, want))
+    data = np.stack([np.frombuffer(w, dtype=np.uint8) for w in want])
+    assert np.array_equal(x.back(c.deserialize(x.to_bytes(data))), pb)
+    back_ntt = x.back(c.deserialize(x.to_bytes(data), to_ntt=True))
+    for i, w in enumerate(want):
+        assert np.array_equal(back_ntt[i], arr(poly_from_wire(o, w, NTT)))
+        assert np.array_equal(back_ntt[i], arr(ntt[i]))
+    # arbitrary bytes decode like the reference (masking only): compare with the oracle
+    junk = bytes(rng.randrange(256) for _ in range(c.serialized_size))
+    dec = x.back(c.deserialize(x.to_bytes(np.frombuffer(junk, dtype=np.uint8)[None])))[0]
+    assert np.array_equal(dec, arr(poly_from_wire(o, junk)))
+    try:
+        c.deserialize(x.to_bytes(data[:, :-1]))
+        raise AssertionError("short payload accepted")
+    except fhe.FheError as err:
+        assert err.code == -1
+
+
 def case_errors(fhe):
     """Error conventions (include/fhe_hip.h status codes <-> fhe_math::Error variants)."""
     def code(fn):

@@ -85,6 +85,13 @@ class Xfer:
             return a
         return self.torch.from_numpy(a.view(np.int64)).cuda()
 
+    def to_bytes(self, a):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.uint8))
+        return a if not self.dev else self.torch.from_numpy(a.copy()).cuda()
+
+    def back_bytes(self, x):
+        return np.asarray(x) if not self.dev else x.cpu().numpy()
+
     def back(self, x):
         if not self.dev:
             return np.asarray(x)

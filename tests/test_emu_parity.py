@@ -103,6 +103,10 @@ def test_expand(fhe):
     cases.case_expand(fhe, False)
 
 
+def test_wire_format(fhe):
+    cases.case_wire_format(fhe, False)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 

@@ -114,6 +114,12 @@ def test_expand(fhe, dev):
     cases.case_expand(fhe, dev)
 
 
+@pytest.mark.parametrize("dev", [False, True])
+def test_wire_format(fhe, dev):
+    cases.case_wire_format(fhe, dev)
+    cases.case_wire_format(fhe, dev, n=8192)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 

@@ -611,6 +611,47 @@ class BfvParameters:
         return Scaler(self.mul_context_at_level(level), self.context_at_level(level),
                       _handle=self._get("fhe_params_down_scaler", level), _owner=self)
 
+    def plaintext_context(self):
+        """parameters.rs:578-595: the shortest prefix of the moduli with >= bits(t) + 60 bits."""
+        if getattr(self, "_plain_ctx", None) is None:
+            acc, count = 0, 0
+            for m in self.moduli:
+                acc += int(m).bit_length()
+                count += 1
+                if acc >= int(self.plaintext).bit_length() + 60:
+                    break
+            self._plain_ctx = Context(self.moduli[:max(1, count)], self.degree, device=self.device)
+        return self._plain_ctx
+
+    def plain_scaler(self, level):
+        """CipherPlainContext::scaler (parameters.rs:636-643): ciphertext level -> plaintext context, t / q."""
+        cache = self.__dict__.setdefault("_plain_scalers", {})
+        if level not in cache:
+            ctx = self.context_at_level(level)
+            q = 1
+            for m in ctx.moduli:
+                q *= int(m)
+            cache[level] = Scaler(ctx, self.plaintext_context(), int(self.plaintext), q)
+        return cache[level]
+
+    def decrypt(self, s_ntt, ct, level=0):
+        """SecretKey::try_decrypt (secret_key.rs:198-247, small plaintext modulus): s_ntt [L, N] is the
+        secret key over the ciphertext context in Ntt form; ct [..., nparts, L, N] -> [..., N] in [0, t)."""
+        L = _lib.lib()
+        sc = self.plain_scaler(level)
+        nparts = int(ct.shape[-3])
+        b = sc.from_ctx._batch(ct) // nparts
+        oshape = tuple(ct.shape[:-3]) + (self.degree,)
+        if _is_dev(ct):
+            out = torch.empty(oshape, dtype=ct.dtype, device=ct.device)
+            check(L.fhe_bfv_decrypt_dev(sc._h, int(self.plaintext), _dptr(s_ntt), _dptr(ct), nparts, _dptr(out), b,
+                                        _stream()))
+            return out
+        x, sk = _np(ct), _np(s_ntt)
+        out = np.zeros(oshape, dtype=np.uint64)
+        check(L.fhe_bfv_decrypt(sc._h, int(self.plaintext), _ptr(sk), _ptr(x), nparts, _ptr(out), b))
+        return out
+
 
 class Multiplicator:
     """bfv::Multiplicator (crates/fhe/src/bfv/ops/mul.rs:21-243)."""

@@ -468,7 +468,7 @@ inline void ew_op(const Ctx &c, u64 *a, const u64 *b, size_t npolys, uint32_t op
 // ------------------------------------------------------------------ Rq wire format ----
 inline size_t wire_poly_bytes(const Ctx &c) {
     size_t b = 0;
-    for (size_t i = 0; i < c.L; i++) b += (size_t)(64 - __builtin_clzll(c.mods[i].p - 1)) * (c.n / 8);
+    for (size_t i = 0; i < c.L; i++) b += (size_t)(64 - __builtin_clzll(c.moduli[i] - 1)) * (c.n / 8);
     return b;
 }
 // polys [npolys][L][N] -> bytes [npolys][wire_poly_bytes]; from_ntt: inverse NTT first (into scratch).
@@ -875,6 +875,34 @@ inline void inner_sum(const Ksk *const *gks, const size_t *exps, size_t ngk, con
         galois_apply(*gks[i], exps[i], out, tmp.u(), batch, s);
         ew_op(cc, out, tmp.u(), batch * 2, k::EW_ADD, s);
     }
+}
+
+// SecretKey::try_decrypt, small-plaintext branch (F/bfv/keys/secret_key.rs:198-247):
+// ct [batch][nparts][L][N] Ntt, s_ntt [L][N] -> out [batch][N] in [0, t).
+inline void decrypt(const Scaler &sc, u64 t, const u64 *s_ntt, const u64 *ct, size_t nparts, u64 *out, size_t batch,
+                    hipStream_t s) {
+    const Ctx &cc = *sc.from, &pc = *sc.to;
+    cc.need_device();
+    require(nparts >= 1, E_ARG, "a ciphertext has at least one part");
+    // (deep levels may be shorter than the plaintext context; only q_0 has to agree, :232-234)
+    require(pc.L >= 1 && pc.moduli[0] == cc.moduli[0], E_PARAMETER_MISMATCH,
+            "the plaintext context must start with the first ciphertext modulus");
+    if (!batch) return;
+    const ModConsts tm = make_mod_consts(t);
+    const u64 PL = (u64)cc.L * cc.n;
+
+    WsGuard ph(batch * PL * sizeof(u64), s), d(batch * pc.L * cc.n * sizeof(u64), s);
+    FHE_LAUNCH("phase", k::phase_kernel, dim3(blocks_for(PL, EW_THREADS), (unsigned)batch), dim3(EW_THREADS), 0, s, ct,
+               s_ntt, ph.u(), cc.dmods(), (uint32_t)nparts, (uint32_t)cc.logn, PL);
+    launch_ntt(cc, true, ph.u(), ph.u(), full_map(cc, cc.L), batch, k::PRO_NONE, s);
+    scale_polys(sc, ph.u(), d.u(), batch, false, s);
+    DevMod q0, tmd;
+    static_assert(sizeof(DevMod) == sizeof(ModConsts), "DevMod layout");
+    std::memcpy(&q0, &cc.root->mods[0], sizeof(DevMod));  // (host tables live on the chain's root)
+    std::memcpy(&tmd, &tm, sizeof(DevMod));
+    const u64 total = (u64)batch * cc.n;
+    FHE_LAUNCH("decrypt_tail", k::decrypt_tail_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, d.u(),
+               (u64)pc.L * cc.n, out, q0, tmd, (uint32_t)cc.logn, total);
 }
 
 // EvaluationKey::expands (F/bfv/keys/evaluation_key.rs:192-256): ct [batch][2][L][N] ->

@@ -943,6 +943,39 @@ fhe_status fhe_bfv_inner_sum(const fhe_ksk *const *gks, const size_t *exponents,
     });
 }
 
+fhe_status fhe_bfv_decrypt_dev(const fhe_scaler *sc, uint64_t t, const uint64_t *s_ntt, const uint64_t *ct, size_t nparts,
+                               uint64_t *out, size_t batch, void *stream) {
+    return guard([&] {
+        need(sc, "cipher_plain_scaler");
+        need(s_ntt, "s_ntt");
+        if (batch) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        set_device(*sc->s->from);
+        decrypt(*sc->s, t, s_ntt, ct, nparts, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_decrypt(const fhe_scaler *sc, uint64_t t, const uint64_t *s_ntt, const uint64_t *ct, size_t nparts,
+                           uint64_t *out, size_t batch) {
+    return guard([&] {
+        need(sc, "cipher_plain_scaler");
+        need(s_ntt, "s_ntt");
+        if (batch) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        const Ctx &cc = *sc->s->from;
+        cc.need_device();
+        set_device(cc);
+        const size_t pe = cc.L * cc.n;
+        HostIO io;
+        u64 *ds = io.in(s_ntt, pe), *di = io.in(ct, batch * nparts * pe), *dout = io.out(batch * cc.n);
+        decrypt(*sc->s, t, ds, di, nparts, dout, batch, nullptr);
+        io.back(out, dout, batch * cc.n);
+    });
+}
+
 static const Ctx &expand_args(const fhe_ksk *const *gks, size_t nlevels, std::vector<const Ksk *> &v) {
     need(gks, "gks");
     if (nlevels == 0) throw StatusError(FHE_E_ARG, "expansion needs at least one Galois key");

@@ -929,6 +929,31 @@ __global__ void mul_plain_kernel(const u64 *__restrict__ ct, const u64 *__restri
     out[idx] = mul_mod(ct[idx], pt[(u64)b * pt_batch_stride + off], m);
 }
 
+// SecretKey::try_decrypt (F/bfv/keys/secret_key.rs:205-247).  phase_kernel: out[b] = sum_i
+// ct[b][i] (.) s^i by Horner's rule (same canonical value as the reference's running power of s);
+// grid = (ceil(L*N / block), batch).  decrypt_tail_kernel: ((d_0 + t) mod q_0) mod t on row 0
+// of the scaled polynomial.
+__global__ void phase_kernel(const u64 *__restrict__ ct, const u64 *__restrict__ sk, u64 *__restrict__ out,
+                             const DevMod *__restrict__ mods, uint32_t nparts, uint32_t logn, u64 pl) {
+    const u64 off = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (off >= pl) return;
+    const uint32_t b = blockIdx.y;
+    const DevMod m = mods[off >> logn];
+    const u64 *c = ct + (u64)b * nparts * pl + off;
+    const u64 sv = sk[off];
+    u64 acc = c[(u64)(nparts - 1) * pl];
+    for (uint32_t i = nparts - 1; i-- > 0;) acc = add_mod(mul_mod(acc, sv, m), c[(u64)i * pl], m.p);
+    out[(u64)b * pl + off] = acc;
+}
+__global__ void decrypt_tail_kernel(const u64 *__restrict__ d, u64 d_poly_stride, u64 *__restrict__ out, DevMod q0,
+                                    DevMod tm, uint32_t logn, u64 total) {
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const u64 b = gid >> logn, x = gid & ((1ull << logn) - 1);
+    const u64 w = reduce_u64(d[b * d_poly_stride + x] + tm.p, q0);
+    out[gid] = reduce_u64(w, tm);
+}
+
 // Rq wire format (crates/fhe-util/src/lib.rs:71-148 via M/zq/mod.rs:783-793): a row is N
 // coefficients of nbits = bitlen(p - 1) bits, little-endian bit-packed.  Eight coefficients are
 // exactly nbits bytes, so one thread transcodes one such group with the reference's shift

@@ -229,6 +229,18 @@ fhe_status fhe_bfv_mul_plain(const fhe_ctx *ctx, size_t nparts, const uint64_t *
                              uint64_t *out, size_t batch);
 fhe_status fhe_bfv_mul_plain_dev(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, const uint64_t *pt,
                                  int pt_shared, uint64_t *out, size_t batch, void *stream);
+/* SecretKey::try_decrypt, small-plaintext branch (F/bfv/keys/secret_key.rs:198-247): phase
+ * c0 + c1 s + c2 s^2 + ... over the ciphertext context, PowerBasis, Scaler::scale with the level's
+ * cipher-to-plaintext scaler (factor t / q, F/bfv/parameters.rs:636-643), then per coefficient
+ * ((d_0 + t) mod q_0) mod t.  `cipher_plain_scaler`: from = the ciphertext context, to = the plaintext
+ * context (a prefix of the moduli).  s_ntt [L][N]: the secret key polynomial over the ciphertext
+ * context in Ntt form (the host builds it from its ternary coefficients, secret_key.rs:200-203).
+ * ct [batch][nparts][L][N] Ntt -> out [batch][N], the plaintext polynomial's coefficients in [0, t). */
+fhe_status fhe_bfv_decrypt(const fhe_scaler *cipher_plain_scaler, uint64_t plaintext_modulus, const uint64_t *s_ntt,
+                           const uint64_t *ct, size_t nparts, uint64_t *out, size_t batch);
+fhe_status fhe_bfv_decrypt_dev(const fhe_scaler *cipher_plain_scaler, uint64_t plaintext_modulus,
+                               const uint64_t *s_ntt, const uint64_t *ct, size_t nparts, uint64_t *out, size_t batch,
+                               void *stream);
 /* `&Ciphertext * &RGSWCiphertext` (F/bfv/rgsw_ciphertext.rs:122-156), RGSWCiphertext{ksk0, ksk1}:
  * ct, out [batch][2][L][N] Ntt; both keys at the ciphertext level. */
 fhe_status fhe_bfv_rgsw_mul(const fhe_ksk *ksk0, const fhe_ksk *ksk1, const uint64_t *ct, uint64_t *out, size_t batch);

@@ -542,11 +542,38 @@ def case_wire_format(fhe, dev, n=32):
     junk = bytes(rng.randrange(256) for _ in range(c.serialized_size))
     dec = x.back(c.deserialize(x.to_bytes(np.frombuffer(junk, dtype=np.uint8)[None])))[0]
     assert np.array_equal(dec, arr(poly_from_wire(o, junk)))
+    # a borrowed level context (drops the last modulus)
+    c1, o1 = c.at_level(1), o.context_at_level(1)
+    p1 = rand_poly(o1, POWER_BASIS, rng)
+    w1 = poly_to_wire(p1)
+    assert c1.serialized_size == len(w1)
+    assert x.back_bytes(c1.serialize(x.to(arr(p1)[None])))[0].tobytes() == w1
     try:
         c.deserialize(x.to_bytes(data[:, :-1]))
         raise AssertionError("short payload accepted")
     except fhe.FheError as err:
         assert err.code == -1
+
+
+def case_decrypt(fhe, dev, n=16, nmod=3):
+    """secret_key.rs:198-247: the decrypt-side scaler.  2- and 3-part ciphertexts at levels 0 and 1;
+    engine output == oracle SecretKey::decrypt == the encrypted values / their product."""
+    x = Xfer(dev)
+    rng = random.Random(31)
+    opar, par = _params(fhe, nmod, n)
+    assert par.plaintext_context().moduli == opar.plaintext_context.moduli
+    sk = obfv.SecretKey.random(opar, rng)
+    t = opar.plaintext
+    for level in (0, 1):
+        s_ntt = x.to(arr(sk._s(opar.ctx[level])))
+        vals = [[rng.randrange(t) for _ in range(n)] for _ in range(3)]
+        cts = [sk.encrypt(v, rng, level) for v in vals]
+        got = x.back(par.decrypt(s_ntt, x.to(np.stack([ct_arr(c) for c in cts])), level))
+        for g, v, c in zip(got, vals, cts):
+            assert g.tolist() == sk.decrypt(c) == v
+        prod = cts[0].mul(cts[1])                               # 3 parts: phase uses s^2
+        got3 = x.back(par.decrypt(s_ntt, x.to(ct_arr(prod)), level))
+        assert got3.tolist() == sk.decrypt(prod)
 
 
 def case_errors(fhe):

@@ -115,6 +115,11 @@ def test_expand(fhe, dev):
 
 
 @pytest.mark.parametrize("dev", [False, True])
+def test_decrypt(fhe, dev):
+    cases.case_decrypt(fhe, dev)
+
+
+@pytest.mark.parametrize("dev", [False, True])
 def test_wire_format(fhe, dev):
     cases.case_wire_format(fhe, dev)
     cases.case_wire_format(fhe, dev, n=8192)

@@ -705,42 +705,22 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
 #undef FHE_KS_CASE
         return;
     }
-    // Unfused path for rows that do not fit LDS: per digit, lift + NTT into scratch, then MAC.
-    const u64 kstride = (u64)kc.L * kc.n;
-    WsGuard t(npolys * kstride * sizeof(u64), s);
-    WsGuard dig(k_.log_base ? npolys * kc.n * sizeof(u64) : 8, s);
-    const u64 total = (u64)npolys * kstride;
-    for (size_t i = 0; i < k_.ndigits; i++) {
-        k::RowMap m{};
-        m.rows = (uint32_t)kc.L;
-        m.row_begin = 0;
-        m.mod_offset = 0;
-        m.dst_poly_stride = kstride;
-        const u64 *src = p;
-        if (k_.log_base) {
-            const u64 tot1 = (u64)npolys * kc.n;
-            require(p_stride == kc.n, E_ARG, "decomposition key switch expects contiguous single-row input");
-            FHE_LAUNCH("digit", k::digit_kernel, dim3(blocks_for(tot1, EW_THREADS)), dim3(EW_THREADS), 0, s, p,
-                       dig.u(), (uint32_t)(i * k_.log_base), (uint32_t)k_.log_base, tot1);
-            src = dig.u();
-            m.src_row_fixed = 0;
-            m.src_poly_stride = kc.n;
-        } else {
-            m.src_row_fixed = (int32_t)i;
-            m.src_poly_stride = p_stride;
-        }
-        launch_ntt(kc, false, src, t.u(), m, npolys, k::PRO_REDUCE, s);
-        FHE_LAUNCH("key_switch_mac", k::ks_mac_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s,
-                   t.u(), o0, o1, out_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), (uint32_t)kc.logn,
-                   (uint32_t)kc.L, (uint32_t)i, i == 0 ? 1u : 0u, total);
+    // Rows larger than LDS (N >= 32768): one workgroup per 8192-point sub-block, the first
+    // logn - 13 stages folded into its loader (ks_fused_split_kernel).
+    const size_t lds = (k::lds_words(8192) + 8192) * sizeof(u64);
+#define FHE_KS_SPLIT_CASE(G0)                                                                                      \
+    case 13 + G0:                                                                                                  \
+        allow_big_lds(k::ks_fused_split_kernel<G0>, lds);                                                          \
+        FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0>), dim3((unsigned)((npolys * kc.L) << G0)),    \
+                   dim3(1024), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p,       \
+                   k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,                  \
+                   (uint32_t)k_.log_base);                                                                         \
+        break;
+    switch (kc.logn) {
+        FHE_KS_SPLIT_CASE(2) FHE_KS_SPLIT_CASE(3)
+        default: throw StatusError(E_ARG, "unsupported key-switch row size");
     }
-    if (a0 || a1) {
-        // out += addend, one polynomial at a time (strides may differ)
-        for (size_t i = 0; i < npolys; i++) {
-            if (a0) ew_op(kc, o0 + i * out_stride, a0 + i * a_stride, 1, k::EW_ADD, s);
-            if (a1) ew_op(kc, o1 + i * out_stride, a1 + i * a_stride, 1, k::EW_ADD, s);
-        }
-    }
+#undef FHE_KS_SPLIT_CASE
 }
 
 // switch_down_to (M/rq/mod.rs:498-507) for Ntt polys living over `from`, `iters` times:

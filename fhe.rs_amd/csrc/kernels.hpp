@@ -11,7 +11,7 @@
 //   ntt_global_kernel<..>   first/last radix stages for N > 16384   (row does not fit LDS)
 //   ks_fused_kernel         KeySwitchingKey::key_switch             F/bfv/keys/key_switching_key.rs:241-320
 //                           (+ lazy lift M/rq/mod.rs:563-586 + Shoup MAC M/rq/ops.rs:208-245)
-//   ks_mac_kernel           unfused MAC step of the same (N > 16384)
+//   ks_fused_split_kernel   the same for N >= 32768: per 8192-point sub-block, first stages in the loader
 //   scale_kernel            RnsScaler::scale per column             M/rns/scaler.rs:249-352, M/rq/scaler.rs:85-94
 //   switch_down_kernel      Poly::switch_down                       M/rq/mod.rs:433-492
 //   substitute_kernel       Poly::substitute                        M/rq/mod.rs:360-412
@@ -96,12 +96,12 @@ __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) {
 // key switch: 8 per thread (leaves registers for the two accumulator sets).
 constexpr int ntt_threads_c(int logm) { return (1 << logm) / 16 > 64 ? ((1 << logm) / 16 > 1024 ? 1024 : (1 << logm) / 16) : 64; }
 constexpr int KS_GMAX = 3;  // radix-8 passes inside the key switch: room for the accumulators
-// fused key switch: c1 accumulators in LDS (see ks_fused_kernel) exactly when a thread is capped at 128 VGPRs
-// and the row tile leaves room for them
-constexpr bool ks_acc1_in_lds_c(int logn) { return logn == 13; }
 constexpr int ks_threads_c(int logn) { return (1 << logn) / 8 > 64 ? ((1 << logn) / 8 > 1024 ? 1024 : (1 << logn) / 8) : 64; }
 // 16-byte chunks per thread (0: tile smaller than one chunk per thread -> scalar loop)
 constexpr int tile_chunks_c(int logm, int threads) { return (1 << logm) >= 2 * threads ? (1 << logm) / (2 * threads) : 0; }
+// fused key switch: the c1 accumulators live in LDS behind the row tile (and the next digit's row is
+// prefetched into the registers this frees) whenever the tile leaves room, i.e. up to N = 8192
+constexpr bool ks_acc1_in_lds_c(int logn) { return logn <= 13 && tile_chunks_c(logn, ks_threads_c(logn)) > 0; }
 // pass plan: NP = ceil(LOGM / GMAX) passes of BASE or BASE+1 stages
 constexpr int plan_np(int logm, int gmax) { return (logm + gmax - 1) / gmax; }
 constexpr int plan_base(int logm, int gmax) { return logm / plan_np(logm, gmax); }
@@ -522,15 +522,44 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
 #pragma unroll
         for (int e = 0; e < NE; e++) acc1[e] = 0;
     }
+    // digit_shift_bits == 0: digit i is residue row i of p (RNS decomposition, :256-268).
+    // otherwise: base-2^bits digits of the single row 0 (key_switch_decomposition, :323-362).
+    const u64 *const src0 = pin + (u64)b * src_poly_stride;
+    const u64 dstride = digit_shift_bits ? 0 : (u64)N;
+    const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+    // The workgroup is alone on its CU (LDS), so nothing else hides the row load: digit i+1's
+    // row is fetched into registers while digit i goes through its passes.
+    constexpr bool PREFETCH = ks_acc1_in_lds_c(LOGN);   // (needs the VGPRs the LDS accumulators free)
+    u64x2 pre[PREFETCH ? CH : 1];
+    if constexpr (PREFETCH) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) pre[c] = reinterpret_cast<const u64x2 *>(src0)[c * T + tid0];
+    }
     for (uint32_t i = 0; i < ndigits; i++) {
         const uint32_t tid = opaque(tid0);
-        // digit_shift_bits == 0: digit i is residue row i of p (RNS decomposition, :256-268).
-        // otherwise: base-2^bits digits of the single row 0 (key_switch_decomposition, :323-362).
-        const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N);
         const uint32_t sh = i * digit_shift_bits;
-        const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
-        tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return reduce_u64((v >> sh) & mask, md); });
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t e = 2 * (c * T + tid);
+                lds[padi(e)] = reduce_u64((pre[c].x >> sh) & mask, md);
+                lds[padi(e + 1)] = reduce_u64((pre[c].y >> sh) & mask, md);
+            }
+        } else {
+            // (address and mask are recomputed per digit on purpose: hoisted, they cost VGPRs that the
+            // N = 16384 variant does not have)
+            const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N);
+            const u64 mask_i = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+            tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return reduce_u64((v >> sh) & mask_i, md); });
+        }
         __syncthreads();
+        if constexpr (PREFETCH) {
+            if (i + 1 < ndigits) {
+                const u64x2 *nx = reinterpret_cast<const u64x2 *>(src0 + (u64)(i + 1) * dstride);
+#pragma unroll
+                for (int c = 0; c < CH; c++) pre[c] = nx[c * T + tid];
+            }
+        }
         ntt_fwd_lds<LOGN, T, KS_GMAX>(lds, twr, 1, pm, tid);
         const u64 koff = ((u64)i * lk + j) * N;
         if constexpr (CH > 0) {
@@ -599,37 +628,120 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     }
 }
 
-// Unfused MAC step (used when the row does not fit LDS): t is NTT(lift(p_i)) [b][lk][N]
-// canonical; out (+)= t (.) key_i.  first != 0 initialises the accumulators.
-__global__ void ks_mac_kernel(const u64 *__restrict__ t, u64 *__restrict__ out0, u64 *__restrict__ out1,
-                              u64 out_poly_stride, const u64 *__restrict__ k0, const u64 *__restrict__ k0s,
-                              const u64 *__restrict__ k1, const u64 *__restrict__ k1s,
-                              const DevMod *__restrict__ mods, uint32_t logn, uint32_t lk, uint32_t digit,
-                              uint32_t first, u64 total) {
-    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const uint32_t n = 1u << logn;
-    const uint32_t x = (uint32_t)(gid & (n - 1));
-    const uint32_t j = (uint32_t)((gid >> logn) % lk);
-    const u64 b = (gid >> logn) / lk;
-    const u64 p = mods[j].p;
-    const u64 koff = ((u64)digit * lk + j) * n + x;
-    const u64 ooff = b * out_poly_stride + (u64)j * n + x;
-    const u64 v = t[gid];
-    u64 r0 = mul_shoup(v, k0[koff], k0s[koff], p), r1 = mul_shoup(v, k1[koff], k1s[koff], p);
-    if (!first) {
-        r0 = add_mod(r0, out0[ooff], p);
-        r1 = add_mod(r1, out1[ooff], p);
+// The same for rows that do not fit LDS (N = 2^(13+G0) >= 32768): one workgroup per (ciphertext,
+// key modulus j, 8192-point sub-block).  The first G0 Cooley-Tukey stages (native.rs:142-175,
+// blocks larger than the tile) are folded into the loader: coefficient e of sub-block `sub`
+// depends on the 2^G0 source coefficients e + k*8192 through G0 butterflies of which only the
+// branch leading to `sub` is evaluated (2^G0 - 1 Shoup multiplications per coefficient instead
+// of G0/2 amortised, but no round trip of the lifted row through HBM); the remaining 13 stages
+// run in LDS with twiddle base 2^G0 + sub, exactly like ntt_kernel's sub-block mode.
+template <int G0>
+__global__ void __launch_bounds__(1024, 4)
+    ks_fused_split_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0,
+                          u64 *__restrict__ out1, u64 out_poly_stride, const u64 *__restrict__ addend0,
+                          const u64 *__restrict__ addend1, u64 addend_poly_stride, const u64 *__restrict__ k0,
+                          const u64 *__restrict__ k0s, const u64 *__restrict__ k1, const u64 *__restrict__ k1s,
+                          const DevMod *__restrict__ mods, const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk,
+                          uint32_t digit_shift_bits) {
+    FHE_DYN_SMEM(u64, lds);
+    constexpr int LOGM = 13, M = 1 << LOGM, T = 1024, CH = M / (2 * T), NS = 1 << G0;
+    constexpr u64 N = (u64)M << G0;
+    const uint32_t tid0 = threadIdx.x;
+    const uint32_t sub = blockIdx.x & (NS - 1);
+    const uint32_t bj = blockIdx.x >> G0;
+    const uint32_t b = to_sgpr(bj / lk), j = bj - b * lk;
+    const DevMod md = mods[j];
+    const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
+    const u64x2 *twr = tw + (u64)j * N;
+    u64 acc0[2 * CH];
+    u64x2 *const acc1_lds = reinterpret_cast<u64x2 *>(lds + lds_words(M));
+#pragma unroll
+    for (int e = 0; e < 2 * CH; e++) acc0[e] = 0;
+#pragma unroll
+    for (int c = 0; c < CH; c++) acc1_lds[c * T + tid0] = u64x2{0, 0};
+    for (uint32_t i = 0; i < ndigits; i++) {
+        const uint32_t tid = opaque(tid0);
+        const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N);
+        const uint32_t sh = i * digit_shift_bits;
+        const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t ci = c * T + tid;
+            u64x2 v[NS];
+#pragma unroll
+            for (int k = 0; k < NS; k++) v[k] = reinterpret_cast<const u64x2 *>(src + (u64)k * M)[ci];
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                v[k].x = reduce_u64((v[k].x >> sh) & mask, md);
+                v[k].y = reduce_u64((v[k].y >> sh) & mask, md);
+            }
+            // stage s keeps the half of the pairs whose output leads to `sub`
+#pragma unroll
+            for (int st = 0; st < G0; st++) {
+                const int half = NS >> (st + 1);
+                const u64x2 w = twr[(1u << st) + (sub >> (G0 - st))];
+                const bool minus = (sub >> (G0 - st - 1)) & 1;
+#pragma unroll
+                for (int m = 0; m < half; m++) {
+                    const u64 lx = csub_n(v[m].x, p2, pm.np2), ly = csub_n(v[m].y, p2, pm.np2);
+                    const u64 tx = mul_shoup_lazy_n(v[m + half].x, w.x, w.y, pm.np);
+                    const u64 ty = mul_shoup_lazy_n(v[m + half].y, w.x, w.y, pm.np);
+                    v[m].x = minus ? lx + p2 - tx : lx + tx;
+                    v[m].y = minus ? ly + p2 - ty : ly + ty;
+                }
+            }
+            lds[padi(2 * ci)] = v[0].x;
+            lds[padi(2 * ci + 1)] = v[0].y;
+        }
+        __syncthreads();
+        ntt_fwd_lds<LOGM, T, KS_GMAX>(lds, twr, NS + sub, pm, tid);
+        const u64 koff = ((u64)i * lk + j) * N + (u64)sub * M;
+        const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
+        const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t ci = c * T + tid;
+            const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+            const u64 vx = lds[padi(2 * ci)], vy = lds[padi(2 * ci + 1)];
+            acc0[2 * c] = csub_n(acc0[2 * c] + mul_shoup_lazy_n(vx, q0.x, q0s.x, pm.np), p2, pm.np2);
+            acc0[2 * c + 1] = csub_n(acc0[2 * c + 1] + mul_shoup_lazy_n(vy, q0.y, q0s.y, pm.np), p2, pm.np2);
+            u64x2 a = acc1_lds[ci];
+            a.x = csub_n(a.x + mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np), p2, pm.np2);
+            a.y = csub_n(a.y + mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np), p2, pm.np2);
+            acc1_lds[ci] = a;
+            if (c & 1) sched_fence();
+        }
+        __syncthreads();
     }
-    out0[ooff] = r0;
-    out1[ooff] = r1;
-}
-
-// Base-2^bits digit extraction for the unfused decomposition path.
-__global__ void digit_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, uint32_t shift, uint32_t bits,
-                             u64 total) {
-    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < total) out[gid] = (in[gid] >> shift) & ((1ull << bits) - 1);
+    const uint32_t tid = opaque(tid0);
+    const u64 ooff = (u64)b * out_poly_stride + (u64)j * N + (u64)sub * M;
+    const u64 aoff = (u64)b * addend_poly_stride + (u64)j * N + (u64)sub * M;
+    u64x2 *o0 = reinterpret_cast<u64x2 *>(out0 + ooff), *o1 = reinterpret_cast<u64x2 *>(out1 + ooff);
+    const u64x2 *d0 = reinterpret_cast<const u64x2 *>(addend0 ? addend0 + aoff : nullptr);
+    const u64x2 *d1 = reinterpret_cast<const u64x2 *>(addend1 ? addend1 + aoff : nullptr);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t ci = c * T + tid;
+        u64x2 r0, r1;
+        r0.x = csub_n(acc0[2 * c], p, pm.np);
+        r0.y = csub_n(acc0[2 * c + 1], p, pm.np);
+        const u64x2 a1v = acc1_lds[ci];
+        r1.x = csub_n(a1v.x, p, pm.np);
+        r1.y = csub_n(a1v.y, p, pm.np);
+        if (d0) {
+            const u64x2 a = d0[ci];
+            r0.x = add_mod_n(r0.x, a.x, pm);
+            r0.y = add_mod_n(r0.y, a.y, pm);
+        }
+        if (d1) {
+            const u64x2 a = d1[ci];
+            r1.x = add_mod_n(r1.x, a.x, pm);
+            r1.y = add_mod_n(r1.y, a.y, pm);
+        }
+        o0[ci] = r0;
+        o1[ci] = r1;
+    }
 }
 
 // ------------------------------------------------------------------ RNS scaler ----

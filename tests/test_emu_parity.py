@@ -115,14 +115,17 @@ def test_errors(fhe):
     cases.case_errors(fhe)
 
 
-def test_key_switch_n8192_lds_accumulators(fhe):
-    """N = 8192: the fused key switch keeps its c1 accumulators in LDS behind the row tile
-    (1024 threads x 128 VGPRs do not hold both sets); synthetic key and input vs the C oracle."""
+@pytest.mark.parametrize("n", [8192, 16384, 32768, 65536])
+def test_key_switch_large_rows(fhe, n):
+    """N = 8192: the fused key switch keeps its c1 accumulators in LDS behind the row tile and
+    prefetches the next digit; N = 16384: both accumulator sets in registers; N >= 32768: one
+    workgroup per 8192-point sub-block with the first stages folded into the loader
+    (ks_fused_split_kernel).  Synthetic key and input vs the C oracle."""
     import numpy as np
     from fhe_oracle import bfv as obfv, coracle
     from fhe_oracle.rq import Context as OCtx
     import full_size
-    n, seed = 8192, 0xF4E50077
+    seed = 0xF4E50077
     q = obfv.generate_moduli([60, 60], n)
     cc = coracle.CCtx(OCtx(q, n))
     ck = full_size.host_key(cc, seed, len(q))

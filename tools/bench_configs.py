@@ -45,7 +45,7 @@ def c3(batch=512):
                            ("C3 rotate rows e=2N-1", lambda: gkr.relinearize(ct2), 2 * L + L * L + 3 * L)):
         ms = timeit(fn)
         print(json.dumps(dict(name=name, batch=batch, ms=round(ms, 3), ops_per_s=round(batch / ms * 1e3, 1),
-                              stage_model_GBps=round(batch * rows * R / ms / 1e6, 1))))
+                              stage_model_GBps=round(batch * rows * R / ms / 1e6, 1), kernels=breakdown(fn))))
 
 
 def c5(batch=16, levels=2):
@@ -63,7 +63,20 @@ def c5(batch=16, levels=2):
         rows = 22 * K + 7 * Ll + Ll * Ll + 4 * Ll + 12 * Ll - 6
         print(json.dumps(dict(name=f"C5 multiply+relin+modswitch level {level} (n=32768, L={Ll}, K={K})", batch=batch,
                               ms=round(ms, 3), ops_per_s=round(batch / ms * 1e3, 1),
-                              stage_model_GBps=round(batch * rows * 8 * n / ms / 1e6, 1))))
+                              stage_model_GBps=round(batch * rows * 8 * n / ms / 1e6, 1),
+                              kernels=breakdown(lambda: m.multiply(a, b)) if level == 0 else None)))
+
+
+def breakdown(fn):
+    """Per-kernel HIP-event times (ms) of one call (the library's own profiler)."""
+    fn()
+    torch.cuda.synchronize()
+    fhe.prof_reset()
+    fhe.prof_enable(True)
+    fn()
+    torch.cuda.synchronize()
+    fhe.prof_enable(False)
+    return {k: dict(launches=v[0], ms=round(v[1], 3)) for k, v in sorted(fhe.prof_report().items())}
 
 
 if __name__ == "__main__":

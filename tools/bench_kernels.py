@@ -47,6 +47,13 @@ def main():
         res.append(dict(tag=tag, name=name, ms=round(ms, 4), GBps=round(alg_bytes / ms / 1e6, 1),
                         rate=round(units / ms * 1e3, 1), unit=unit_name))
 
+    # measured HBM ceiling on this box (report fractions against nominal AND measured):
+    # device-to-device copy of 2 GiB, read + write bytes counted
+    src = torch.empty(1 << 28, dtype=torch.int64, device="cuda")
+    dst = torch.empty_like(src)
+    ms = timeit(lambda: dst.copy_(src))
+    rec("hbm ceiling: D2D copy 2 GiB (read+write)", ms, 2 * src.numel() * 8, src.numel() * 8, "B copied/s")
+    del src, dst
     ms = timeit(lambda: ctx.ntt_forward(x))
     rec("ntt_forward [B,2,4,8192]", ms, rows * 2 * R, rows, "row-NTT/s")
     ms = timeit(lambda: ctx.ntt_backward(x))

@@ -55,7 +55,7 @@ def host_key(cctx, seed, ndigits):
     return coracle.CKsk(c0, c0s, c1, c1s, cctx, cctx)
 
 
-def check_mul(fhe, n, sizes, batch, relin, cfg, sample=None):
+def check_mul(fhe, n, sizes, batch, relin, cfg, sample=None, mod_switch=False):
     import torch
     q = obfv.generate_moduli(sizes, n)
     t = plaintext_modulus(n)
@@ -70,12 +70,12 @@ def check_mul(fhe, n, sizes, batch, relin, cfg, sample=None):
         c0, c1 = device_key(ctx, seed, len(q))
         rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1))
         crk = host_key(o["cb"], seed, len(q))
-    m = fhe.Multiplicator.default(par, rk, 0)
+    m = fhe.Multiplicator.default(par, rk, 0, mod_switch)
     lhs = ctx.synth_uniform(seed, 0, 0, 2, batch)
     rhs = ctx.synth_uniform(seed, 0, 2, 2, batch)
     out = m.multiply(lhs, rhs)
     torch.cuda.synchronize()
-    cm = coracle.CMul(o["cb"], o["cm"], o["cel"], o["cel"], o["cdn"], crk, False)
+    cm = coracle.CMul(o["cb"], o["cm"], o["cel"], o["cel"], o["cdn"], crk, mod_switch)
     for i in (sample or range(batch)):
         l = np.stack([o["cb"].synth_poly(seed, i, 0), o["cb"].synth_poly(seed, i, 1)])
         r = np.stack([o["cb"].synth_poly(seed, i, 2), o["cb"].synth_poly(seed, i, 3)])
@@ -136,7 +136,7 @@ def check_relin_rotate(fhe, n, sizes, batch, cfg):
     got = fhe.RelinearizationKey(ksk).relinearizes(ct3)
     rots = {e: fhe.GaloisKey(ksk, e).relinearize(ct3[:, :2].contiguous()) for e in (3, 2 * n - 1)}
     torch.cuda.synchronize()
-    for i in (0, batch - 1):
+    for i in sorted({0, batch - 1}):
         parts = [cc.synth_poly(seed, i, p) for p in range(3)]
         k0, k1 = ck.key_switch(cc.poly_ntt_backward(parts[2]))
         want = np.stack([cc.poly_add(parts[0], k0), cc.poly_add(parts[1], k1)])
@@ -172,3 +172,25 @@ def check_chain(fhe, n, sizes, batch, levels, cfg):
             r = np.stack([o["cb"].synth_poly(seed + level, i, 2), o["cb"].synth_poly(seed + level, i, 3)])
             want[i] = cm.multiply(want[i], r)
             assert np.array_equal(u64(cur[i]), want[i]), f"level {level} ciphertext {i}"
+
+
+def random_shape(idx):
+    """A deterministic 'random' parameter shape: degree, modulus sizes (mixed widths), batch."""
+    import random
+    rng = random.Random(0xC0FFEE + idx)
+    n = 1 << rng.randrange(5, 15)
+    L = rng.randrange(1, 7)
+    sizes = [rng.choice([36, 45, 50, 54, 58, 60, 61, 62]) for _ in range(L)]
+    batch = rng.randrange(1, 6)
+    return n, sizes, batch
+
+
+def check_random_shape(fhe, idx):
+    """Multiply (+relinearise, +modulus switch when the chain allows), relinearise and rotations on
+    a pseudo-random parameter shape, every ciphertext against the C oracle."""
+    n, sizes, batch = random_shape(idx)
+    cfg = 100 + idx
+    L = len(sizes)
+    check_mul(fhe, n, sizes, batch, relin=L >= 2, cfg=cfg, mod_switch=L >= 2 and idx % 2 == 0)
+    if L >= 2:
+        check_relin_rotate(fhe, n, sizes, batch, cfg)

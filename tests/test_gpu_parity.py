@@ -210,3 +210,11 @@ def test_concurrent_streams_share_handles(fhe):
     assert not errs, errs
     for i in range(4):
         assert torch.equal(got[i], want[i])
+
+
+@pytest.mark.parametrize("idx", range(48))
+def test_random_parameter_shapes(fhe, idx):
+    """Sweep of degrees 32..16384, 1..6 moduli of mixed widths (36..62 bits), small ragged batches:
+    ct x ct (+relinearise, +mod switch), relinearise, rotations -- bit-exact vs the C oracle."""
+    import full_size
+    full_size.check_random_shape(fhe, idx)

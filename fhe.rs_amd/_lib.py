@@ -97,6 +97,8 @@ SIGNATURES = {
     "fhe_mul_out_shape": (i32, [vp, szp, szp]),
     "fhe_bfv_mul": (i32, [vp, u64p, u64p, u64p, sz]),
     "fhe_bfv_mul_dev": (i32, [vp, vp, vp, vp, sz, vp]),
+    "fhe_bfv_tensor": (i32, [vp, sz, sz, u64p, u64p, u64p, sz]),
+    "fhe_bfv_tensor_dev": (i32, [vp, sz, sz, vp, vp, vp, sz, vp]),
     "fhe_params_create": (i32, [i32, sz, sz, u64p, u64, C.POINTER(vp)]),
     "fhe_params_destroy": (None, [vp]),
     "fhe_params_max_level": (sz, [vp]),

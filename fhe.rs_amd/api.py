@@ -700,6 +700,26 @@ class Multiplicator:
         check(L.fhe_bfv_mul(self._h, _ptr(x), _ptr(y), _ptr(out), b))
         return out
 
+    def tensor(self, lhs, rhs):
+        """`&ct * &ct` (ops/mod.rs:259-358) for any number of parts: lhs [..., la, L, N], rhs [..., lb, L, N]
+        -> [..., la + lb - 1, L, N]; no relinearisation."""
+        L = _lib.lib()
+        if tuple(lhs.shape[:-3]) != tuple(rhs.shape[:-3]) or tuple(lhs.shape[-2:]) != tuple(rhs.shape[-2:]):
+            raise FheError(-11, "ParameterMismatch: operands of different batch shape or level")
+        la, lb = int(lhs.shape[-3]), int(rhs.shape[-3])
+        b = 1
+        for d in lhs.shape[:-3]:
+            b *= d
+        oshape = tuple(lhs.shape[:-3]) + (la + lb - 1,) + tuple(lhs.shape[-2:])
+        if _is_dev(lhs):
+            out = torch.empty(oshape, dtype=lhs.dtype, device=lhs.device)
+            check(L.fhe_bfv_tensor_dev(self._h, la, lb, _dptr(lhs), _dptr(rhs), _dptr(out), b, _stream()))
+            return out
+        x, y = _np(lhs), _np(rhs)
+        out = np.zeros(oshape, dtype=np.uint64)
+        check(L.fhe_bfv_tensor(self._h, la, lb, _ptr(x), _ptr(y), _ptr(out), b))
+        return out
+
 
 # ---- zq::primes (host) ---------------------------------------------------------------------
 def generate_prime(num_bits, modulo, upper_bound):

@@ -954,6 +954,31 @@ inline void bfv_switch_down(const Ctx &c, size_t nparts, const u64 *ct, u64 *out
 }
 
 // Multiplicator::multiply (F/bfv/ops/mul.rs:165-243) on `batch` ciphertext pairs.
+// `&ct * &ct` with any number of parts (F/bfv/ops/mod.rs:259-358), the generic (unfused) pipeline:
+// lhs [batch][la][L][N], rhs [batch][lb][L][N] -> out [batch][la+lb-1][L][N], all Ntt.
+inline void bfv_tensor(const Mul &m, size_t la, size_t lb, const u64 *lhs, const u64 *rhs, u64 *out, size_t batch,
+                       hipStream_t s) {
+    const Ctx &b = *m.base, &e = *m.mulc;
+    b.need_device();
+    require(la >= 1 && lb >= 1, E_MUL_POLY_COUNT, "a ciphertext has at least one part");
+    if (!batch) return;
+    const u64 PL = (u64)b.L * b.n, PK = (u64)e.L * e.n;
+    const size_t lo = la + lb - 1;
+    // bound the workspace like bfv_mul does: chunks of ciphertext pairs
+    const size_t per_pair = (la + lb + lo) * PK * sizeof(u64);
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>({batch, (size_t)32768, ((size_t)8 << 30) / per_pair}));
+    WsGuard ea(chunk * la * PK * sizeof(u64), s), eb(chunk * lb * PK * sizeof(u64), s), ten(chunk * lo * PK * sizeof(u64), s);
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = std::min(chunk, batch - b0);
+        scale_polys(*m.ext_lhs, lhs + b0 * la * PL, ea.u(), nb * la, true, s);
+        scale_polys(*m.ext_rhs, rhs + b0 * lb * PL, eb.u(), nb * lb, true, s);
+        FHE_LAUNCH("tensor_general", k::tensor_general_kernel, dim3(blocks_for(PK, EW_THREADS), (unsigned)lo, (unsigned)nb),
+                   dim3(EW_THREADS), 0, s, ea.u(), eb.u(), ten.u(), e.dmods(), (uint32_t)la, (uint32_t)lb,
+                   (uint32_t)e.logn, PK);
+        scale_polys(*m.down, ten.u(), out + b0 * lo * PL, nb * lo, true, s);
+    }
+}
+
 // Workspace per chunk of nb pairs (all slot-major so that every step is ONE launch over
 // nb * {2,3} polynomials):  extL/extR [nb][2][K][N] extended operands,  ten [3][nb][K][N]
 // tensor,  d [3][nb][L][N] down-scaled parts (c0, c1 Ntt; c2 PowerBasis for the key switch).

@@ -1092,6 +1092,44 @@ fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rh
     });
 }
 
+fhe_status fhe_bfv_tensor_dev(const fhe_mul *m, size_t lhs_parts, size_t rhs_parts, const uint64_t *lhs,
+                              const uint64_t *rhs, uint64_t *out, size_t batch, void *stream) {
+    return guard([&] {
+        need(m, "mul");
+        if (batch) {
+            need(lhs, "lhs");
+            need(rhs, "rhs");
+            need(out, "out");
+        }
+        const Mul &mm = *m->m;
+        mm.base->need_device();
+        set_device(*mm.base);
+        bfv_tensor(mm, lhs_parts, rhs_parts, lhs, rhs, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_tensor(const fhe_mul *m, size_t lhs_parts, size_t rhs_parts, const uint64_t *lhs, const uint64_t *rhs,
+                          uint64_t *out, size_t batch) {
+    return guard([&] {
+        need(m, "mul");
+        if (batch) {
+            need(lhs, "lhs");
+            need(rhs, "rhs");
+            need(out, "out");
+        }
+        if (lhs_parts < 1 || rhs_parts < 1)
+            throw StatusError(FHE_E_MUL_POLY_COUNT, "a ciphertext has at least one part");
+        const Mul &mm = *m->m;
+        mm.base->need_device();
+        set_device(*mm.base);
+        const size_t pe = mm.base->L * mm.base->n, lo = lhs_parts + rhs_parts - 1;
+        HostIO io;
+        u64 *dl = io.in(lhs, batch * lhs_parts * pe), *dr = io.in(rhs, batch * rhs_parts * pe);
+        u64 *dout = io.out(batch * lo * pe);
+        bfv_tensor(mm, lhs_parts, rhs_parts, dl, dr, dout, batch, nullptr);
+        io.back(out, dout, batch * lo * pe);
+    });
+}
+
 // -------------------------------------------------------------------------- params ----
 fhe_status fhe_params_create(int device, size_t degree, size_t nmoduli, const uint64_t *moduli,
                              uint64_t plaintext_modulus, fhe_params **out) {

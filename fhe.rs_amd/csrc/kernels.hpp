@@ -1029,6 +1029,23 @@ __global__ void dot_kernel(const u64 *__restrict__ cts, u64 ct_batch_stride, con
     }
 }
 
+// General tensor step of `&ct * &ct` (F/bfv/ops/mod.rs:300-327): out[b][k] = sum_{i+j=k} a[b][i] (.) b[b][j];
+// grid = (ceil(pl / block), la + lb - 1, batch).
+__global__ void tensor_general_kernel(const u64 *__restrict__ a, const u64 *__restrict__ bb, u64 *__restrict__ out,
+                                      const DevMod *__restrict__ mods, uint32_t la, uint32_t lb, uint32_t logn, u64 pl) {
+    const u64 off = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (off >= pl) return;
+    const uint32_t kk = blockIdx.y, b = blockIdx.z;
+    const DevMod m = mods[off >> logn];
+    const u64 *pa = a + (u64)b * la * pl + off, *pb = bb + (u64)b * lb * pl + off;
+    u64 acc = 0;
+    for (uint32_t i = 0; i < la; i++) {
+        if (kk < i || kk - i >= lb) continue;
+        acc = add_mod(acc, mul_mod(pa[(u64)i * pl], pb[(u64)(kk - i) * pl], m), m.p);
+    }
+    out[((u64)b * (la + lb - 1) + kk) * pl + off] = acc;
+}
+
 // `Ciphertext * Plaintext` (F/bfv/ops/mod.rs:229-257): out[b][part] = ct[b][part] (.) pt[b].
 __global__ void mul_plain_kernel(const u64 *__restrict__ ct, const u64 *__restrict__ pt, u64 pt_batch_stride,
                                  u64 *__restrict__ out, const DevMod *__restrict__ mods, uint32_t nparts, uint32_t logn,

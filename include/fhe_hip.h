@@ -278,6 +278,15 @@ fhe_status fhe_mul_out_shape(const fhe_mul *m, size_t *parts, size_t *rows);
 fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out, size_t batch);
 fhe_status fhe_bfv_mul_dev(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out,
                            size_t batch, void *stream);
+/* `Mul<&Ciphertext> for &Ciphertext` with any number of parts (F/bfv/ops/mod.rs:259-358; the squaring branch
+ * computes the same values): extend every part, c[k] = sum_{i+j=k} lhs[i] (.) rhs[j] over the multiplication
+ * basis, scale every c[k] down; never relinearises (the handle's key and mod-switch flag are ignored).
+ * lhs [batch][lhs_parts][L][N], rhs [batch][rhs_parts][L][N] Ntt -> out [batch][lhs_parts+rhs_parts-1][L][N] Ntt.
+ * (fhe_bfv_mul is the 2 x 2 case on its fused pipeline and is what Multiplicator::multiply accepts.) */
+fhe_status fhe_bfv_tensor(const fhe_mul *m, size_t lhs_parts, size_t rhs_parts, const uint64_t *lhs, const uint64_t *rhs,
+                          uint64_t *out, size_t batch);
+fhe_status fhe_bfv_tensor_dev(const fhe_mul *m, size_t lhs_parts, size_t rhs_parts, const uint64_t *lhs,
+                              const uint64_t *rhs, uint64_t *out, size_t batch, void *stream);
 
 /* ------------------------------------------------------------- BfvParameters ---- */
 /* BfvParametersBuilder::build (F/bfv/parameters.rs:560-738), the part that defines device

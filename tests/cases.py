@@ -576,6 +576,36 @@ def case_decrypt(fhe, dev, n=16, nmod=3):
         assert got3.tolist() == sk.decrypt(prod)
 
 
+def case_tensor_any_parts(fhe, dev, n=16, nmod=3):
+    """ops/mod.rs:259-358: `&ct * &ct` for 1-, 2- and 3-part operands (incl. the squaring branch,
+    which computes the same values); results equal the oracle and decrypt to the product."""
+    x = Xfer(dev)
+    rng = random.Random(37)
+    opar, par = _params(fhe, nmod, n)
+    sk = obfv.SecretKey.random(opar, rng)
+    t = opar.plaintext
+    m = fhe.Multiplicator.default(par, None, 0)
+    va, vb, vc = ([rng.randrange(t) for _ in range(n)] for _ in range(3))
+    A, B, C = (sk.encrypt(v, rng, 0) for v in (va, vb, vc))
+    AB = A.mul(B)                                                     # 3 parts
+    one = obfv.Ciphertext(opar, [A.c[0]], 0)                          # 1 part
+    for lhs, rhs in ((A, B), (AB, C), (C, AB), (AB, AB), (A, A), (one, B), (one, one)):
+        want = lhs.mul(rhs)
+        got = x.back(m.tensor(x.to(ct_arr(lhs)[None]), x.to(ct_arr(rhs)[None])))[0]
+        assert got.shape[0] == len(lhs) + len(rhs) - 1
+        assert np.array_equal(got, ct_arr(want)), (len(lhs), len(rhs))
+    # batched, and the 2 x 2 case agrees with the fused Multiplicator pipeline
+    l2 = x.to(np.stack([ct_arr(A), ct_arr(B)]))
+    r2 = x.to(np.stack([ct_arr(B), ct_arr(C)]))
+    assert np.array_equal(x.back(m.tensor(l2, r2)), x.back(m.multiply(l2, r2)))
+    # (a * b) * c decrypts to the triple product (4 parts, phase uses s^3)
+    ABC = AB.mul(C)
+    got = x.back(m.tensor(x.to(ct_arr(AB)[None]), x.to(ct_arr(C)[None])))[0]
+    assert np.array_equal(got, ct_arr(ABC))
+    s_ntt = x.to(arr(sk._s(opar.ctx[0])))
+    assert x.back(par.decrypt(s_ntt, x.to(got), 0)).tolist() == sk.decrypt(ABC)
+
+
 def case_errors(fhe):
     """Error conventions (include/fhe_hip.h status codes <-> fhe_math::Error variants)."""
     def code(fn):

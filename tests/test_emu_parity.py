@@ -107,6 +107,10 @@ def test_wire_format(fhe):
     cases.case_wire_format(fhe, False)
 
 
+def test_tensor_any_parts(fhe):
+    cases.case_tensor_any_parts(fhe, False)
+
+
 def test_decrypt(fhe):
     cases.case_decrypt(fhe, False)
 

@@ -115,6 +115,11 @@ def test_expand(fhe, dev):
 
 
 @pytest.mark.parametrize("dev", [False, True])
+def test_tensor_any_parts(fhe, dev):
+    cases.case_tensor_any_parts(fhe, dev)
+
+
+@pytest.mark.parametrize("dev", [False, True])
 def test_decrypt(fhe, dev):
     cases.case_decrypt(fhe, dev)
 

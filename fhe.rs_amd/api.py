@@ -767,5 +767,10 @@ def prof_report():
     return out
 
 
+def workspace_trim():
+    """Frees the engine's idle scratch buffers; returns the bytes released."""
+    return int(_lib.lib().fhe_workspace_trim())
+
+
 def set_chunk(chunk):
     _lib.lib().fhe_set_chunk(chunk)

@@ -161,14 +161,17 @@ public:
         return w;
     }
     void *acquire(size_t bytes, hipStream_t s) {
+        int dev = 0;
+        FHE_HIP_CHECK(hipGetDevice(&dev));
         std::lock_guard<std::mutex> lk(mu);
         Block *best = nullptr;
         for (auto &b : blocks)
-            if (!b.in_use && b.stream == s && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+            if (!b.in_use && b.device == dev && b.stream == s && b.bytes >= bytes && (!best || b.bytes < best->bytes))
+                best = &b;
         if (!best) {
-            // free idle blocks of this stream that are too small before growing
+            // free idle blocks of this (device, stream) that are too small before growing
             for (auto &b : blocks)
-                if (!b.in_use && b.stream == s && b.ptr) {
+                if (!b.in_use && b.device == dev && b.stream == s && b.ptr) {
                     (void)hipFree(b.ptr);
                     b.ptr = nullptr;
                     b.bytes = 0;
@@ -179,6 +182,7 @@ public:
             FHE_HIP_CHECK(hipMalloc(&nb.ptr, bytes ? bytes : 8));
             nb.bytes = bytes;
             nb.stream = s;
+            nb.device = dev;
             blocks.push_back(nb);
             best = &blocks.back();
         }
@@ -190,12 +194,30 @@ public:
         for (auto &b : blocks)
             if (b.ptr == p) b.in_use = false;
     }
+    // Frees every idle block (all devices); returns the number of bytes released.
+    size_t trim() {
+        std::lock_guard<std::mutex> lk(mu);
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        size_t freed = 0;
+        for (auto &b : blocks)
+            if (!b.in_use && b.ptr) {
+                (void)hipSetDevice(b.device);
+                (void)hipFree(b.ptr);
+                freed += b.bytes;
+                b.ptr = nullptr;
+            }
+        (void)hipSetDevice(cur);
+        blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const Block &b) { return !b.ptr; }), blocks.end());
+        return freed;
+    }
 
 private:
     struct Block {
         void *ptr = nullptr;
         size_t bytes = 0;
         hipStream_t stream = nullptr;
+        int device = 0;
         bool in_use = false;
     };
     std::vector<Block> blocks;

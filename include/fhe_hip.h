@@ -322,6 +322,9 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
                                  uint64_t *out, size_t batch, void *stream);
 /* Chunk (ciphertexts per pipeline pass) used by the batched BFV entry points; 0 = default. */
 void fhe_set_chunk(size_t chunk);
+/* The engine keeps its scratch buffers (grow-only, reused in stream order per device) between calls;
+ * this frees every idle one and returns the number of bytes released. */
+size_t fhe_workspace_trim(void);
 size_t fhe_get_chunk(void);
 /* Per-kernel HIP-event timing (events recorded on the launching stream). */
 void fhe_prof_enable(int on);

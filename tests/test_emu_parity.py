@@ -115,6 +115,13 @@ def test_decrypt(fhe):
     cases.case_decrypt(fhe, False)
 
 
+def test_workspace_trim(fhe):
+    cases.case_multiply(fhe, False, nmod=2)
+    assert fhe.workspace_trim() > 0
+    assert fhe.workspace_trim() == 0
+    cases.case_multiply(fhe, False, nmod=2)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 

@@ -223,3 +223,11 @@ def test_random_parameter_shapes(fhe, idx):
     ct x ct (+relinearise, +mod switch), relinearise, rotations -- bit-exact vs the C oracle."""
     import full_size
     full_size.check_random_shape(fhe, idx)
+
+
+def test_workspace_trim(fhe):
+    """Scratch buffers persist between calls; trimming frees the idle ones and the next call regrows them."""
+    cases.case_multiply(fhe, True, nmod=2)
+    assert fhe.workspace_trim() > 0
+    assert fhe.workspace_trim() == 0
+    cases.case_multiply(fhe, True, nmod=2)

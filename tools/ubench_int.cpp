@@ -12,6 +12,12 @@
 #include "../fhe.rs_amd/csrc/zq_dev.hpp"
 using namespace fhe;
 
+// -p / -2p made opaque so that the compiler keeps the add form (the engine loads them from DevMod)
+__device__ __forceinline__ u64 opaque_neg(u64 v) {
+    u64 r = 0 - v;
+    asm("" : "+s"(r));
+    return r;
+}
 constexpr int ILP = 8;
 constexpr int ITERS = 4096;
 
@@ -26,6 +32,7 @@ __global__ void bench(u64 *out, u64 seed, u64 p, u64 w, u64 ws) {
         b[i] = (uint32_t)y[i] | 1;
     }
     const u64 p2 = 2 * p;
+    const PM pm{p, p2, opaque_neg(p), opaque_neg(p2)};
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
         for (int i = 0; i < ILP; i++) {
@@ -35,8 +42,8 @@ __global__ void bench(u64 *out, u64 seed, u64 p, u64 w, u64 ws) {
             if (KIND == 3) x[i] = x[i] + y[i] + (u64)it;                               // 64-bit adds
             if (KIND == 4) x[i] = mulhi64(x[i], y[i]) + 1;                             // 64x64 -> hi64
             if (KIND == 5) x[i] = mul_shoup_lazy(x[i], w, ws, p);                      // Shoup modmul
-            if (KIND == 6) fwd_butterfly(x[i], y[i], w, ws, p, p2);                    // Harvey CT butterfly
-            if (KIND == 7) inv_butterfly(x[i], y[i], w, ws, p, p2);                    // Harvey GS butterfly
+            if (KIND == 6) fwd_butterfly(x[i], y[i], w, ws, pm);                       // Harvey CT butterfly
+            if (KIND == 7) inv_butterfly(x[i], y[i], w, ws, pm);                       // Harvey GS butterfly
             if (KIND == 8) x[i] = x[i] * y[i] + 1;                                     // 64x64 -> lo64
         }
     }

@@ -18,6 +18,8 @@
 //   ew_kernel / tensor_kernel / mul_shoup_kernel                    M/rq/ops.rs:10-245, F/bfv/ops/mul.rs:198-201
 //   synth_kernel            synthetic uniform residues (bench/test inputs)
 #pragma once
+#include <type_traits>
+
 #include "rt.hpp"
 #include "zq_dev.hpp"
 
@@ -115,9 +117,16 @@ constexpr int plan_rem(int logm, int gmax) { return logm % plan_np(logm, gmax); 
 // UNIFORM (64 consecutive groups share the block index, i.e. lo_bits >= 6): the twiddles are
 // wave-uniform and come through the scalar cache.  Otherwise all 2^G - 1 twiddles of a group
 // are fetched up front, one batch of loads in flight instead of a dependent load per stage.
-template <int G, int LOGM, int S0, int T>
+// `Src`: NoSrc -> the group is read from the LDS tile; otherwise a functor (idx, e) -> coefficient
+// idx (= element e of the calling thread's group) that
+// feeds the pass straight from global memory / registers (first pass only: the elements of a
+// group are 2^lo_bits apart, so consecutive lanes read consecutive coefficients -- coalesced --
+// and one LDS round trip plus its barrier disappear).
+struct NoSrc {};
+template <int G, int LOGM, int S0, int T, class Src = NoSrc>
 __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
-                                         uint32_t tid) {
+                                         uint32_t tid, Src src = Src{}) {
+    constexpr bool DIRECT = !std::is_same<Src, NoSrc>::value;
     constexpr uint32_t R = 1u << G;
     constexpr uint32_t lo_bits = LOGM - S0 - G;
     constexpr uint32_t ngroups = 1u << (LOGM - G);
@@ -144,8 +153,13 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
         // multiple of 16), so the per-element LDS offsets are compile-time constants.
         u64 *const g = lds + padi(base);
         u64 x[R];
+        if constexpr (DIRECT) {
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++) x[e] = g[padi(e << lo_bits)];
+            for (uint32_t e = 0; e < R; e++) x[e] = src(base + (e << lo_bits), e);
+        } else {
+#pragma unroll
+            for (uint32_t e = 0; e < R; e++) x[e] = g[padi(e << lo_bits)];
+        }
 #pragma unroll
         for (int u = 0; u < G; u++) {
             const uint32_t half = R >> (u + 1);
@@ -167,12 +181,15 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
 
 // All stages of a size-2^LOGM forward transform on an LDS tile (values < 4p on exit); the
 // pass plan is resolved at compile time.  Early passes (scalar twiddles) take the wider radix.
-template <int LOGM, int T, int GM = GMAX, int PASS = 0, int S0 = 0>
+template <int LOGM, int T, int GM = GMAX, int PASS = 0, int S0 = 0, class Src = NoSrc>
 __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
-                                            uint32_t tid) {
+                                            uint32_t tid, Src src = Src{}) {
     if constexpr (PASS < plan_np(LOGM, GM)) {
         constexpr int G = plan_base(LOGM, GM) + (PASS < plan_rem(LOGM, GM) ? 1 : 0);
-        fwd_pass<G, LOGM, S0, T>(lds, tw, kbase, pm, tid);
+        if constexpr (PASS == 0)
+            fwd_pass<G, LOGM, S0, T, Src>(lds, tw, kbase, pm, tid, src);   // (Src != NoSrc: reads `src`, not LDS)
+        else
+            fwd_pass<G, LOGM, S0, T>(lds, tw, kbase, pm, tid);
         __syncthreads();
         ntt_fwd_lds<LOGM, T, GM, PASS + 1, S0 + G>(lds, tw, kbase, pm, tid);
     }
@@ -238,7 +255,8 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
     }
 }
 
-// Late passes (scalar twiddles) take the wider radix.
+// Late passes (scalar twiddles) take the wider radix.  (Storing the last pass straight to global
+// memory instead of going through the tile once more was measured: no gain -- 8-byte stores.)
 template <int LOGM, int T, int PASS = 0, int V0 = 0>
 __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
                                             const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv) {
@@ -321,15 +339,20 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * n + (u64)sub * M;
     const u64x2 *twr = tw + (u64)mi * n;
 
-    if (prologue == PRO_REDUCE)
-        tile_to_lds<CH, M, T>(lds, src, tid, [&](u64 v) { return reduce_u64(v, md); });
-    else
-        tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
-    __syncthreads();
-    if (!INVERSE) {
-        ntt_fwd_lds<LOGM, T>(lds, twr, nsub + sub, pm, tid);
+    if constexpr (!INVERSE) {
+        // the first pass reads its groups straight from global memory (no tile staging)
+        const bool red = prologue == PRO_REDUCE;
+        ntt_fwd_lds<LOGM, T>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) {
+            const u64 v = src[i];
+            return red ? reduce_u64(v, md) : v;
+        });
         lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(csub_n(v, p2, pm.np2), p, pm.np); });
     } else {
+        if (prologue == PRO_REDUCE)
+            tile_to_lds<CH, M, T>(lds, src, tid, [&](u64 v) { return reduce_u64(v, md); });
+        else
+            tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
+        __syncthreads();
         const bool whole = logn == LOGM;  // ninv[2*mi] = {N^-1, shoup}, ninv[2*mi+1] = {z_last * N^-1, shoup}
         ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1]);
         if (whole)
@@ -408,8 +431,8 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         for (uint32_t i = tid; i < M; i += T) lds[padi(i)] = prod(a0[i], a1[i], b0[i], b1[i]);
     }
     __syncthreads();
-    ntt_inv_lds<LOGM, T>(lds, itw + (u64)r * M, LOGM, 0, pm, tid, true, ninv[2 * r], ninv[2 * r + 1]);
     u64 *dst = out + ((u64)slot * nb + b) * pk + (u64)r * M;
+    ntt_inv_lds<LOGM, T>(lds, itw + (u64)r * M, LOGM, 0, pm, tid, true, ninv[2 * r], ninv[2 * r + 1]);
     lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
 }
 
@@ -530,6 +553,8 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     // The workgroup is alone on its CU (LDS), so nothing else hides the row load: digit i+1's
     // row is fetched into registers while digit i goes through its passes.
     constexpr bool PREFETCH = ks_acc1_in_lds_c(LOGN);   // (needs the VGPRs the LDS accumulators free)
+    // (Feeding the first pass from these registers instead of staging the lifted row in LDS was
+    // measured: 2.5 % slower -- the extra register shuffling outweighs the saved barrier.)
     u64x2 pre[PREFETCH ? CH : 1];
     if constexpr (PREFETCH) {
 #pragma unroll

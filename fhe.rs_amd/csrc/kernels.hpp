@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     const uint32_t tid = threadIdx.x;
     const uint32_t r = blockIdx.x, b = blockIdx.y, slot = blockIdx.z, nb = gridDim.y;
     const DevMod md = mods[r];
-    const u64 p = md.p, p2 = md.p2;
+    const u64 p = md.p;
     const PM pm = make_pm(md);
     const u64 pk = (u64)nrows << LOGM;
     const u64 *a0, *a1, *b0, *b1;  // rows of c00, c01, c10, c11
@@ -454,7 +454,7 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
     const uint32_t r = map.row_begin + rowb % map.rows;
     const uint32_t mi = (uint32_t)(map.mod_offset + (int32_t)r);
     const DevMod md = mods[mi];
-    const u64 p = md.p, p2 = md.p2;
+    const u64 p = md.p;
     const PM pm = make_pm(md);
     const u64 *src = in + (u64)poly * map.src_poly_stride +
                      (u64)(map.src_row_fixed >= 0 ? (uint32_t)map.src_row_fixed : r) * n;

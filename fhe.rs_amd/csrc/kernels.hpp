@@ -123,9 +123,41 @@ constexpr int plan_rem(int logm, int gmax) { return logm % plan_np(logm, gmax); 
 // group are 2^lo_bits apart, so consecutive lanes read consecutive coefficients -- coalesced --
 // and one LDS round trip plus its barrier disappear).
 struct NoSrc {};
-template <int G, int LOGM, int S0, int T, class Src = NoSrc>
+// Per-lane twiddles of a non-UNIFORM pass: all 2^G - 1 of every group the thread handles.  They
+// are fetched BEFORE the barrier that precedes the pass (they do not depend on the tile), so
+// their L2 latency overlaps the barrier instead of following it.
+template <int G, int LOGM, int S0, int T>
+struct FwdTw {
+    static constexpr bool UNIFORM = (LOGM - S0 - G) >= 6;
+    static constexpr int NG = (1 << (LOGM - G)) > T ? (1 << (LOGM - G)) / T : 1;  // groups per thread
+    u64x2 w[UNIFORM ? 1 : NG][UNIFORM ? 1 : (1 << G) - 1];
+};
+template <int G, int LOGM, int S0, int T>
+__device__ __forceinline__ void fwd_tw_load(FwdTw<G, LOGM, S0, T> &tw_regs, const u64x2 *__restrict__ tw,
+                                            uint32_t kbase, uint32_t tid) {
+    using W = FwdTw<G, LOGM, S0, T>;
+    if constexpr (!W::UNIFORM) {
+        constexpr uint32_t lo_bits = LOGM - S0 - G;
+        constexpr uint32_t ngroups = 1u << (LOGM - G);
+#pragma unroll
+        for (int gi = 0; gi < W::NG; gi++) {
+            const uint32_t grp = gi * T + tid;
+            if (ngroups < T && grp >= ngroups) break;
+            const uint32_t hi = grp >> lo_bits;
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const uint32_t kst = (kbase << (S0 + u)) + (hi << u);
+#pragma unroll
+                for (uint32_t blk = 0; blk < (1u << u); blk++) tw_regs.w[gi][(1u << u) - 1 + blk] = tw[kst + blk];
+            }
+        }
+    }
+}
+// PRE: the per-lane twiddles were fetched ahead into tw_regs; otherwise each group fetches its
+// own right before use (fewer live registers).
+template <int G, int LOGM, int S0, int T, bool PRE, class Src = NoSrc>
 __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
-                                         uint32_t tid, Src src = Src{}) {
+                                         uint32_t tid, const FwdTw<G, LOGM, S0, T> &tw_regs, Src src = Src{}) {
     constexpr bool DIRECT = !std::is_same<Src, NoSrc>::value;
     constexpr uint32_t R = 1u << G;
     constexpr uint32_t lo_bits = LOGM - S0 - G;
@@ -139,13 +171,13 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
         uint32_t hi = grp >> lo_bits;
         if (UNIFORM) hi = wave_uniform(hi);
         const uint32_t base = ((grp >> lo_bits) << (LOGM - S0)) + lo;
-        u64x2 w[UNIFORM ? 1 : R - 1];
-        if (!UNIFORM) {
+        u64x2 w[UNIFORM || PRE ? 1 : R - 1];
+        if constexpr (!UNIFORM && !PRE) {
 #pragma unroll
             for (int u = 0; u < G; u++) {
                 const uint32_t kst = (kbase << (S0 + u)) + (hi << u);
 #pragma unroll
-                for (uint32_t blk = 0; blk < (1u << u); blk++) w[UNIFORM ? 0 : (1u << u) - 1 + blk] = tw[kst + blk];
+                for (uint32_t blk = 0; blk < (1u << u); blk++) w[(1u << u) - 1 + blk] = tw[kst + blk];
             }
         }
         // padi(base + off) = padi(base) + padi(off) for every element of a group (no carry out
@@ -166,7 +198,9 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
             const uint32_t kst = (kbase << (S0 + u)) + (hi << u);
 #pragma unroll
             for (uint32_t blk = 0; blk < (1u << u); blk++) {
-                const u64x2 wv = UNIFORM ? tw[kst + blk] : w[UNIFORM ? 0 : (1u << u) - 1 + blk];
+                const u64x2 wv = UNIFORM ? tw[kst + blk]
+                                 : PRE   ? tw_regs.w[UNIFORM || !PRE ? 0 : g0 / T][UNIFORM || !PRE ? 0 : (1u << u) - 1 + blk]
+                                         : w[UNIFORM || PRE ? 0 : (1u << u) - 1 + blk];
 #pragma unroll
                 for (uint32_t j = 0; j < half; j++) {
                     const uint32_t a = blk * 2 * half + j;
@@ -181,18 +215,35 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
 
 // All stages of a size-2^LOGM forward transform on an LDS tile (values < 4p on exit); the
 // pass plan is resolved at compile time.  Early passes (scalar twiddles) take the wider radix.
-template <int LOGM, int T, int GM = GMAX, int PASS = 0, int S0 = 0, class Src = NoSrc>
+template <int LOGM, int GM, int PASS>
+constexpr int fwd_plan_g() { return plan_base(LOGM, GM) + (PASS < plan_rem(LOGM, GM) ? 1 : 0); }
+// TWPF: fetch the next pass's per-lane twiddles before the barrier (costs their registers across
+// it: the key-switch kernels, which also hold accumulators, leave it off).
+template <int LOGM, int T, int GM, bool TWPF, int PASS, int S0, class W, class Src>
+__device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
+                                                uint32_t tid, const W &tw_regs, Src src) {
+    constexpr int G = fwd_plan_g<LOGM, GM, PASS>();
+    if constexpr (PASS == 0)
+        fwd_pass<G, LOGM, S0, T, TWPF, Src>(lds, tw, kbase, pm, tid, tw_regs, src);   // (Src != NoSrc: reads `src`, not LDS)
+    else
+        fwd_pass<G, LOGM, S0, T, TWPF>(lds, tw, kbase, pm, tid, tw_regs);
+    if constexpr (PASS + 1 < plan_np(LOGM, GM)) {
+        constexpr int GN = fwd_plan_g<LOGM, GM, PASS + 1>();
+        FwdTw<GN, LOGM, S0 + G, T> next;
+        if constexpr (TWPF) fwd_tw_load(next, tw, kbase, tid);   // in flight across the barrier
+        __syncthreads();
+        ntt_fwd_lds_rec<LOGM, T, GM, TWPF, PASS + 1, S0 + G>(lds, tw, kbase, pm, tid, next, NoSrc{});
+    } else {
+        __syncthreads();
+    }
+}
+template <int LOGM, int T, int GM = GMAX, bool TWPF = true, class Src = NoSrc>
 __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                             uint32_t tid, Src src = Src{}) {
-    if constexpr (PASS < plan_np(LOGM, GM)) {
-        constexpr int G = plan_base(LOGM, GM) + (PASS < plan_rem(LOGM, GM) ? 1 : 0);
-        if constexpr (PASS == 0)
-            fwd_pass<G, LOGM, S0, T, Src>(lds, tw, kbase, pm, tid, src);   // (Src != NoSrc: reads `src`, not LDS)
-        else
-            fwd_pass<G, LOGM, S0, T>(lds, tw, kbase, pm, tid);
-        __syncthreads();
-        ntt_fwd_lds<LOGM, T, GM, PASS + 1, S0 + G>(lds, tw, kbase, pm, tid);
-    }
+    constexpr int G = fwd_plan_g<LOGM, GM, 0>();
+    FwdTw<G, LOGM, 0, T> first;
+    if constexpr (TWPF) fwd_tw_load(first, tw, kbase, tid);
+    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, 0, 0>(lds, tw, kbase, pm, tid, first, src);
 }
 
 // ---------------------------------------------------------------- inverse passes ----
@@ -201,9 +252,40 @@ __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ 
 // `fold` (only meaningful for the pass that contains the last stage of a whole-row transform):
 // the N^-1 scaling of native.rs:229-232 is folded into the last stage -- x' = (x + y) * N^-1,
 // y' = (x - y) * (z * N^-1) -- which saves half a Shoup multiplication per coefficient.
+// Per-lane twiddles of the non-UNIFORM (early) inverse passes, fetched ahead like FwdTw.
+template <int G, int LOGM, int V0, int T>
+struct InvTw {
+    static constexpr bool UNIFORM = V0 >= 6;
+    static constexpr int NG = (1 << (LOGM - G)) > T ? (1 << (LOGM - G)) / T : 1;
+    u64x2 z[UNIFORM ? 1 : NG][UNIFORM ? 1 : (1 << G) - 1];
+};
+template <int G, int LOGM, int V0, int T>
+__device__ __forceinline__ void inv_tw_load(InvTw<G, LOGM, V0, T> &tw_regs, const u64x2 *__restrict__ itw,
+                                            uint32_t logn, uint32_t sub, uint32_t tid) {
+    using W = InvTw<G, LOGM, V0, T>;
+    if constexpr (!W::UNIFORM) {
+        constexpr uint32_t R = 1u << G;
+        constexpr uint32_t ngroups = 1u << (LOGM - G);
+        const uint32_t n = 1u << logn;
+#pragma unroll
+        for (int gi = 0; gi < W::NG; gi++) {
+            const uint32_t grp = gi * T + tid;
+            if (ngroups < T && grp >= ngroups) break;
+            const uint32_t hi = grp >> V0;
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const uint32_t nblk = R >> (u + 1);
+                const uint32_t kst = n - (n >> (V0 + u)) + (sub << (LOGM - (V0 + u) - 1)) + hi * nblk;
+#pragma unroll
+                for (uint32_t blk = 0; blk < nblk; blk++) tw_regs.z[gi][R - 2 * nblk + blk] = itw[kst + blk];
+            }
+        }
+    }
+}
 template <int G, int LOGM, int V0, int T>
 __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
-                                         const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv) {
+                                         const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv,
+                                         const InvTw<G, LOGM, V0, T> &tw_regs) {
     constexpr uint32_t R = 1u << G;
     constexpr uint32_t ngroups = 1u << (LOGM - G);
     constexpr bool UNIFORM = V0 >= 6;
@@ -216,16 +298,6 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
         uint32_t hi = grp >> V0;
         if (UNIFORM) hi = wave_uniform(hi);
         const uint32_t base = ((grp >> V0) << (V0 + G)) + lo;
-        u64x2 z[UNIFORM ? 1 : R - 1];
-        if (!UNIFORM) {
-#pragma unroll
-            for (int u = 0; u < G; u++) {
-                const uint32_t nblk = R >> (u + 1);
-                const uint32_t kst = n - (n >> (V0 + u)) + (sub << (LOGM - (V0 + u) - 1)) + hi * nblk;
-#pragma unroll
-                for (uint32_t blk = 0; blk < nblk; blk++) z[UNIFORM ? 0 : R - 2 * nblk + blk] = itw[kst + blk];
-            }
-        }
         u64 *const g = lds + padi(base);  // see fwd_pass: constant per-element offsets
         u64 x[R];
 #pragma unroll
@@ -236,7 +308,7 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
             const uint32_t kst = n - (n >> (V0 + u)) + (sub << (LOGM - (V0 + u) - 1)) + hi * nblk;
 #pragma unroll
             for (uint32_t blk = 0; blk < nblk; blk++) {
-                const u64x2 zv = UNIFORM ? itw[kst + blk] : z[UNIFORM ? 0 : R - 2 * nblk + blk];
+                const u64x2 zv = UNIFORM ? itw[kst + blk] : tw_regs.z[UNIFORM ? 0 : g0 / T][UNIFORM ? 0 : R - 2 * nblk + blk];
 #pragma unroll
                 for (uint32_t j = 0; j < (1u << u); j++) {
                     const uint32_t a = blk * (2u << u) + j, b = a + (1u << u);
@@ -257,14 +329,26 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
 
 // Late passes (scalar twiddles) take the wider radix.  (Storing the last pass straight to global
 // memory instead of going through the tile once more was measured: no gain -- 8-byte stores.)
-template <int LOGM, int T, int PASS = 0, int V0 = 0>
+// The caller fetches the first pass's twiddles (inv_tw_first) BEFORE it waits for its tile loads.
+template <int LOGM, int PASS>
+constexpr int inv_plan_g() {
+    return plan_base(LOGM, GMAX) + (PASS >= plan_np(LOGM, GMAX) - plan_rem(LOGM, GMAX) ? 1 : 0);
+}
+template <int LOGM, int T>
+using InvTwFirst = InvTw<inv_plan_g<LOGM, 0>(), LOGM, 0, T>;
+template <int LOGM, int T, int PASS = 0, int V0 = 0, class W>
 __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
-                                            const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv) {
-    if constexpr (PASS < plan_np(LOGM, GMAX)) {
-        constexpr int G = plan_base(LOGM, GMAX) + (PASS >= plan_np(LOGM, GMAX) - plan_rem(LOGM, GMAX) ? 1 : 0);
-        inv_pass<G, LOGM, V0, T>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv);
+                                            const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv,
+                                            const W &tw_regs) {
+    constexpr int G = inv_plan_g<LOGM, PASS>();
+    inv_pass<G, LOGM, V0, T>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, tw_regs);
+    if constexpr (PASS + 1 < plan_np(LOGM, GMAX)) {
+        InvTw<inv_plan_g<LOGM, PASS + 1>(), LOGM, V0 + G, T> next;
+        inv_tw_load(next, itw, logn, sub, tid);   // in flight across the barrier
         __syncthreads();
-        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv);
+        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, next);
+    } else {
+        __syncthreads();
     }
 }
 
@@ -348,13 +432,15 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         });
         lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(csub_n(v, p2, pm.np2), p, pm.np); });
     } else {
+        InvTwFirst<LOGM, T> tw0;
+        inv_tw_load(tw0, twr, logn, sub, tid);   // issued ahead of the tile loads: one latency for both
         if (prologue == PRO_REDUCE)
             tile_to_lds<CH, M, T>(lds, src, tid, [&](u64 v) { return reduce_u64(v, md); });
         else
             tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
         __syncthreads();
         const bool whole = logn == LOGM;  // ninv[2*mi] = {N^-1, shoup}, ninv[2*mi+1] = {z_last * N^-1, shoup}
-        ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1]);
+        ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1], tw0);
         if (whole)
             lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
         else
@@ -430,9 +516,11 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     } else {
         for (uint32_t i = tid; i < M; i += T) lds[padi(i)] = prod(a0[i], a1[i], b0[i], b1[i]);
     }
+    InvTwFirst<LOGM, T> tw0;
+    inv_tw_load(tw0, itw + (u64)r * M, LOGM, 0, tid);   // in flight across the barrier (the loader needs the registers)
     __syncthreads();
     u64 *dst = out + ((u64)slot * nb + b) * pk + (u64)r * M;
-    ntt_inv_lds<LOGM, T>(lds, itw + (u64)r * M, LOGM, 0, pm, tid, true, ninv[2 * r], ninv[2 * r + 1]);
+    ntt_inv_lds<LOGM, T>(lds, itw + (u64)r * M, LOGM, 0, pm, tid, true, ninv[2 * r], ninv[2 * r + 1], tw0);
     lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
 }
 
@@ -585,7 +673,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                 for (int c = 0; c < CH; c++) pre[c] = nx[c * T + tid];
             }
         }
-        ntt_fwd_lds<LOGN, T, KS_GMAX>(lds, twr, 1, pm, tid);
+        ntt_fwd_lds<LOGN, T, KS_GMAX, false>(lds, twr, 1, pm, tid);  // (prefetch measured: no gain here)
         const u64 koff = ((u64)i * lk + j) * N;
         if constexpr (CH > 0) {
             const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
@@ -720,7 +808,7 @@ __global__ void __launch_bounds__(1024, 4)
             lds[padi(2 * ci + 1)] = v[0].y;
         }
         __syncthreads();
-        ntt_fwd_lds<LOGM, T, KS_GMAX>(lds, twr, NS + sub, pm, tid);
+        ntt_fwd_lds<LOGM, T, KS_GMAX, false>(lds, twr, NS + sub, pm, tid);
         const u64 koff = ((u64)i * lk + j) * N + (u64)sub * M;
         const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
         const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);

@@ -434,12 +434,14 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     } else {
         InvTwFirst<LOGM, T> tw0;
         inv_tw_load(tw0, twr, logn, sub, tid);   // issued ahead of the tile loads: one latency for both
+        const bool whole = logn == LOGM;  // ninv[2*mi] = {N^-1, shoup}, ninv[2*mi+1] = {z_last * N^-1, shoup}
+        // (feeding the first pass straight from global memory, as the forward transform does, was
+        // measured for the inverse: no gain -- its groups are runs of consecutive coefficients)
         if (prologue == PRO_REDUCE)
             tile_to_lds<CH, M, T>(lds, src, tid, [&](u64 v) { return reduce_u64(v, md); });
         else
             tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
         __syncthreads();
-        const bool whole = logn == LOGM;  // ninv[2*mi] = {N^-1, shoup}, ninv[2*mi+1] = {z_last * N^-1, shoup}
         ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1], tw0);
         if (whole)
             lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });

@@ -15,7 +15,13 @@
 //   scale_kernel            RnsScaler::scale per column             M/rns/scaler.rs:249-352, M/rq/scaler.rs:85-94
 //   switch_down_kernel      Poly::switch_down                       M/rq/mod.rs:433-492
 //   substitute_kernel       Poly::substitute                        M/rq/mod.rs:360-412
-//   ew_kernel / tensor_kernel / mul_shoup_kernel                    M/rq/ops.rs:10-245, F/bfv/ops/mul.rs:198-201
+//   tensor_intt_kernel      tensor step fused with the following inverse NTT   F/bfv/ops/mul.rs:198-205
+//   ew_kernel / tensor_kernel / tensor_general_kernel / mul_shoup_kernel   M/rq/ops.rs:10-245, F/bfv/ops/mul.rs:198-201,
+//                                                                   F/bfv/ops/mod.rs:300-327
+//   dot_kernel, mul_plain_kernel        dot_product_scalar, ct x pt F/bfv/ops/dot_product.rs:54-180, ops/mod.rs:229-257
+//   expand_step_kernel, monomial_kernel EvaluationKey::expands      F/bfv/keys/evaluation_key.rs:192-256
+//   phase_kernel, decrypt_tail_kernel   SecretKey::try_decrypt      F/bfv/keys/secret_key.rs:198-247
+//   wire_pack_kernel, wire_unpack_kernel  Rq payload bit packing    M/rq/convert.rs:17-99, fhe-util lib.rs:71-148
 //   synth_kernel            synthetic uniform residues (bench/test inputs)
 #pragma once
 #include <type_traits>

@@ -111,3 +111,38 @@ def test_host_scaler_constants_c2(fhe):
         assert sc.constants(7).tolist() == osc.theta_garner_lo and sc.constants(8).tolist() == osc.theta_garner_hi
         assert sc.constants(9).tolist()[:4] == [osc.theta_gamma_lo, osc.theta_gamma_hi,
                                                1 if osc.theta_gamma_sign else 0, osc.theta_garner_shift]
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/fhe_hip.h is the boundary a C / cgo / JNI / Rust-bindgen host consumes: it must
+    compile as C99 on its own, and a C program linked against the library can call the host-only
+    entry points (no GPU needed: prime search and a device = -1 context)."""
+    import subprocess
+    src = tmp_path / "abi_smoke.c"
+    src.write_text(r'''
+#include "fhe_hip.h"
+#include <stdio.h>
+int main(void) {
+    uint64_t p = fhe_generate_prime(62, 2 * 8192, (uint64_t)1 << 62);
+    uint64_t moduli[2] = {4611686018427322369ull, 4611686018427289601ull};
+    fhe_ctx *ctx = NULL;
+    fhe_status st = fhe_ctx_create(-1, 8192, 2, moduli, NULL, NULL, NULL, NULL, NULL, NULL, &ctx);
+    printf("%llu %d %zu %zu\n", (unsigned long long)p, (int)st, fhe_ctx_degree(ctx), fhe_poly_serialized_size(ctx));
+    /* compute calls on a host-only handle fail cleanly with FHE_E_NO_DEVICE */
+    uint64_t dummy[2 * 8192] = {0};
+    st = fhe_ntt_forward(ctx, dummy, 1);
+    printf("%d %s\n", (int)st, st == FHE_E_NO_DEVICE ? "no-device" : "unexpected");
+    fhe_ctx_destroy(ctx);
+    return 0;
+}
+''')
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "fhe.rs_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", "-I", inc,
+                           os.path.join(inc, "fhe_hip.h")])
+    exe = tmp_path / "abi_smoke"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", inc, str(src), "-o", str(exe), "-L", libdir,
+                           "-lfhe_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    assert out[0] == "4611686018427322369 0 8192 126976", out   # 2 x 8192 x 62 bits / 8
+    assert out[1] == "-18 no-device", out

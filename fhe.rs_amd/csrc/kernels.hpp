@@ -879,10 +879,23 @@ struct ScalerDev {
     uint32_t theta_gamma_sign, is_one, shift, nfrom, nto, ncommon;
 };
 
-// acc (192-bit: 128-bit low part + top word) += a * b
-FHE_HD void mac192(u128_t &acc, u64 &top, u64 a, u64 b) {
-    const bool c = __builtin_add_overflow(acc, (u128_t)a * b, &acc);
-    top += c ? 1 : 0;
+// Sum of 64x64-bit products without carry detection: the low and the high 64-bit halves of the
+// products are summed separately (each sum of up to 2^32 terms fits 96 bits, so a plain
+// zero-extending 128-bit add never overflows and the compiler emits one add/addc chain, no
+// compares); value = lo + (hi << 64), resolved once at the end.
+struct Acc192 {
+    u128_t lo = 0, hi = 0;
+};
+FHE_HD void mac192(Acc192 &acc, u64 a, u64 b) {
+    const u128_t p = (u128_t)a * b;
+    acc.lo += (u64)p;
+    acc.hi += (u64)(p >> 64);
+}
+// -> low 128 bits and the bits above them (`top`)
+FHE_HD void acc192_resolve(const Acc192 &acc, u128_t &low, u64 &top) {
+    const u128_t mid = acc.hi + (acc.lo >> 64);
+    low = (u128_t)(u64)acc.lo | (mid << 64);
+    top = (u64)(mid >> 64);
 }
 
 // One lane per coefficient column (RnsScaler::scale, M/rns/scaler.rs:249-352).  The 256-bit
@@ -960,9 +973,8 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
     for (uint32_t jt = s.ncommon; jt < s.nto; jt++) {
         const DevMod q = to_mods[jt];
         const u64 *om = s.omega + (u64)jt * s.nfrom;
-        u128_t acc = 0;
-        u64 top = 0;
-        mac192(acc, top, vlo, s.gamma_neg[jt]);               // -v_lo * gamma
+        Acc192 a192;
+        mac192(a192, vlo, s.gamma_neg[jt]);                    // -v_lo * gamma
         u64 small = s.vhi_tab[jt * 16 + vh];                   // -v_hi * 2^64 * gamma   (< q)
         if (!s.is_one) {
             const u64 wi = csub_n(reduce_u64(wlo, q) + s.c64_tab[jt * 16 + wh], q.p, q.np);  // w mod q
@@ -970,8 +982,11 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
         }
 #pragma unroll
         for (int i = 0; i < NF; i++)
-            if ((uint32_t)i < s.nfrom) mac192(acc, top, rests[i], om[i]);
-        top += __builtin_add_overflow(acc, (u128_t)small, &acc) ? 1 : 0;
+            if ((uint32_t)i < s.nfrom) mac192(a192, rests[i], om[i]);
+        a192.lo += small;
+        u128_t acc;
+        u64 top;
+        acc192_resolve(a192, acc, top);
         u64 r = reduce_u128((u64)(acc >> 64), (u64)acc, q);    // [0, q)
         r = csub_n(r + s.c128_tab[jt * 16 + ((uint32_t)top & 15)], q.p, q.np);
         o[(u64)jt * n] = r;
@@ -1117,10 +1132,7 @@ __global__ void dot_kernel(const u64 *__restrict__ cts, u64 ct_batch_stride, con
     const DevMod m = mods[row];
     const u64 *cp = cts + (u64)b * ct_batch_stride + (u64)part0 * pl + off;
     const u64 *pp = pts + (u64)b * pt_batch_stride + off;
-    u128_t a0[NP], a1[NP];
-    u64 t0[NP], t1[NP];
-#pragma unroll
-    for (int q = 0; q < NP; q++) a0[q] = a1[q] = 0, t0[q] = t1[q] = 0;
+    Acc192 a0[NP], a1[NP];
 #pragma unroll 2
     for (uint32_t k = 0; k < count; k++) {
         const u64x2 y = *reinterpret_cast<const u64x2 *>(pp + (u64)k * pl);
@@ -1128,14 +1140,17 @@ __global__ void dot_kernel(const u64 *__restrict__ cts, u64 ct_batch_stride, con
         for (int q = 0; q < NP; q++) {
             if (part0 + q < nparts) {
                 const u64x2 x = *reinterpret_cast<const u64x2 *>(cp + ((u64)k * nparts + q) * pl);
-                mac192(a0[q], t0[q], x.x, y.x);
-                mac192(a1[q], t1[q], x.y, y.y);
+                mac192(a0[q], x.x, y.x);
+                mac192(a1[q], x.y, y.y);
             }
         }
     }
     // value = top * 2^128 + a: reduce a, then add (top mod q) * (2^128 mod q)
     const u64 c128 = pow2[row].y;
-    auto fold = [&](u128_t a, u64 top) -> u64 {
+    auto fold = [&](const Acc192 &acc) -> u64 {
+        u128_t a;
+        u64 top;
+        acc192_resolve(acc, a, top);
         const u64 r = reduce_u128((u64)(a >> 64), (u64)a, m);
         return top ? add_mod(r, mul_mod(reduce_u64(top, m), c128, m), m.p) : r;
     };
@@ -1143,8 +1158,8 @@ __global__ void dot_kernel(const u64 *__restrict__ cts, u64 ct_batch_stride, con
     for (int q = 0; q < NP; q++) {
         if (part0 + q < nparts) {
             u64x2 o;
-            o.x = fold(a0[q], t0[q]);
-            o.y = fold(a1[q], t1[q]);
+            o.x = fold(a0[q]);
+            o.y = fold(a1[q]);
             *reinterpret_cast<u64x2 *>(out + ((u64)b * nparts + part0 + q) * pl + off) = o;
         }
     }

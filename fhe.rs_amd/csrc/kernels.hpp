@@ -922,10 +922,11 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
 #pragma unroll
     for (int i = 0; i < NF; i++) rests[i] = (uint32_t)i < s.nfrom ? src[(u64)i * n] : 0;
 
-    U256 sum = {0, 0};
+    Cols256 vc;
 #pragma unroll
     for (int i = 0; i < NF; i++)
-        if ((uint32_t)i < s.nfrom) u256_mac_64x128(sum, rests[i], s.theta_garner_lo[i], s.theta_garner_hi[i], false);
+        if ((uint32_t)i < s.nfrom) cols_mac_64x128(vc, rests[i], s.theta_garner_lo[i], s.theta_garner_hi[i]);
+    const U256 sum = cols_resolve(vc);
     u64 vlo, vhi;
     u256_shr_lo128(sum, s.shift - 1, vlo, vhi);
     {  // v = div_ceil(v, 2)
@@ -938,20 +939,26 @@ __global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, 
     u64 wlo = 0, whi = 0;
     bool w_sign = false;
     if (!s.is_one) {
-        U256 t = {0, 0};
+        // t = sum_i +/- r_i * theta_omega_i  -/+  v * theta_gamma  (mod 2^256, scaler.rs:278-301): the
+        // terms added and the terms subtracted are summed separately, one wrapping subtraction at the end
+        Cols256 pos, neg;
 #pragma unroll
         for (int i = 0; i < NF; i++)
-            if ((uint32_t)i < s.nfrom)
-                u256_mac_64x128(t, rests[i], s.theta_omega_lo[i], s.theta_omega_hi[i], s.theta_omega_sign[i] != 0);
-        // t -/+= v * theta_gamma  (128 x 128 -> 256 wrapping): low word of v, then high word << 64
-        const bool neg = !s.theta_gamma_sign;
-        u256_mac_64x128(t, vlo, s.theta_gamma_lo, s.theta_gamma_hi, neg);
-        {
-            U256 sh = {(t.lo >> 64) | (t.hi << 64), t.hi >> 64};  // t >> 64
-            u256_mac_64x128(sh, vhi, s.theta_gamma_lo, s.theta_gamma_hi, neg);
-            t.hi = (sh.lo >> 64) | (sh.hi << 64);
-            t.lo = (t.lo & (u128_t)~0ull) | (sh.lo << 64);
+            if ((uint32_t)i < s.nfrom) {
+                if (s.theta_omega_sign[i])
+                    cols_mac_64x128(neg, rests[i], s.theta_omega_lo[i], s.theta_omega_hi[i]);
+                else
+                    cols_mac_64x128(pos, rests[i], s.theta_omega_lo[i], s.theta_omega_hi[i]);
+            }
+        // v * theta_gamma (128 x 128 -> 256 wrapping): low word of v, then (high word) << 64
+        if (s.theta_gamma_sign) {
+            cols_mac_64x128(pos, vlo, s.theta_gamma_lo, s.theta_gamma_hi);
+            cols_mac_64x128_shl64(pos, vhi, s.theta_gamma_lo, s.theta_gamma_hi);
+        } else {
+            cols_mac_64x128(neg, vlo, s.theta_gamma_lo, s.theta_gamma_hi);
+            cols_mac_64x128_shl64(neg, vhi, s.theta_gamma_lo, s.theta_gamma_hi);
         }
+        const U256 t = u256_sub(cols_resolve(pos), cols_resolve(neg));
         w_sign = u256_ge_2_191(t);
         if (w_sign) {
             u256_shr_lo128(u256_not(t), 126, wlo, whi);

@@ -147,6 +147,41 @@ FHE_HD void u256_mac_64x128(U256 &acc, u64 r, u64 lo, u64 hi, bool negate) {
         acc.hi -= t_hi + (b2 ? 1 : 0);
     }
 }
+// The same sums without carry detection: 64-bit columns of the 64 x 128-bit products are added
+// into separate 128-bit accumulators (a column sum of < 2^32 terms stays below 2^96, so the
+// zero-extending adds cannot overflow and compile to plain add/addc chains); the 256-bit value
+// c0 + c1*2^64 + c2*2^128 + c3*2^192 (mod 2^256) is formed once.
+struct Cols256 {
+    u128_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+};
+// c += r * (lo | hi << 64)
+FHE_HD void cols_mac_64x128(Cols256 &c, u64 r, u64 lo, u64 hi) {
+    const u128_t p0 = (u128_t)r * lo, p1 = (u128_t)r * hi;
+    c.c0 += (u64)p0;
+    c.c1 += (u64)(p0 >> 64);
+    c.c1 += (u64)p1;
+    c.c2 += (u64)(p1 >> 64);
+}
+// c += (r * (lo | hi << 64)) << 64
+FHE_HD void cols_mac_64x128_shl64(Cols256 &c, u64 r, u64 lo, u64 hi) {
+    const u128_t p0 = (u128_t)r * lo, p1 = (u128_t)r * hi;
+    c.c1 += (u64)p0;
+    c.c2 += (u64)(p0 >> 64);
+    c.c2 += (u64)p1;
+    c.c3 += (u64)(p1 >> 64);
+}
+FHE_HD U256 cols_resolve(const Cols256 &c) {
+    const u128_t m1 = c.c1 + (c.c0 >> 64);
+    const u128_t m2 = c.c2 + (m1 >> 64);
+    const u128_t m3 = c.c3 + (m2 >> 64);  // bits >= 2^256 fall off: U256 arithmetic wraps
+    return U256{(u128_t)(u64)c.c0 | (m1 << 64), (u128_t)(u64)m2 | (m3 << 64)};
+}
+FHE_HD U256 u256_sub(const U256 &a, const U256 &b) {  // wrapping
+    U256 r;
+    const bool borrow = __builtin_sub_overflow(a.lo, b.lo, &r.lo);
+    r.hi = a.hi - b.hi - (borrow ? 1 : 0);
+    return r;
+}
 // bits [s, s+128) of a, for 1 <= s <= 127
 FHE_HD void u256_shr_lo128(const U256 &a, uint32_t s, u64 &lo, u64 &hi) {
     const u128_t v = (a.lo >> s) | (a.hi << (128 - s));

@@ -909,7 +909,8 @@ FHE_HD void acc192_resolve(const Acc192 &acc, u128_t &low, u64 &top) {
 // NF >= nfrom: the column's residues are loaded once, together, into registers (coalesced
 // along N; one batch of loads in flight); all scaler constants are wave-uniform scalar loads.
 template <int NF>
-__global__ void scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,
+__global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs / 8 waves per SIMD measured 3 % faster)
+    scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,
                              u64 out_poly_stride, ScalerDev s, const DevMod *__restrict__ to_mods, uint32_t logn,
                              u64 total) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;

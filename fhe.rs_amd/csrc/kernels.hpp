@@ -946,10 +946,14 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
 #pragma unroll
         for (int i = 0; i < NF; i++)
             if ((uint32_t)i < s.nfrom) {
+                // theta_omega_i = 0 whenever the scaled Garner coefficient is an integer -- e.g. every
+                // source modulus outside the denominator when scaling Q*P -> Q by t/Q (5 of C2's 9)
+                const u64 tlo = s.theta_omega_lo[i], thi = s.theta_omega_hi[i];
+                if ((tlo | thi) == 0) continue;
                 if (s.theta_omega_sign[i])
-                    cols_mac_64x128(neg, rests[i], s.theta_omega_lo[i], s.theta_omega_hi[i]);
+                    cols_mac_64x128(neg, rests[i], tlo, thi);
                 else
-                    cols_mac_64x128(pos, rests[i], s.theta_omega_lo[i], s.theta_omega_hi[i]);
+                    cols_mac_64x128(pos, rests[i], tlo, thi);
             }
         // v * theta_gamma (128 x 128 -> 256 wrapping): low word of v, then (high word) << 64
         if (s.theta_gamma_sign) {

@@ -989,8 +989,12 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
         mac192(a192, vlo, s.gamma_neg[jt]);                    // -v_lo * gamma
         u64 small = s.vhi_tab[jt * 16 + vh];                   // -v_hi * 2^64 * gamma   (< q)
         if (!s.is_one) {
-            const u64 wi = csub_n(reduce_u64(wlo, q) + s.c64_tab[jt * 16 + wh], q.p, q.np);  // w mod q
-            small += w_sign ? (wi ? q.p - wi : 0) : wi;        // < 2q
+            // +/- w = +/- (w_hi * 2^64 + w_lo): the high part through the table, the low word straight
+            // into the 192-bit sum -- as w_lo, or as K - w_lo with K = q * ceil(2^64 / q) = 2^64 + K_lo = 0 (mod q)
+            const u64 c = s.c64_tab[jt * 16 + wh];             // w_hi * 2^64 mod q
+            small += w_sign ? (c ? q.p - c : 0) : c;           // < 2q
+            const u64 k_lo = q.p * (q.brt_hi + 1);             // K mod 2^64 (K >= 2^64 > w_lo)
+            a192.lo += w_sign ? ((((u128_t)1 << 64) | k_lo) - wlo) : (u128_t)wlo;
         }
 #pragma unroll
         for (int i = 0; i < NF; i++)

@@ -879,6 +879,53 @@ struct ScalerDev {
     uint32_t theta_gamma_sign, is_one, shift, nfrom, nto, ncommon;
 };
 
+// Sum of 64x64-bit products on the device: the four 32x32 partial products of a term go straight
+// into three 64-bit column accumulators (weights 2^0, 2^32, 2^64) THROUGH v_mad_u64_u32's addend,
+// and each accumulator's carry-out -- which the compiler never uses -- is banked in a 32-bit
+// overflow counter by a v_addc.  8 VALU instructions per term and no register shuffling, against
+// 14 for the 128-bit formulation below (the multiply needs zero-extended register pairs there).
+// The hazard recognizer does not see inside asm: a VALU-written SGPR needs two wait states
+// before a VALU reads it as carry-in; the instruction order below provides them.
+struct Acc3x64 {
+    u64 c0 = 0, c1 = 0, c2 = 0;
+    uint32_t o0 = 0, o1 = 0, o2 = 0;
+};
+FHE_HD void mac3x64(Acc3x64 &a, u64 x, u64 y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
+    u64 s0, s1, s2;  // carry-outs (SGPR pairs)
+    asm("v_mad_u64_u32 %[c0], %[s0], %[xl], %[yl], %[c0]\n\t"
+        "v_mad_u64_u32 %[c1], %[s1], %[xl], %[yh], %[c1]\n\t"
+        "v_mad_u64_u32 %[c2], %[s2], %[xh], %[yh], %[c2]\n\t"
+        "v_addc_co_u32 %[o0], vcc, 0, %[o0], %[s0]\n\t"
+        "v_mad_u64_u32 %[c1], %[s0], %[xh], %[yl], %[c1]\n\t"
+        "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[s1]\n\t"
+        "v_addc_co_u32 %[o2], vcc, 0, %[o2], %[s2]\n\t"
+        "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[s0]"
+        : [c0] "+v"(a.c0), [c1] "+v"(a.c1), [c2] "+v"(a.c2), [o0] "+v"(a.o0), [o1] "+v"(a.o1), [o2] "+v"(a.o2),
+          [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
+        : [xl] "v"(xl), [xh] "v"(xh), [yl] "v"(yl), [yh] "v"(yh)
+        : "vcc");
+#else  // host pass / host emulation: the same columns in plain C
+    const u64 xl = (uint32_t)x, xh = x >> 32, yl = (uint32_t)y, yh = y >> 32;
+    const u64 pr[4] = {xl * yl, xl * yh, xh * yh, xh * yl};
+    u64 *const cs[4] = {&a.c0, &a.c1, &a.c2, &a.c1};
+    uint32_t *const os[4] = {&a.o0, &a.o1, &a.o2, &a.o1};
+    for (int k = 0; k < 4; k++) {
+        const u64 t = *cs[k] + pr[k];
+        *os[k] += t < *cs[k];
+        *cs[k] = t;
+    }
+#endif
+}
+// value = (c0 + o0 2^64) + (c1 + o1 2^64) 2^32 + (c2 + o2 2^64) 2^64  ->  low 128 bits and the rest
+FHE_HD void acc3x64_resolve(const Acc3x64 &a, u64 extra, u128_t &low, u64 &top) {
+    const u128_t l = (u128_t)a.c0 + ((u128_t)a.c1 << 32) + extra;                     // < 2^98
+    const u128_t m = (u128_t)a.c2 + a.o0 + ((u128_t)a.o1 << 32) + (l >> 64);         // weight 2^64, < 2^67
+    low = (u128_t)(u64)l | (m << 64);
+    top = (u64)(m >> 64) + a.o2;
+}
+
 // Sum of 64x64-bit products without carry detection: the low and the high 64-bit halves of the
 // products are summed separately (each sum of up to 2^32 terms fits 96 bits, so a plain
 // zero-extending 128-bit add never overflows and the compiler emits one add/addc chain, no
@@ -985,8 +1032,9 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
     for (uint32_t jt = s.ncommon; jt < s.nto; jt++) {
         const DevMod q = to_mods[jt];
         const u64 *om = s.omega + (u64)jt * s.nfrom;
-        Acc192 a192;
-        mac192(a192, vlo, s.gamma_neg[jt]);                    // -v_lo * gamma
+        Acc3x64 a192;
+        u128_t extra = 0;                                      // small addends of the sum (< 2^66)
+        mac3x64(a192, vlo, s.gamma_neg[jt]);                   // -v_lo * gamma
         u64 small = s.vhi_tab[jt * 16 + vh];                   // -v_hi * 2^64 * gamma   (< q)
         if (!s.is_one) {
             // +/- w = +/- (w_hi * 2^64 + w_lo): the high part through the table, the low word straight
@@ -994,15 +1042,21 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
             const u64 c = s.c64_tab[jt * 16 + wh];             // w_hi * 2^64 mod q
             small += w_sign ? (c ? q.p - c : 0) : c;           // < 2q
             const u64 k_lo = q.p * (q.brt_hi + 1);             // K mod 2^64 (K >= 2^64 > w_lo)
-            a192.lo += w_sign ? ((((u128_t)1 << 64) | k_lo) - wlo) : (u128_t)wlo;
+            extra = w_sign ? ((((u128_t)1 << 64) | k_lo) - wlo) : (u128_t)wlo;
         }
 #pragma unroll
         for (int i = 0; i < NF; i++)
-            if ((uint32_t)i < s.nfrom) mac192(a192, rests[i], om[i]);
-        a192.lo += small;
+            if ((uint32_t)i < s.nfrom) mac3x64(a192, rests[i], om[i]);
+        extra += small;
+        // (extra < 2^66 does not fit the u64 parameter: split it)
         u128_t acc;
         u64 top;
-        acc192_resolve(a192, acc, top);
+        acc3x64_resolve(a192, (u64)extra, acc, top);
+        {
+            const u128_t hi_extra = (extra >> 64) << 64;       // at most 3 * 2^64
+            const bool c = __builtin_add_overflow(acc, hi_extra, &acc);
+            top += c ? 1 : 0;
+        }
         u64 r = reduce_u128((u64)(acc >> 64), (u64)acc, q);    // [0, q)
         r = csub_n(r + s.c128_tab[jt * 16 + ((uint32_t)top & 15)], q.p, q.np);
         o[(u64)jt * n] = r;

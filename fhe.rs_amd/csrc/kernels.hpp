@@ -498,7 +498,10 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     auto prod = [&](u64 x00, u64 x01, u64 x10, u64 x11) -> u64 {
         if (slot == 0) return mul_mod(x00, x10, md);
         if (slot == 2) return mul_mod(x01, x11, md);
-        return add_mod_n(mul_mod(x00, x11, md), mul_mod(x01, x10, md), pm);
+        // c1 = c00*c11 + c01*c10: one Barrett reduction of the 128-bit sum (< 2p^2 < 2^(2k+1): the
+        // quotient estimate is then short by at most 3, which the two conditional subtractions absorb)
+        const u128_t sum = (u128_t)x00 * x11 + (u128_t)x01 * x10;
+        return barrett_reduce_wide((u64)(sum >> 64), (u64)sum, md);
     };
     if constexpr (CH > 0) {
         constexpr int HALF = CH > 1 ? CH / 2 : 1;  // loads of at most HALF chunks x 4 operands in flight
@@ -1179,7 +1182,10 @@ __global__ void tensor_kernel(const u64 *__restrict__ extL, const u64 *__restric
         return;
     }
     o[0] = mul_mod(c00, c10, m);
-    o[nb * pn] = csub_n(mul_mod(c00, c11, m) + mul_mod(c01, c10, m), m.p, m.np);
+    {
+        const u128_t sum = (u128_t)c00 * c11 + (u128_t)c01 * c10;  // one reduction, see tensor_intt_kernel
+        o[nb * pn] = barrett_reduce_wide((u64)(sum >> 64), (u64)sum, m);
+    }
     o[2 * nb * pn] = mul_mod(c01, c11, m);
 }
 // dot_product_scalar / rq::dot_product (F/bfv/ops/dot_product.rs:54-180, M/rq/ops.rs:449-570):

@@ -54,8 +54,9 @@ FHE_HD u64 mul_shoup_lazy(u64 a, u64 b, u64 bs, u64 p) {
 }
 FHE_HD u64 mul_shoup(u64 a, u64 b, u64 bs, u64 p) { return csub(mul_shoup_lazy(a, b, bs, p), p); }
 
-// Barrett reduction of x = hi:lo < 2^(2k) (e.g. a product of two residues) to [0, p).
-// q = floor(floor(x / 2^(k-1)) * floor(2^(2k)/p) / 2^(k+1)) underestimates floor(x/p) by <= 2.
+// Barrett reduction of x = hi:lo < 2^(2k+1) (a product of two residues, or the sum of two) to [0, p).
+// q = floor(floor(x / 2^(k-1)) * floor(2^(2k)/p) / 2^(k+1)) underestimates floor(x/p) by <= 2
+// for x < 2^(2k) and by <= 3 for x < 2^(2k+1), so x - q*p < 4p < 2^64.
 FHE_HD u64 barrett_reduce_wide(u64 hi, u64 lo, const DevMod &m) {
     const uint32_t s = m.k - 1;
     u64 xs = (s == 0) ? lo : ((lo >> s) | (hi << (64 - s)));  // x >> (k-1), < 2^(k+1)

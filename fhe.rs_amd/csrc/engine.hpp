@@ -716,7 +716,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     const Ctx &kc = *k_.ksk_ctx;
     kc.need_device();
     if (!npolys) return;
-    if (kc.logn <= 14) {  // (N = 16384: the whole-row kernel beats the sub-block one, 82.6 k vs 77.8 k relin/s)
+    if (kc.logn <= 14) {  // (sub-block variants measured: N = 16384 82.6 k vs 77.8 k relin/s; N = 8192 as 2 x 4096 +-1 %)
 #define FHE_KS_CASE(LN) \
     case LN: launch_ks_fused<LN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s); break;
         switch (kc.logn) {

@@ -759,8 +759,8 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
 // branch leading to `sub` is evaluated (2^G0 - 1 Shoup multiplications per coefficient instead
 // of G0/2 amortised, but no round trip of the lifted row through HBM); the remaining 13 stages
 // run in LDS with twiddle base 2^G0 + sub, exactly like ntt_kernel's sub-block mode.
-template <int G0>
-__global__ void __launch_bounds__(1024, 4)
+template <int G0, int LOGM = 13>
+__global__ void __launch_bounds__((1 << LOGM) / 8, 4)
     ks_fused_split_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0,
                           u64 *__restrict__ out1, u64 out_poly_stride, const u64 *__restrict__ addend0,
                           const u64 *__restrict__ addend1, u64 addend_poly_stride, const u64 *__restrict__ k0,
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(1024, 4)
                           const DevMod *__restrict__ mods, const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk,
                           uint32_t digit_shift_bits) {
     FHE_DYN_SMEM(u64, lds);
-    constexpr int LOGM = 13, M = 1 << LOGM, T = 1024, CH = M / (2 * T), NS = 1 << G0;
+    constexpr int M = 1 << LOGM, T = M / 8, CH = M / (2 * T), NS = 1 << G0;
     constexpr u64 N = (u64)M << G0;
     const uint32_t tid0 = threadIdx.x;
     const uint32_t sub = blockIdx.x & (NS - 1);

@@ -165,6 +165,13 @@ def case_scaler_grid(fhe, dev, n=16, pairs=None):
             assert np.array_equal(got[0], arr(osc.scale(p)))
             pn = p.into_ntt()
             assert np.array_equal(x.back(sc.scale(x.to(arr(pn)), ntt=True)), arr(osc.scale(pn)))
+            # carry-chain extremes of the wide sums: every residue at its maximum, zero, and a mix
+            ext = Poly(of, POWER_BASIS, [[(m - 1) if (i + r) % 3 else (0 if i % 2 else m - 1) for i in range(n)]
+                                         for r, m in enumerate(of.moduli)])
+            ext.coefficients[0][:4] = [of.moduli[0] - 1, 0, 1, of.moduli[0] // 2]
+            for r in range(1, len(of.moduli)):
+                ext.coefficients[r][:4] = [of.moduli[r] - 1, 0, 1, of.moduli[r] // 2]
+            assert np.array_equal(x.back(sc.scale(x.to(arr(ext)), ntt=False)), arr(osc.scale(ext)))
 
 
 def case_scaler_extend_and_constants_api(fhe, dev, n=16):

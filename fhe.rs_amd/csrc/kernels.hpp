@@ -225,7 +225,8 @@ template <int LOGM, int GM, int PASS>
 constexpr int fwd_plan_g() { return plan_base(LOGM, GM) + (PASS < plan_rem(LOGM, GM) ? 1 : 0); }
 // TWPF: fetch the next pass's per-lane twiddles before the barrier (costs their registers across
 // it: the key-switch kernels, which also hold accumulators, leave it off).
-template <int LOGM, int T, int GM, bool TWPF, int PASS, int S0, class W, class Src>
+// FSYNC = false: the caller places the barrier after the last pass itself (it has loads to issue first).
+template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, int PASS, int S0, class W, class Src>
 __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                                 uint32_t tid, const W &tw_regs, Src src) {
     constexpr int G = fwd_plan_g<LOGM, GM, PASS>();
@@ -238,18 +239,18 @@ __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restric
         FwdTw<GN, LOGM, S0 + G, T> next;
         if constexpr (TWPF) fwd_tw_load(next, tw, kbase, tid);   // in flight across the barrier
         __syncthreads();
-        ntt_fwd_lds_rec<LOGM, T, GM, TWPF, PASS + 1, S0 + G>(lds, tw, kbase, pm, tid, next, NoSrc{});
+        ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, PASS + 1, S0 + G>(lds, tw, kbase, pm, tid, next, NoSrc{});
     } else {
-        __syncthreads();
+        if constexpr (FSYNC) __syncthreads();
     }
 }
-template <int LOGM, int T, int GM = GMAX, bool TWPF = true, class Src = NoSrc>
+template <int LOGM, int T, int GM = GMAX, bool TWPF = true, bool FSYNC = true, class Src = NoSrc>
 __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                             uint32_t tid, Src src = Src{}) {
     constexpr int G = fwd_plan_g<LOGM, GM, 0>();
     FwdTw<G, LOGM, 0, T> first;
     if constexpr (TWPF) fwd_tw_load(first, tw, kbase, tid);
-    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, 0, 0>(lds, tw, kbase, pm, tid, first, src);
+    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, 0, 0>(lds, tw, kbase, pm, tid, first, src);
 }
 
 // ---------------------------------------------------------------- inverse passes ----
@@ -684,15 +685,32 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                 for (int c = 0; c < CH; c++) pre[c] = nx[c * T + tid];
             }
         }
-        ntt_fwd_lds<LOGN, T, KS_GMAX, false>(lds, twr, 1, pm, tid);  // (prefetch measured: no gain here)
         const u64 koff = ((u64)i * lk + j) * N;
         if constexpr (CH > 0) {
             const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
             const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
+            // KPF: the key words of the first two chunks are requested before the barrier that ends the
+            // transform, so their L2 latency is spent waiting for the other waves, not after them
+            constexpr bool KPF = PREFETCH && CH >= 2;
+            ntt_fwd_lds<LOGN, T, KS_GMAX, false, !KPF>(lds, twr, 1, pm, tid);  // (twiddle prefetch measured: no gain here)
+            u64x2 kq[KPF ? 8 : 1];
+            if constexpr (KPF) {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t ci = c * T + tid;
+                    kq[4 * c] = a0[ci], kq[4 * c + 1] = a0s[ci], kq[4 * c + 2] = a1[ci], kq[4 * c + 3] = a1s[ci];
+                }
+                __syncthreads();
+            }
 #pragma unroll
             for (int c = 0; c < CH; c++) {
                 const uint32_t ci = c * T + tid;
-                const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+                u64x2 q0, q0s, q1, q1s;
+                if (KPF && c < 2) {
+                    q0 = kq[KPF ? 4 * c : 0], q0s = kq[KPF ? 4 * c + 1 : 0], q1 = kq[KPF ? 4 * c + 2 : 0], q1s = kq[KPF ? 4 * c + 3 : 0];
+                } else {
+                    q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+                }
                 const u64 vx = lds[padi(2 * ci)], vy = lds[padi(2 * ci + 1)];  // < 4p: Shoup accepts any u64
                 acc0[2 * c] = csub_n(acc0[2 * c] + mul_shoup_lazy_n(vx, q0.x, q0s.x, pm.np), p2, pm.np2);
                 acc0[2 * c + 1] = csub_n(acc0[2 * c + 1] + mul_shoup_lazy_n(vy, q0.y, q0s.y, pm.np), p2, pm.np2);
@@ -707,10 +725,13 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                 }
                 if (c & 1) sched_fence();  // at most two chunks of key loads (32 VGPRs) in flight
             }
-        } else if (tid < N) {
+        } else {
+            ntt_fwd_lds<LOGN, T, KS_GMAX, false>(lds, twr, 1, pm, tid);
+            if (tid < N) {
             const u64 v = lds[padi(tid)];
             acc0[0] = csub_n(acc0[0] + mul_shoup_lazy_n(v, k0[koff + tid], k0s[koff + tid], pm.np), p2, pm.np2);
             acc1[0] = csub_n(acc1[0] + mul_shoup_lazy_n(v, k1[koff + tid], k1s[koff + tid], pm.np), p2, pm.np2);
+            }
         }
         __syncthreads();
     }

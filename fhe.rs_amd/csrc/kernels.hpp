@@ -505,6 +505,23 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         return barrett_reduce_wide((u64)(sum >> 64), (u64)sum, md);
     };
     if constexpr (CH > 0) {
+        if (slot != 1) {
+            // c0 = c00*c10 / c2 = c01*c11: two operand rows, all CH chunks of both in flight at once
+            const u64x2 *pa = reinterpret_cast<const u64x2 *>(slot == 0 ? a0 : a1);
+            const u64x2 *pb = reinterpret_cast<const u64x2 *>(slot == 0 ? b0 : b1);
+            u64x2 va[CH], vb[CH];
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                va[c] = pa[c * T + tid];
+                vb[c] = pb[c * T + tid];
+            }
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t i = 2 * (c * T + tid);
+                lds[padi(i)] = mul_mod(va[c].x, vb[c].x, md);
+                lds[padi(i + 1)] = mul_mod(va[c].y, vb[c].y, md);
+            }
+        } else {
         constexpr int HALF = CH > 1 ? CH / 2 : 1;  // loads of at most HALF chunks x 4 operands in flight
 #pragma unroll
         for (int h = 0; h < CH; h += HALF) {
@@ -524,6 +541,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
                 lds[padi(i + 1)] = prod(v00[c].y, v01[c].y, v10[c].y, v11[c].y);
             }
             sched_fence();
+        }
         }
     } else {
         for (uint32_t i = tid; i < M; i += T) lds[padi(i)] = prod(a0[i], a1[i], b0[i], b1[i]);

@@ -575,6 +575,21 @@ inline void scaler_upload(Scaler &s) {
     s.dev.theta_garner_hi = b + o_tgh;
     s.dev.theta_gamma_lo = c.theta_gamma_lo;
     s.dev.theta_gamma_hi = c.theta_gamma_hi;
+    // narrow_mask: for a factor-one scaler v = round(sum_i r_i theta_i / 2^shift) <= sum_i r_i + 2 (theta_i / 2^shift
+    // ~ garner_i / Q < 1), so target j's sum  sum_i r_i omega_ij + v gamma_neg_j + (small terms < 4 q_j)  is at most
+    // (2 * sum_i (q_i - 1) + 2) * (q_j - 1) + 4 q_j.  Where that is below 2^(2 k_j + 1), k_j = bits(q_j), the
+    // kernel reduces with the single-word Barrett instead of the 128-bit-ratio reduction.
+    s.dev.narrow_mask = 0;
+    if (c.is_one && c.nto <= 64) {
+        BigUint sum_q(0);
+        for (size_t i = 0; i < c.nfrom; i++) sum_q = sum_q + BigUint(s.from->moduli[i] - 1);
+        for (size_t j = 0; j < c.nto; j++) {
+            const u64 q = s.to->moduli[j];
+            const size_t k = 64 - (size_t)__builtin_clzll(q);
+            const BigUint bound = (sum_q * BigUint(2) + BigUint(2)) * BigUint(q - 1) + BigUint(q) * BigUint(4);
+            if (bound < BigUint::pow2(2 * k + 1)) s.dev.narrow_mask |= (u64)1 << j;
+        }
+    }
     s.dev.theta_gamma_sign = c.theta_gamma_sign ? 1 : 0;
     s.dev.is_one = c.is_one ? 1 : 0;
     s.dev.shift = (uint32_t)c.theta_garner_shift;

@@ -918,6 +918,7 @@ struct ScalerDev {
     const u64 *theta_omega_sign;                         // [nfrom] (0/1)
     const u64 *theta_garner_lo, *theta_garner_hi;        // [nfrom]
     u64 theta_gamma_lo, theta_gamma_hi;
+    u64 narrow_mask;  // bit j: the output sum for target modulus j provably stays below 2^(2k_j+1) (see scaler_upload)
     uint32_t theta_gamma_sign, is_one, shift, nfrom, nto, ncommon;
 };
 
@@ -1099,8 +1100,14 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
             const bool c = __builtin_add_overflow(acc, hi_extra, &acc);
             top += c ? 1 : 0;
         }
-        u64 r = reduce_u128((u64)(acc >> 64), (u64)acc, q);    // [0, q)
-        r = csub_n(r + s.c128_tab[jt * 16 + ((uint32_t)top & 15)], q.p, q.np);
+        u64 r;
+        if ((s.narrow_mask >> (jt & 63)) & 1) {
+            // the whole sum is < 2^(2k+1) (hence top == 0): the single-word Barrett of zq_dev.hpp does it
+            r = barrett_reduce_wide((u64)(acc >> 64), (u64)acc, q);
+        } else {
+            r = reduce_u128((u64)(acc >> 64), (u64)acc, q);    // [0, q)
+            r = csub_n(r + s.c128_tab[jt * 16 + ((uint32_t)top & 15)], q.p, q.np);
+        }
         o[(u64)jt * n] = r;
     }
 }

@@ -613,6 +613,24 @@ def case_tensor_any_parts(fhe, dev, n=16, nmod=3):
     assert x.back(par.decrypt(s_ntt, x.to(got), 0)).tolist() == sk.decrypt(ABC)
 
 
+def case_extender_narrow_sums(fhe, dev, n=32):
+    """Factor-one extension Q -> Q*P with 60-bit Q and 62-bit P (the C2 shape): every output sum
+    stays below 2^(2k+1), so the engine takes the single-word Barrett branch of the scaler
+    (engine.hpp narrow_mask); residues at their maxima included.  rq/scaler.rs:55-127."""
+    x = Xfer(dev)
+    rng = random.Random(41)
+    opar = obfv.BfvParameters(n, 1153 if n <= 64 else obfv.generate_moduli([20], n)[0], moduli_sizes=[60] * 4)
+    par = fhe.BfvParameters(n, opar.plaintext, moduli=opar.moduli)
+    oext, ext = opar.mul_params[0].extender, par.extender(0)
+    base = opar.ctx[0]
+    polys = [rand_poly(base, POWER_BASIS, rng) for _ in range(3)]
+    polys.append(Poly(base, POWER_BASIS, [[m - 1] * n for m in base.moduli]))
+    polys.append(Poly(base, POWER_BASIS, [[(m - 1) if i % 2 else 0 for i in range(n)] for m in base.moduli]))
+    got = x.back(ext.scale(x.to(np.stack([arr(p) for p in polys])), ntt=False))
+    for g, p in zip(got, polys):
+        assert np.array_equal(g, arr(oext.scale(p)))
+
+
 def case_errors(fhe):
     """Error conventions (include/fhe_hip.h status codes <-> fhe_math::Error variants)."""
     def code(fn):

@@ -111,6 +111,10 @@ def test_tensor_any_parts(fhe):
     cases.case_tensor_any_parts(fhe, False)
 
 
+def test_extender_narrow_sums(fhe):
+    cases.case_extender_narrow_sums(fhe, False)
+
+
 def test_decrypt(fhe):
     cases.case_decrypt(fhe, False)
 

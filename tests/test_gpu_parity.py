@@ -120,6 +120,12 @@ def test_tensor_any_parts(fhe, dev):
 
 
 @pytest.mark.parametrize("dev", [False, True])
+def test_extender_narrow_sums(fhe, dev):
+    cases.case_extender_narrow_sums(fhe, dev)
+    cases.case_extender_narrow_sums(fhe, dev, n=2048)
+
+
+@pytest.mark.parametrize("dev", [False, True])
 def test_decrypt(fhe, dev):
     cases.case_decrypt(fhe, dev)
 

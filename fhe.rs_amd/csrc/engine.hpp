@@ -557,7 +557,27 @@ inline void scaler_upload(Scaler &s) {
             c128[j * 16 + k] = mulmod(k % q, two128, q);
         }
     }
+    // fold_mask / fold_tab (any factor): v_lo < 2^64 and the small addends (w's low word or its complement
+    // < 2^64 + q, table values < 3q) give  sum_j <= (2^64 - 1 + sum_i (p_i - 1)) (q_j - 1) + 2^65 + 4 q_j;  where that
+    // is below 2^(2 k_j + 6) the bits above 2^(2 k_j) index a 64-entry table of their residues.
+    std::vector<u64> fold(c.nto * 64, 0);
+    u64 fold_mask = 0;
+    if (c.nto <= 64) {
+        BigUint sum_p = BigUint::pow2(64) - BigUint(1);
+        for (size_t i = 0; i < c.nfrom; i++) sum_p = sum_p + BigUint(s.from->moduli[i] - 1);
+        for (size_t j = 0; j < c.nto; j++) {
+            const u64 q = s.to->moduli[j];
+            const size_t k = 64 - (size_t)__builtin_clzll(q);
+            const BigUint bound = sum_p * BigUint(q - 1) + BigUint::pow2(65) + BigUint(q) * BigUint(4);
+            if (bound < BigUint::pow2(std::min<size_t>(2 * k + 6, 128))) {   // (< 2^128: nothing above the 128-bit sum)
+                fold_mask |= (u64)1 << j;
+                const u64 unit = (BigUint::pow2(2 * k) % BigUint(q)).to_u64();
+                for (u64 i = 0; i < 64; i++) fold[j * 64 + i] = mulmod(i % q, unit, q);
+            }
+        }
+    }
     std::vector<u64> sign64(c.theta_omega_sign.begin(), c.theta_omega_sign.end());
+    size_t o_fold = push(fold);
     size_t o_gn = push(gneg), o_om = push(c.omega), o_vt = push(vtab), o_c64 = push(c64), o_c128 = push(c128);
     size_t o_tol = push(c.theta_omega_lo), o_toh = push(c.theta_omega_hi), o_tos = push(sign64);
     size_t o_tgl = push(c.theta_garner_lo), o_tgh = push(c.theta_garner_hi);
@@ -590,6 +610,8 @@ inline void scaler_upload(Scaler &s) {
             if (bound < BigUint::pow2(2 * k + 1)) s.dev.narrow_mask |= (u64)1 << j;
         }
     }
+    s.dev.fold_mask = fold_mask;
+    s.dev.fold_tab = b + o_fold;
     s.dev.theta_gamma_sign = c.theta_gamma_sign ? 1 : 0;
     s.dev.is_one = c.is_one ? 1 : 0;
     s.dev.shift = (uint32_t)c.theta_garner_shift;

@@ -919,6 +919,8 @@ struct ScalerDev {
     const u64 *theta_garner_lo, *theta_garner_hi;        // [nfrom]
     u64 theta_gamma_lo, theta_gamma_hi;
     u64 narrow_mask;  // bit j: the output sum for target modulus j provably stays below 2^(2k_j+1) (see scaler_upload)
+    u64 fold_mask;    // bit j: it stays below 2^(2k_j+6): bits >= 2^(2k_j) are folded through fold_tab first
+    const u64 *fold_tab;                                 // [nto][64]  i * 2^(2k_j) mod q_j
     uint32_t theta_gamma_sign, is_one, shift, nfrom, nto, ncommon;
 };
 
@@ -1103,6 +1105,13 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
         u64 r;
         if ((s.narrow_mask >> (jt & 63)) & 1) {
             // the whole sum is < 2^(2k+1) (hence top == 0): the single-word Barrett of zq_dev.hpp does it
+            r = barrett_reduce_wide((u64)(acc >> 64), (u64)acc, q);
+        } else if ((s.fold_mask >> (jt & 63)) & 1) {
+            // < 2^(2k+6): replace the bits above 2^(2k) by their residue (64-entry table), which leaves
+            // < 2^(2k) + q < 2^(2k+1) for the same single-word Barrett
+            const uint32_t f = 2 * q.k;
+            const uint32_t idx = (uint32_t)(acc >> f);
+            acc = (acc & ((((u128_t)1) << f) - 1)) + s.fold_tab[jt * 64 + idx];
             r = barrett_reduce_wide((u64)(acc >> 64), (u64)acc, q);
         } else {
             r = reduce_u128((u64)(acc >> 64), (u64)acc, q);    // [0, q)

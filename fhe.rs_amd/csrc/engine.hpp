@@ -715,6 +715,18 @@ inline void substitute_polys(const Ctx &c, size_t exponent, const u64 *in, u64 *
 struct Ksk {
     const Ctx *ct_ctx = nullptr, *ksk_ctx = nullptr;
     size_t ndigits = 0, log_base = 0;
+    // how far a digit can exceed the key moduli (ks_fused_kernel's lift_mode): RNS digits are residues
+    // < q_i, so q_i < 2 q_j for all i, j -> 1, < 4 q_j -> 2, otherwise (and for base-2^k digits) 0
+    uint32_t lift_mode() const {
+        if (log_base != 0) return 0;
+        u64 mx = 0, mn = ~0ull;
+        for (u64 q : ct_ctx->moduli) mx = std::max(mx, q);
+        for (u64 q : ksk_ctx->moduli) mn = std::min(mn, q);
+        if (mx < 2 * mn) return 1;          // (moduli < 2^62: no overflow)
+        if (mx < 4 * mn) return 2;
+        return 0;
+    }
+    uint32_t digit_arg() const { return (uint32_t)log_base | (lift_mode() << 8); }
     DevBuf<u64> c0, c0s, c1, c1s;  // [ndigits][Lk][N]
 };
 
@@ -742,7 +754,7 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN>), dim3((unsigned)(npolys * kc.L)),
                dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,
                k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
-               (uint32_t)k_.log_base);
+               k_.digit_arg());
 }
 
 // KeySwitchingKey::key_switch (:241-320): p [npolys][L][N] PowerBasis (poly stride p_stride) ->
@@ -773,7 +785,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
         FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0>), dim3((unsigned)((npolys * kc.L) << G0)),    \
                    dim3(1024), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p,       \
                    k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,                  \
-                   (uint32_t)k_.log_base);                                                                         \
+                   k_.digit_arg());                                                                                \
         break;
     switch (kc.logn) {
         FHE_KS_SPLIT_CASE(2) FHE_KS_SPLIT_CASE(3)

@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                     u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
                     u64 addend_poly_stride, const u64 *__restrict__ k0, const u64 *__restrict__ k0s,
                     const u64 *__restrict__ k1, const u64 *__restrict__ k1s, const DevMod *__restrict__ mods,
-                    const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk, uint32_t digit_shift_bits) {
+                    const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk, uint32_t digit_arg) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ks_threads_c(LOGN);
     constexpr int N = 1 << LOGN;
@@ -663,6 +663,15 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
 #pragma unroll
         for (int e = 0; e < NE; e++) acc1[e] = 0;
     }
+    // `digit_arg` = digit_shift_bits | lift_mode << 8.  lift_mode says how far a source residue can exceed
+    // the key moduli (host-side, from the moduli): 1 -> below 2 q_j (one conditional subtraction lifts
+    // it), 2 -> below 4 q_j (two), 0 -> anything (Barrett).  RNS digits of same-width moduli are mode 1.
+    const uint32_t digit_shift_bits = digit_arg & 0xff, lift_mode = digit_arg >> 8;
+    auto lift = [&](u64 v) -> u64 {
+        if (lift_mode == 1) return csub_n(v, p, pm.np);
+        if (lift_mode == 2) return csub_n(csub_n(v, p2, pm.np2), p, pm.np);
+        return reduce_u64(v, md);
+    };
     // digit_shift_bits == 0: digit i is residue row i of p (RNS decomposition, :256-268).
     // otherwise: base-2^bits digits of the single row 0 (key_switch_decomposition, :323-362).
     const u64 *const src0 = pin + (u64)b * src_poly_stride;
@@ -685,15 +694,15 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
 #pragma unroll
             for (int c = 0; c < CH; c++) {
                 const uint32_t e = 2 * (c * T + tid);
-                lds[padi(e)] = reduce_u64((pre[c].x >> sh) & mask, md);
-                lds[padi(e + 1)] = reduce_u64((pre[c].y >> sh) & mask, md);
+                lds[padi(e)] = lift((pre[c].x >> sh) & mask);
+                lds[padi(e + 1)] = lift((pre[c].y >> sh) & mask);
             }
         } else {
             // (address and mask are recomputed per digit on purpose: hoisted, they cost VGPRs that the
             // N = 16384 variant does not have)
             const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N);
             const u64 mask_i = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
-            tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return reduce_u64((v >> sh) & mask_i, md); });
+            tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return lift((v >> sh) & mask_i); });
         }
         __syncthreads();
         if constexpr (PREFETCH) {
@@ -805,7 +814,7 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
                           const u64 *__restrict__ addend1, u64 addend_poly_stride, const u64 *__restrict__ k0,
                           const u64 *__restrict__ k0s, const u64 *__restrict__ k1, const u64 *__restrict__ k1s,
                           const DevMod *__restrict__ mods, const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk,
-                          uint32_t digit_shift_bits) {
+                          uint32_t digit_arg) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int M = 1 << LOGM, T = M / 8, CH = M / (2 * T), NS = 1 << G0;
     constexpr u64 N = (u64)M << G0;
@@ -817,6 +826,12 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
     const u64 p = md.p, p2 = md.p2;
     const PM pm = make_pm(md);
     const u64x2 *twr = tw + (u64)j * N;
+    const uint32_t digit_shift_bits = digit_arg & 0xff, lift_mode = digit_arg >> 8;  // see ks_fused_kernel
+    auto lift = [&](u64 v) -> u64 {
+        if (lift_mode == 1) return csub_n(v, p, pm.np);
+        if (lift_mode == 2) return csub_n(csub_n(v, p2, pm.np2), p, pm.np);
+        return reduce_u64(v, md);
+    };
     u64 acc0[2 * CH];
     u64x2 *const acc1_lds = reinterpret_cast<u64x2 *>(lds + lds_words(M));
 #pragma unroll
@@ -836,8 +851,8 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
             for (int k = 0; k < NS; k++) v[k] = reinterpret_cast<const u64x2 *>(src + (u64)k * M)[ci];
 #pragma unroll
             for (int k = 0; k < NS; k++) {
-                v[k].x = reduce_u64((v[k].x >> sh) & mask, md);
-                v[k].y = reduce_u64((v[k].y >> sh) & mask, md);
+                v[k].x = lift((v[k].x >> sh) & mask);
+                v[k].y = lift((v[k].y >> sh) & mask);
             }
             // stage s keeps the half of the pairs whose output leads to `sub`
 #pragma unroll

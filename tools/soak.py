@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Determinism soak on the GPU: the C2 ct x ct + relinearise batch is recomputed many times and every
+result must be bit-identical to the first (which bench.py / the parity tests tie to the oracle).  A
+missing wait state in hand-placed asm, a race on LDS or on the workspace pool would show up here as
+a sporadic mismatch rather than as a reproducible wrong answer."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import fhe_rs_amd as fhe
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    n = 8192
+    t = fhe.generate_prime(20, 2 * n, 1 << 20)
+    par = fhe.BfvParameters(n, t, moduli_sizes=[60] * 4)
+    ctx = par.context_at_level(0)
+    L = ctx.nmoduli
+    kk = ctx.synth_uniform(7, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, n)
+    ksk = fhe.KeySwitchingKey(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous())
+    mul = fhe.Multiplicator.default(par, fhe.RelinearizationKey(ksk), 0)
+    gk = fhe.GaloisKey(ksk, 3)
+    a, b = ctx.synth_uniform(7, 0, 0, 2, 1024), ctx.synth_uniform(7, 0, 2, 2, 1024)
+    ref_m, ref_r = mul.multiply(a, b), gk.relinearize(a)
+    torch.cuda.synchronize()
+    bad, t0 = 0, time.time()
+    for i in range(reps):
+        m, r = mul.multiply(a, b), gk.relinearize(a)
+        if not (torch.equal(m, ref_m) and torch.equal(r, ref_r)):
+            bad += 1
+    torch.cuda.synchronize()
+    print(json.dumps(dict(repetitions=reps, ops=reps * 2048, mismatches=bad, seconds=round(time.time() - t0, 1))))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

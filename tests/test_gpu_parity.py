@@ -237,3 +237,11 @@ def test_workspace_trim(fhe):
     assert fhe.workspace_trim() > 0
     assert fhe.workspace_trim() == 0
     cases.case_multiply(fhe, True, nmod=2)
+
+
+def test_c2_full_batch_against_oracle(fhe):
+    """BASELINE config C2 at the benchmark's batch size (1024 pairs, one launch per pipeline step):
+    96 ciphertexts spread over the batch, each whole output compared with the C oracle."""
+    import full_size
+    full_size.check_mul(fhe, n=8192, sizes=[60] * 4, batch=1024, relin=True, cfg=2,
+                        sample=tuple(range(0, 1024, 11)) + (1023, 1022, 1021))

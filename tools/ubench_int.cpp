@@ -44,6 +44,11 @@ __global__ void bench(u64 *out, u64 seed, u64 p, u64 w, u64 ws) {
             if (KIND == 5) x[i] = mul_shoup_lazy(x[i], w, ws, p);                      // Shoup modmul
             if (KIND == 6) fwd_butterfly(x[i], y[i], w, ws, pm);                       // Harvey CT butterfly
             if (KIND == 7) inv_butterfly(x[i], y[i], w, ws, pm);                       // Harvey GS butterfly
+            if (KIND == 9) {  // CT butterfly without the conditional subtraction (headroom of <= 60-bit moduli)
+                const u64 t = mul_shoup_lazy_n(y[i], w, ws, pm.np);
+                y[i] = x[i] + pm.p2 - t;
+                x[i] = x[i] + t;
+            }
             if (KIND == 8) x[i] = x[i] * y[i] + 1;                                     // 64x64 -> lo64
         }
     }
@@ -85,6 +90,7 @@ int main() {
     run<3>("add_u64 x2", 2);
     run<4>("mulhi64 (4 mad_u64_u32)", 1);
     run<8>("mullo64", 1);
+    run<9>("fwd_butterfly without conditional subtraction (not used: needs moduli <= 60 bits)", 1);
     run<5>("mul_shoup_lazy", 1);
     run<6>("fwd_butterfly", 1);
     run<7>("inv_butterfly", 1);

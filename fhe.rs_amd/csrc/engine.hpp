@@ -750,8 +750,19 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
                             const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s) {
     const Ctx &kc = *k_.ksk_ctx;
     const size_t lds = (k::lds_words(1u << LOGN) + (k::ks_acc1_in_lds_c(LOGN) ? (size_t)1 << LOGN : 0)) * sizeof(u64);
-    allow_big_lds(k::ks_fused_kernel<LOGN>, lds);
-    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN>), dim3((unsigned)(npolys * kc.L)),
+    // key moduli below 2^60: the transform runs without most conditional subtractions (fwd_butterfly_narrow)
+    bool narrow = !debug_flag("FHE_NO_NARROW");
+    for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
+    if (narrow) {
+        allow_big_lds((k::ks_fused_kernel<LOGN, true>), lds);
+        FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, true>), dim3((unsigned)(npolys * kc.L)),
+                   dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,
+                   k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
+                   k_.digit_arg());
+        return;
+    }
+    allow_big_lds((k::ks_fused_kernel<LOGN, false>), lds);
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, false>), dim3((unsigned)(npolys * kc.L)),
                dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,
                k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
                k_.digit_arg());

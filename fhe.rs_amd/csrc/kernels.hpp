@@ -161,7 +161,9 @@ __device__ __forceinline__ void fwd_tw_load(FwdTw<G, LOGM, S0, T> &tw_regs, cons
 }
 // PRE: the per-lane twiddles were fetched ahead into tw_regs; otherwise each group fetches its
 // own right before use (fewer live registers).
-template <int G, int LOGM, int S0, int T, bool PRE, class Src = NoSrc>
+// NARROW: moduli below 2^60 and canonical input to stage 0 -- fwd_butterfly_narrow (zq_dev.hpp);
+// values are below 16p on exit instead of 4p.
+template <int G, int LOGM, int S0, int T, bool PRE, bool NARROW = false, class Src = NoSrc>
 __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                          uint32_t tid, const FwdTw<G, LOGM, S0, T> &tw_regs, Src src = Src{}) {
     constexpr bool DIRECT = !std::is_same<Src, NoSrc>::value;
@@ -210,7 +212,10 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
 #pragma unroll
                 for (uint32_t j = 0; j < half; j++) {
                     const uint32_t a = blk * 2 * half + j;
-                    fwd_butterfly(x[a], x[a + half], wv.x, wv.y, pm);
+                    if constexpr (NARROW)
+                        fwd_butterfly_narrow(x[a], x[a + half], wv.x, wv.y, pm, fwd_narrow_corrects(S0 + u));
+                    else
+                        fwd_butterfly(x[a], x[a + half], wv.x, wv.y, pm);
                 }
             }
         }
@@ -226,31 +231,31 @@ constexpr int fwd_plan_g() { return plan_base(LOGM, GM) + (PASS < plan_rem(LOGM,
 // TWPF: fetch the next pass's per-lane twiddles before the barrier (costs their registers across
 // it: the key-switch kernels, which also hold accumulators, leave it off).
 // FSYNC = false: the caller places the barrier after the last pass itself (it has loads to issue first).
-template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, int PASS, int S0, class W, class Src>
+template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, bool NARROW, int PASS, int S0, class W, class Src>
 __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                                 uint32_t tid, const W &tw_regs, Src src) {
     constexpr int G = fwd_plan_g<LOGM, GM, PASS>();
     if constexpr (PASS == 0)
-        fwd_pass<G, LOGM, S0, T, TWPF, Src>(lds, tw, kbase, pm, tid, tw_regs, src);   // (Src != NoSrc: reads `src`, not LDS)
+        fwd_pass<G, LOGM, S0, T, TWPF, NARROW, Src>(lds, tw, kbase, pm, tid, tw_regs, src);   // (Src != NoSrc: reads `src`, not LDS)
     else
-        fwd_pass<G, LOGM, S0, T, TWPF>(lds, tw, kbase, pm, tid, tw_regs);
+        fwd_pass<G, LOGM, S0, T, TWPF, NARROW>(lds, tw, kbase, pm, tid, tw_regs);
     if constexpr (PASS + 1 < plan_np(LOGM, GM)) {
         constexpr int GN = fwd_plan_g<LOGM, GM, PASS + 1>();
         FwdTw<GN, LOGM, S0 + G, T> next;
         if constexpr (TWPF) fwd_tw_load(next, tw, kbase, tid);   // in flight across the barrier
         __syncthreads();
-        ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, PASS + 1, S0 + G>(lds, tw, kbase, pm, tid, next, NoSrc{});
+        ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, PASS + 1, S0 + G>(lds, tw, kbase, pm, tid, next, NoSrc{});
     } else {
         if constexpr (FSYNC) __syncthreads();
     }
 }
-template <int LOGM, int T, int GM = GMAX, bool TWPF = true, bool FSYNC = true, class Src = NoSrc>
+template <int LOGM, int T, int GM = GMAX, bool TWPF = true, bool FSYNC = true, bool NARROW = false, class Src = NoSrc>
 __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                             uint32_t tid, Src src = Src{}) {
     constexpr int G = fwd_plan_g<LOGM, GM, 0>();
     FwdTw<G, LOGM, 0, T> first;
     if constexpr (TWPF) fwd_tw_load(first, tw, kbase, tid);
-    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, 0, 0>(lds, tw, kbase, pm, tid, first, src);
+    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, 0, 0>(lds, tw, kbase, pm, tid, first, src);
 }
 
 // ---------------------------------------------------------------- inverse passes ----
@@ -630,7 +635,7 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
 // F/bfv/ops/mul.rs:224-225; rotation adds substitute(c0) to c0 only); canonical outputs.
 // ks_threads_c(LOGN) threads; thread t owns the 16-byte chunks {c*T + t}, c < CH (or the single
 // coefficient t when the row is smaller than one chunk per thread).
-template <int LOGN>
+template <int LOGN, bool NARROW = false>
 __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
                     u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
@@ -719,7 +724,8 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
             // KPF: the key words of the first two chunks are requested before the barrier that ends the
             // transform, so their L2 latency is spent waiting for the other waves, not after them
             constexpr bool KPF = PREFETCH && CH >= 2;
-            ntt_fwd_lds<LOGN, T, KS_GMAX, false, !KPF>(lds, twr, 1, pm, tid);  // (twiddle prefetch measured: no gain here)
+            // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
+            ntt_fwd_lds<LOGN, T, KS_GMAX, false, !KPF, NARROW>(lds, twr, 1, pm, tid);
             u64x2 kq[KPF ? 8 : 1];
             if constexpr (KPF) {
 #pragma unroll
@@ -753,7 +759,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                 if (c & 1) sched_fence();  // at most two chunks of key loads (32 VGPRs) in flight
             }
         } else {
-            ntt_fwd_lds<LOGN, T, KS_GMAX, false>(lds, twr, 1, pm, tid);
+            ntt_fwd_lds<LOGN, T, KS_GMAX, false, true, NARROW>(lds, twr, 1, pm, tid);
             if (tid < N) {
             const u64 v = lds[padi(tid)];
             acc0[0] = csub_n(acc0[0] + mul_shoup_lazy_n(v, k0[koff + tid], k0s[koff + tid], pm.np), p2, pm.np2);

@@ -115,6 +115,29 @@ FHE_HD void fwd_butterfly(u64 &x, u64 &y, u64 w, u64 ws, const PM &m) {
     y = x + m.p2 - t;
     x = x + t;
 }
+// Forward butterflies for moduli below 2^60 (16p < 2^64): the conditional subtraction on x is not
+// needed every stage.  With every value below b*p before a stage, both outputs are below (b+2)*p
+// (t < 2p whatever y is); fwd_narrow_bound() tracks b over the stages of a transform whose input is
+// canonical and says where the one strong correction (x < 16p -> x < 4p) has to sit.
+constexpr int fwd_narrow_bound(int stage) {  // b before `stage`
+    int b = 1;
+    for (int s = 0; s < stage; s++) b = (b > 14 ? 4 : b) + 2;
+    return b;
+}
+constexpr bool fwd_narrow_corrects(int stage) { return fwd_narrow_bound(stage) > 14; }
+FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, bool correct) {
+    if (correct) {  // x < 16p -> < 4p
+        const u64 p4 = m.p2 << 1, p8 = m.p2 << 2, np4 = m.np2 << 1, np8 = m.np2 << 2;
+        x = csub_n(x, p8, np8);
+        x = csub_n(x, p4, np4);
+    }
+    const u64 t = mul_shoup_lazy_n(y, w, ws, m.np);
+#if defined(FHE_HOST_EMULATION)
+    if (x > ~0ull - m.p2 || x + m.p2 < t) __builtin_trap();  // range tracking broken
+#endif
+    y = x + m.p2 - t;
+    x = x + t;
+}
 FHE_HD void inv_butterfly(u64 &x, u64 &y, u64 z, u64 zs, const PM &m) {
     u64 t = x;
     x = csub_n(y + t, m.p2, m.np2);

@@ -385,16 +385,16 @@ inline void allow_big_lds(K kernel, size_t bytes) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
-template <bool INV>
+template <bool INV, bool NARROW = false>
 inline void launch_ntt_lds(const char *name, uint32_t logm, unsigned grid, hipStream_t s, const u64 *in, u64 *out,
                            const k::RowMap &map, const DevMod *mods, const k::u64x2 *tw, const k::u64x2 *ninv,
                            uint32_t logn, uint32_t prologue) {
     const size_t lds = k::lds_words(1u << logm) * sizeof(u64);
 #define FHE_NTT_CASE(LM)                                                                                        \
     case LM:                                                                                                    \
-        allow_big_lds(k::ntt_kernel<INV, LM>, lds);                                                             \
-        FHE_LAUNCH(name, (k::ntt_kernel<INV, LM>), dim3(grid), dim3(k::ntt_threads_c(LM)), lds, s, in, out, map, \
-                   mods, tw, ninv, logn, prologue);                                                             \
+        allow_big_lds((k::ntt_kernel<INV, LM, NARROW>), lds);                                                   \
+        FHE_LAUNCH(name, (k::ntt_kernel<INV, LM, NARROW>), dim3(grid), dim3(k::ntt_threads_c(LM)), lds, s, in,   \
+                   out, map, mods, tw, ninv, logn, prologue);                                                   \
         break;
     switch (logm) {
         FHE_NTT_CASE(3) FHE_NTT_CASE(4) FHE_NTT_CASE(5) FHE_NTT_CASE(6) FHE_NTT_CASE(7) FHE_NTT_CASE(8)
@@ -412,10 +412,18 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     const uint32_t logn = (uint32_t)c.logn;
     const unsigned rows_total = (unsigned)(npolys * map.rows);
     if (logn <= 14) {
-        if (!inverse)
-            launch_ntt_lds<false>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(), logn,
-                                  prologue);
-        else
+        if (!inverse) {
+            // every modulus of the launch below 2^60: the transform without per-stage conditional subtractions
+            bool narrow = !debug_flag("FHE_NO_NARROW");
+            for (uint32_t r = 0; r < map.rows; r++)
+                narrow = narrow && (c.root->moduli[(size_t)((int32_t)(map.row_begin + r) + map.mod_offset)] >> 60) == 0;
+            if (narrow)
+                launch_ntt_lds<false, true>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(),
+                                            logn, prologue);
+            else
+                launch_ntt_lds<false>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(), logn,
+                                      prologue);
+        } else
             launch_ntt_lds<true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn,
                                  prologue);
         return;

@@ -411,7 +411,8 @@ __device__ __forceinline__ void lds_to_tile(const u64 *lds, u64 *__restrict__ ds
 //   inverse: multiplies by N^-1 (Shoup) when LOGM == logn (native.rs:229-232)
 // Register budget 128 VGPRs = 4 waves/SIMD, which is what the LDS footprint allows anyway
 // (N = 8192: 68 KiB/workgroup -> 2 workgroups of 8 waves per CU).
-template <bool INVERSE, int LOGM>
+// NARROW (forward, whole row, every modulus of the launch below 2^60): see fwd_butterfly_narrow.
+template <bool INVERSE, int LOGM, bool NARROW = false>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     ntt_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map, const DevMod *__restrict__ mods,
                const u64x2 *__restrict__ tw, const u64x2 *__restrict__ ninv, uint32_t logn, uint32_t prologue) {
@@ -438,11 +439,18 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     if constexpr (!INVERSE) {
         // the first pass reads its groups straight from global memory (no tile staging)
         const bool red = prologue == PRO_REDUCE;
-        ntt_fwd_lds<LOGM, T>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) {
+        ntt_fwd_lds<LOGM, T, GMAX, true, true, NARROW>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) {
             const u64 v = src[i];
             return red ? reduce_u64(v, md) : v;
         });
-        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(csub_n(v, p2, pm.np2), p, pm.np); });
+        if constexpr (NARROW) {  // < 16p -> canonical
+            const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
+            lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) {
+                return csub_n(csub_n(csub_n(csub_n(v, p8, np8), p4, np4), p2, pm.np2), p, pm.np);
+            });
+        } else {
+            lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(csub_n(v, p2, pm.np2), p, pm.np); });
+        }
     } else {
         InvTwFirst<LOGM, T> tw0;
         inv_tw_load(tw0, twr, logn, sub, tid);   // issued ahead of the tile loads: one latency for both

@@ -798,19 +798,27 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     // Rows larger than LDS (N >= 32768): one workgroup per 8192-point sub-block, the first
     // logn - 13 stages folded into its loader (ks_fused_split_kernel).
     const size_t lds = (k::lds_words(8192) + 8192) * sizeof(u64);
+    bool narrow = !debug_flag("FHE_NO_NARROW");
+    for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
+#define FHE_KS_SPLIT_LAUNCH(G0, NW)                                                                                \
+    allow_big_lds((k::ks_fused_split_kernel<G0, 13, NW>), lds);                                                    \
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0, 13, NW>), dim3((unsigned)((npolys * kc.L) << G0)), \
+               dim3(1024), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p,  \
+               k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg())
 #define FHE_KS_SPLIT_CASE(G0)                                                                                      \
     case 13 + G0:                                                                                                  \
-        allow_big_lds(k::ks_fused_split_kernel<G0>, lds);                                                          \
-        FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0>), dim3((unsigned)((npolys * kc.L) << G0)),    \
-                   dim3(1024), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p,       \
-                   k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,                  \
-                   k_.digit_arg());                                                                                \
+        if (narrow) {                                                                                              \
+            FHE_KS_SPLIT_LAUNCH(G0, true);                                                                         \
+        } else {                                                                                                   \
+            FHE_KS_SPLIT_LAUNCH(G0, false);                                                                        \
+        }                                                                                                          \
         break;
     switch (kc.logn) {
         FHE_KS_SPLIT_CASE(2) FHE_KS_SPLIT_CASE(3)
         default: throw StatusError(E_ARG, "unsupported key-switch row size");
     }
 #undef FHE_KS_SPLIT_CASE
+#undef FHE_KS_SPLIT_LAUNCH
 }
 
 // switch_down_to (M/rq/mod.rs:498-507) for Ntt polys living over `from`, `iters` times:

@@ -161,9 +161,9 @@ __device__ __forceinline__ void fwd_tw_load(FwdTw<G, LOGM, S0, T> &tw_regs, cons
 }
 // PRE: the per-lane twiddles were fetched ahead into tw_regs; otherwise each group fetches its
 // own right before use (fewer live registers).
-// NARROW: moduli below 2^60 and canonical input to stage 0 -- fwd_butterfly_narrow (zq_dev.hpp);
-// values are below 16p on exit instead of 4p.
-template <int G, int LOGM, int S0, int T, bool PRE, bool NARROW = false, class Src = NoSrc>
+// NARROW = b0 > 0: moduli below 2^60 and input to stage 0 below b0*p (1: canonical) --
+// fwd_butterfly_narrow (zq_dev.hpp); values are below 16p on exit instead of 4p.
+template <int G, int LOGM, int S0, int T, bool PRE, int NARROW = 0, class Src = NoSrc>
 __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                          uint32_t tid, const FwdTw<G, LOGM, S0, T> &tw_regs, Src src = Src{}) {
     constexpr bool DIRECT = !std::is_same<Src, NoSrc>::value;
@@ -212,8 +212,8 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
 #pragma unroll
                 for (uint32_t j = 0; j < half; j++) {
                     const uint32_t a = blk * 2 * half + j;
-                    if constexpr (NARROW)
-                        fwd_butterfly_narrow(x[a], x[a + half], wv.x, wv.y, pm, fwd_narrow_corrects(S0 + u));
+                    if constexpr (NARROW > 0)
+                        fwd_butterfly_narrow(x[a], x[a + half], wv.x, wv.y, pm, fwd_narrow_corrects(S0 + u, NARROW));
                     else
                         fwd_butterfly(x[a], x[a + half], wv.x, wv.y, pm);
                 }
@@ -231,7 +231,7 @@ constexpr int fwd_plan_g() { return plan_base(LOGM, GM) + (PASS < plan_rem(LOGM,
 // TWPF: fetch the next pass's per-lane twiddles before the barrier (costs their registers across
 // it: the key-switch kernels, which also hold accumulators, leave it off).
 // FSYNC = false: the caller places the barrier after the last pass itself (it has loads to issue first).
-template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, bool NARROW, int PASS, int S0, class W, class Src>
+template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, int NARROW, int PASS, int S0, class W, class Src>
 __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                                 uint32_t tid, const W &tw_regs, Src src) {
     constexpr int G = fwd_plan_g<LOGM, GM, PASS>();
@@ -249,7 +249,7 @@ __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restric
         if constexpr (FSYNC) __syncthreads();
     }
 }
-template <int LOGM, int T, int GM = GMAX, bool TWPF = true, bool FSYNC = true, bool NARROW = false, class Src = NoSrc>
+template <int LOGM, int T, int GM = GMAX, bool TWPF = true, bool FSYNC = true, int NARROW = 0, class Src = NoSrc>
 __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                             uint32_t tid, Src src = Src{}) {
     constexpr int G = fwd_plan_g<LOGM, GM, 0>();
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     if constexpr (!INVERSE) {
         // the first pass reads its groups straight from global memory (no tile staging)
         const bool red = prologue == PRO_REDUCE;
-        ntt_fwd_lds<LOGM, T, GMAX, true, true, NARROW>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) {
+        ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? 1 : 0)>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) {
             const u64 v = src[i];
             return red ? reduce_u64(v, md) : v;
         });
@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
             // transform, so their L2 latency is spent waiting for the other waves, not after them
             constexpr bool KPF = PREFETCH && CH >= 2;
             // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
-            ntt_fwd_lds<LOGN, T, KS_GMAX, false, !KPF, NARROW>(lds, twr, 1, pm, tid);
+            ntt_fwd_lds<LOGN, T, KS_GMAX, false, !KPF, (NARROW ? 1 : 0)>(lds, twr, 1, pm, tid);
             u64x2 kq[KPF ? 8 : 1];
             if constexpr (KPF) {
 #pragma unroll
@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                 if (c & 1) sched_fence();  // at most two chunks of key loads (32 VGPRs) in flight
             }
         } else {
-            ntt_fwd_lds<LOGN, T, KS_GMAX, false, true, NARROW>(lds, twr, 1, pm, tid);
+            ntt_fwd_lds<LOGN, T, KS_GMAX, false, true, (NARROW ? 1 : 0)>(lds, twr, 1, pm, tid);
             if (tid < N) {
             const u64 v = lds[padi(tid)];
             acc0[0] = csub_n(acc0[0] + mul_shoup_lazy_n(v, k0[koff + tid], k0s[koff + tid], pm.np), p2, pm.np2);
@@ -821,7 +821,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
 // branch leading to `sub` is evaluated (2^G0 - 1 Shoup multiplications per coefficient instead
 // of G0/2 amortised, but no round trip of the lifted row through HBM); the remaining 13 stages
 // run in LDS with twiddle base 2^G0 + sub, exactly like ntt_kernel's sub-block mode.
-template <int G0, int LOGM = 13>
+template <int G0, int LOGM = 13, bool NARROW = false>
 __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
     ks_fused_split_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0,
                           u64 *__restrict__ out1, u64 out_poly_stride, const u64 *__restrict__ addend0,
@@ -887,7 +887,8 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
             lds[padi(2 * ci + 1)] = v[0].y;
         }
         __syncthreads();
-        ntt_fwd_lds<LOGM, T, KS_GMAX, false>(lds, twr, NS + sub, pm, tid);
+        // (NARROW: the folded loader stages leave values below 4p)
+        ntt_fwd_lds<LOGM, T, KS_GMAX, false, true, (NARROW ? 4 : 0)>(lds, twr, NS + sub, pm, tid);
         const u64 koff = ((u64)i * lk + j) * N + (u64)sub * M;
         const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
         const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);

@@ -118,13 +118,13 @@ FHE_HD void fwd_butterfly(u64 &x, u64 &y, u64 w, u64 ws, const PM &m) {
 // Forward butterflies for moduli below 2^60 (16p < 2^64): the conditional subtraction on x is not
 // needed every stage.  With every value below b*p before a stage, both outputs are below (b+2)*p
 // (t < 2p whatever y is); fwd_narrow_bound() tracks b over the stages of a transform whose input is
-// canonical and says where the one strong correction (x < 16p -> x < 4p) has to sit.
-constexpr int fwd_narrow_bound(int stage) {  // b before `stage`
-    int b = 1;
+// below b0*p (1: canonical) and says where the one strong correction (x < 16p -> x < 4p) has to sit.
+constexpr int fwd_narrow_bound(int stage, int b0 = 1) {  // b before `stage`, b0 before stage 0
+    int b = b0;
     for (int s = 0; s < stage; s++) b = (b > 14 ? 4 : b) + 2;
     return b;
 }
-constexpr bool fwd_narrow_corrects(int stage) { return fwd_narrow_bound(stage) > 14; }
+constexpr bool fwd_narrow_corrects(int stage, int b0 = 1) { return fwd_narrow_bound(stage, b0) > 14; }
 FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, bool correct) {
     if (correct) {  // x < 16p -> < 4p
         const u64 p4 = m.p2 << 1, p8 = m.p2 << 2, np4 = m.np2 << 1, np8 = m.np2 << 2;

@@ -423,9 +423,17 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
             else
                 launch_ntt_lds<false>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(), logn,
                                       prologue);
-        } else
-            launch_ntt_lds<true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn,
-                                 prologue);
+        } else {
+            bool narrow = !debug_flag("FHE_NO_NARROW");
+            for (uint32_t r = 0; r < map.rows; r++)
+                narrow = narrow && (c.root->moduli[(size_t)((int32_t)(map.row_begin + r) + map.mod_offset)] >> 60) == 0;
+            if (narrow)
+                launch_ntt_lds<true, true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(),
+                                           logn, prologue);
+            else
+                launch_ntt_lds<true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn,
+                                     prologue);
+        }
         return;
     }
     const uint32_t logm = 13, g0 = logn - logm, m = 1u << logm;

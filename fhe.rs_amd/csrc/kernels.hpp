@@ -294,7 +294,12 @@ __device__ __forceinline__ void inv_tw_load(InvTw<G, LOGM, V0, T> &tw_regs, cons
         }
     }
 }
-template <int G, int LOGM, int V0, int T>
+// NARROW (moduli below 2^60, 16p < 2^64): the sum output of a Gentleman-Sande butterfly is left
+// unreduced -- its bound is the sum of the input bounds, the difference output goes through the Shoup
+// multiplication and is below 2p again -- and `bnd[]` tracks every register's bound (in units of p)
+// through the fully unrolled stages, so the conditional subtractions shrink to the few needed to keep
+// sums below 16p and to hand the next pass values below 2p (7 instead of 12 per radix-8 group).
+template <int G, int LOGM, int V0, int T, bool NARROW = false>
 __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
                                          const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv,
                                          const InvTw<G, LOGM, V0, T> &tw_regs) {
@@ -314,6 +319,15 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
         u64 x[R];
 #pragma unroll
         for (uint32_t e = 0; e < R; e++) x[e] = g[padi(e << V0)];
+        int bnd[R];  // NARROW: x[e] < bnd[e] * p (compile-time after unrolling); powers of two
+#pragma unroll
+        for (uint32_t e = 0; e < R; e++) bnd[e] = 2;
+        // x < bnd*p -> x < (bnd/2)*p
+        auto halve = [&](u64 &v, int &bd) {
+            const int sh = bd == 16 ? 2 : bd == 8 ? 1 : 0;   // (bd/2) * p = p2 << sh for bd = 16, 8, 4
+            v = csub_n(v, pm.p2 << sh, pm.np2 << sh);
+            bd /= 2;
+        };
 #pragma unroll
         for (int u = 0; u < G; u++) {
             const uint32_t nblk = R >> (u + 1);
@@ -324,13 +338,44 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
 #pragma unroll
                 for (uint32_t j = 0; j < (1u << u); j++) {
                     const uint32_t a = blk * (2u << u) + j, b = a + (1u << u);
-                    if (V0 + G == LOGM && u == G - 1 && fold) {
+                    if constexpr (NARROW) {
+                        // keep x[a] + x[b] and x[a] + bnd[b]*p below 16p
+                        // (straight-line ifs, not loops: they fold once the stage loops are unrolled)
+                        if (bnd[a] + bnd[b] > 16) halve(x[a], bnd[a]);
+                        if (bnd[a] + bnd[b] > 16) halve(x[b], bnd[b]);
+                        const u64 t = x[a], y = x[b];
+                        const int shb = bnd[b] == 16 ? 3 : bnd[b] == 8 ? 2 : bnd[b] == 4 ? 1 : 0;  // bnd[b]*p = p2 << shb
+                        const u64 diff = (pm.p2 << shb) + t - y;
+#if defined(FHE_HOST_EMULATION)
+                        if (y >= (pm.p2 << shb) || t >= (pm.p >> 0) * (u64)bnd[a] || bnd[a] + bnd[b] > 16)
+                            __builtin_trap();  // range tracking broken
+#endif
+                        if (V0 + G == LOGM && u == G - 1 && fold) {  // both outputs below 2p
+                            x[a] = mul_shoup_lazy_n(y + t, ninv.x, ninv.y, pm.np);
+                            x[b] = mul_shoup_lazy_n(diff, zninv.x, zninv.y, pm.np);
+                        } else {
+                            x[a] = y + t;
+                            x[b] = mul_shoup_lazy_n(diff, zv.x, zv.y, pm.np);
+                        }
+                        bnd[a] = bnd[a] + bnd[b];  // (kept independent of the run-time `fold`)
+                        bnd[b] = 2;
+                    } else if (V0 + G == LOGM && u == G - 1 && fold) {
                         const u64 t = x[a], y = x[b];
                         x[a] = mul_shoup_lazy_n(y + t, ninv.x, ninv.y, pm.np);
                         x[b] = mul_shoup_lazy_n(pm.p2 + t - y, zninv.x, zninv.y, pm.np);
                     } else {
                         inv_butterfly(x[a], x[b], zv.x, zv.y, pm);
                     }
+                }
+            }
+        }
+        if constexpr (NARROW) {  // the next pass (and the epilogue) expect values below 2p
+            if (!(V0 + G == LOGM && fold)) {
+#pragma unroll
+                for (uint32_t e = 0; e < R; e++) {
+                    if (bnd[e] > 8) halve(x[e], bnd[e]);
+                    if (bnd[e] > 4) halve(x[e], bnd[e]);
+                    if (bnd[e] > 2) halve(x[e], bnd[e]);
                 }
             }
         }
@@ -348,17 +393,17 @@ constexpr int inv_plan_g() {
 }
 template <int LOGM, int T>
 using InvTwFirst = InvTw<inv_plan_g<LOGM, 0>(), LOGM, 0, T>;
-template <int LOGM, int T, int PASS = 0, int V0 = 0, class W>
+template <int LOGM, int T, int PASS = 0, int V0 = 0, bool NARROW = false, class W>
 __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
                                             const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv,
                                             const W &tw_regs) {
     constexpr int G = inv_plan_g<LOGM, PASS>();
-    inv_pass<G, LOGM, V0, T>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, tw_regs);
+    inv_pass<G, LOGM, V0, T, NARROW>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, tw_regs);
     if constexpr (PASS + 1 < plan_np(LOGM, GMAX)) {
         InvTw<inv_plan_g<LOGM, PASS + 1>(), LOGM, V0 + G, T> next;
         inv_tw_load(next, itw, logn, sub, tid);   // in flight across the barrier
         __syncthreads();
-        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, next);
+        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G, NARROW>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, next);
     } else {
         __syncthreads();
     }
@@ -462,7 +507,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         else
             tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
         __syncthreads();
-        ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1], tw0);
+        ntt_inv_lds<LOGM, T, 0, 0, NARROW>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1], tw0);
         if (whole)
             lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
         else

@@ -465,11 +465,12 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
 // Fused tensor + inverse NTT over the extended basis (rows fit LDS: logn <= 14).
 inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s) {
     const size_t lds = k::lds_words((uint32_t)e.n) * sizeof(u64);
+    const unsigned groups = (unsigned)((e.L * nb + 7) / 8);  // 8 (row, pair) combinations x 3 slots per group
 #define FHE_TI_CASE(LM)                                                                                       \
     case LM:                                                                                                  \
         allow_big_lds(k::tensor_intt_kernel<LM>, lds);                                                        \
-        FHE_LAUNCH("tensor_intt", (k::tensor_intt_kernel<LM>), dim3((unsigned)e.L, (unsigned)nb, 3),          \
-                   dim3(k::ntt_threads_c(LM)), lds, s, ts, out, e.dmods(), e.ditw(), e.dninv(), (uint32_t)e.L); \
+        FHE_LAUNCH("tensor_intt", (k::tensor_intt_kernel<LM>), dim3(groups * 24), dim3(k::ntt_threads_c(LM)),  \
+                   lds, s, ts, out, e.dmods(), e.ditw(), e.dninv(), (uint32_t)e.L, (uint32_t)nb);              \
         break;
     switch (e.logn) {
         FHE_TI_CASE(3) FHE_TI_CASE(4) FHE_TI_CASE(5) FHE_TI_CASE(6) FHE_TI_CASE(7) FHE_TI_CASE(8)
@@ -1043,13 +1044,17 @@ inline size_t &chunk_setting() {
     static size_t chunk = 0;
     return chunk;
 }
-inline size_t default_chunk(const Ctx &base, const Ctx &mulc) {
-    if (chunk_setting()) return chunk_setting();
-    // The path is integer-issue bound, not HBM bound, so launches are made as
-    // large as a bounded workspace allows (every launch should cover >> 512 workgroup slots).
+inline size_t default_chunk(const Ctx &base, const Ctx &mulc, size_t batch) {
+    if (chunk_setting()) return std::min(batch, chunk_setting());
+    // Every launch should cover >> 512 workgroup slots (small chunks lose to tail effects: 64 pairs per
+    // chunk is 15 % slower at C2), but beyond ~3 GiB of workspace nothing is gained and the step-to-step
+    // reuse in the 256 MiB Infinity Cache is lost (chunks of 256-512 pairs measured 1.5 % ahead of one
+    // 1024-pair chunk).  The batch is split into equal chunks under that budget.
     const size_t per_ct = (7 * mulc.L + 7 * base.L) * mulc.n * sizeof(u64);
-    const size_t budget = (size_t)8 << 30;
-    return std::max<size_t>(1, std::min<size_t>(budget / per_ct, 4096));
+    const size_t budget = (size_t)3 << 30;
+    const size_t cap = std::max<size_t>(1, std::min<size_t>(budget / per_ct, 4096));
+    const size_t nchunks = (batch + cap - 1) / cap;
+    return (batch + nchunks - 1) / nchunks;
 }
 
 // Ciphertext::switch_down (F/bfv/ciphertext.rs:148-161): ct [b][nparts][L][N] Ntt -> [b][nparts][L-1][N] Ntt
@@ -1095,7 +1100,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     const u64 PL = (u64)L * N, PK = (u64)K * N;
     const size_t parts = m.out_parts();
     if (!batch) return;
-    const size_t chunk = std::min(batch, default_chunk(b, e));
+    const size_t chunk = default_chunk(b, e, batch);
     // the extenders copy the shared prefix rows verbatim; when both share all L rows the tensor
     // kernel reads those rows from the inputs directly and the copy is skipped
     const bool skip_copy = m.ext_lhs->ncommon == L && m.ext_rhs->ncommon == L && !debug_flag("FHE_NO_SKIP_COPY");
@@ -1113,7 +1118,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         // larger rows: element-wise tensor kernel, then the two-kernel inverse NTT.
         const bool fused_tensor = e.logn <= 14 && !debug_flag("FHE_NO_TENSOR_FUSION");
         if (fused_tensor) {
-            require(nb <= 32768, E_ARG, "chunk too large for the fused tensor kernel");  // grid.y limit
+            require(nb <= 32768, E_ARG, "chunk too large for the fused tensor kernel");  // 3*K*nb blocks in a 1-D grid
             k::TensorSrc ts{extL.u(), extR.u(), skip_copy ? l : nullptr, skip_copy ? r : nullptr, (uint32_t)L,
                             (uint32_t)L};
             launch_tensor_intt(e, ts, ten.u(), nb, s);

@@ -530,13 +530,20 @@ struct TensorSrc {
 template <int LOGM>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     tensor_intt_kernel(TensorSrc ts, u64 *__restrict__ out, const DevMod *__restrict__ mods,
-                       const u64x2 *__restrict__ itw, const u64x2 *__restrict__ ninv, uint32_t nrows) {
+                       const u64x2 *__restrict__ itw, const u64x2 *__restrict__ ninv, uint32_t nrows, uint32_t nb) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ntt_threads_c(LOGM);
     constexpr int M = 1 << LOGM;
     constexpr int CH = tile_chunks_c(LOGM, T);
     const uint32_t tid = threadIdx.x;
-    const uint32_t r = blockIdx.x, b = blockIdx.y, slot = blockIdx.z, nb = gridDim.y;
+    // XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (id mod 8), each with its
+    // own L2.  The three slots of one (row, ciphertext) pair read the same four operand rows, so their
+    // ids are 8 apart: same XCD, dispatched back to back, and the re-reads hit that L2 instead of HBM
+    // (a (row, pair, slot) 3-D grid put them nb*K blocks apart: 1.8x the algorithmic HBM traffic).
+    const uint32_t t8 = blockIdx.x >> 3, grp = t8 / 3, slot = t8 - 3 * grp;
+    const uint32_t combo = grp * 8 + (blockIdx.x & 7);
+    if (combo >= nrows * nb) return;  // (block-uniform) tail of the rounded-up grid
+    const uint32_t b = to_sgpr(combo / nrows), r = combo - b * nrows;
     const DevMod md = mods[r];
     const u64 p = md.p;
     const PM pm = make_pm(md);
@@ -701,6 +708,8 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     constexpr int CH = tile_chunks_c(LOGN, T);
     constexpr int NE = CH > 0 ? 2 * CH : 1;  // coefficients owned by a thread
     const uint32_t tid0 = threadIdx.x;
+    // (an XCD-aware order that puts the lk workgroups of one polynomial on one L2, as tensor_intt_kernel
+    // does, was measured: no change -- this kernel is nowhere near the HBM limit)
     const uint32_t b = to_sgpr(blockIdx.x / lk), j = blockIdx.x - b * lk;
     const DevMod md = mods[j];
     const u64 p = md.p, p2 = md.p2;

@@ -149,7 +149,8 @@ def main():
     # 2*Lk rows and reads 2 addend rows per key modulus (the key itself is cache resident).
     alg_rows = {
         "ntt_inv": 2 * (4 * L),                       # extend: inverse NTT of the 4 input polynomials
-        "tensor_intt": 8 * K + 3 * K,                 # fused tensor + inverse NTT: reads 2+4+2, writes 3 rows per modulus
+        "tensor_intt": 4 * K + 3 * K,                 # fused tensor + inverse NTT (SURVEY §8d "7K"): the 4 operand rows
+                                                      # once (the slots' re-reads are L2 hits, see the kernel), 3 rows out
         "ntt_fwd": 2 * (4 * (K - L) + 2 * L),         # new rows of the 4 extended polys + (c0, c1)
         "key_switch_fused": L * L + 4 * L,            # L digit rows per key modulus, 2 addend rows + 2 output rows
         "scale_extend": 4 * (L + (K - L)),            # extend 4 polys: L rows in, K-L new rows out

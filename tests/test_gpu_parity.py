@@ -245,3 +245,47 @@ def test_c2_full_batch_against_oracle(fhe):
     import full_size
     full_size.check_mul(fhe, n=8192, sizes=[60] * 4, batch=1024, relin=True, cfg=2,
                         sample=tuple(range(0, 1024, 11)) + (1023, 1022, 1021))
+
+
+def test_dev_entry_points_are_graph_capturable(fhe):
+    """The `_dev` entry points enqueue kernels only (no allocation, copy or synchronisation once the
+    stream's workspace exists), so a call sequence can be captured into a hipGraph and replayed --
+    the launch-bound small-batch case (one ciphertext pair: ten launches of a few microseconds each)."""
+    import torch
+    import full_size
+    from fhe_oracle import bfv as obfv
+    n, sizes = 8192, [60] * 4
+    q = obfv.generate_moduli(sizes, n)
+    par = fhe.BfvParameters(n, full_size.plaintext_modulus(n), moduli=q)
+    ctx = par.context_at_level(0)
+    c0, c1 = full_size.device_key(ctx, 5, len(q))
+    ksk = fhe.KeySwitchingKey(ctx, ctx, c0, c1)
+    m = fhe.Multiplicator.default(par, fhe.RelinearizationKey(ksk), 0)
+    gk = fhe.GaloisKey(ksk, 3)
+    a, b = ctx.synth_uniform(9, 0, 0, 2, 2), ctx.synth_uniform(9, 0, 2, 2, 2)
+    want_m = m.multiply(a, b)
+    want_r = gk.relinearize(want_m)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):      # warm-up on the capture stream: its workspace blocks get allocated
+        gk.relinearize(m.multiply(a, b))
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        got_m = m.multiply(a, b)
+        got_r = gk.relinearize(got_m)
+    got_m.zero_()
+    got_r.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got_m, want_m) and torch.equal(got_r, want_r)
+    # new inputs through the captured graph (static input buffers, as with any graph)
+    a2, b2 = ctx.synth_uniform(10, 0, 0, 2, 2), ctx.synth_uniform(10, 0, 2, 2, 2)
+    want2 = m.multiply(a2, b2)
+    a.copy_(a2)
+    b.copy_(b2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got_m, want2)

@@ -615,6 +615,8 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     inv_tw_load(tw0, itw + (u64)r * M, LOGM, 0, tid);   // in flight across the barrier (the loader needs the registers)
     __syncthreads();
     u64 *dst = out + ((u64)slot * nb + b) * pk + (u64)r * M;
+    // (a block-uniform branch to the narrow inverse passes for this launch's 60-bit rows was measured:
+    // 128 VGPRs, spills and twice the code -- 2 % slower)
     ntt_inv_lds<LOGM, T>(lds, itw + (u64)r * M, LOGM, 0, pm, tid, true, ninv[2 * r], ninv[2 * r + 1], tw0);
     lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
 }

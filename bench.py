@@ -6,7 +6,9 @@ crates/fhe/src/bfv/ops/mul.rs:165-243) over one batch of synthetic ciphertext pa
 Workload (config C2, BASELINE.json configs[1]): N = 8192, 4 x 60-bit RNS moduli
 (K = 9 rows in the extended basis), batch = 1024 ciphertext pairs per GPU, relin key at level 0.
 Inputs (and the synthetic relin key) are generated ON the device by the shared splitmix64
-counter generator and are resident in HBM before the timed region starts.
+counter generator and are resident in HBM before the timed region starts.  Setup also makes one
+call of the path so that the stream's workspace exists (a one-time hipMalloc); the W warmup steps
+and the K timed steps follow.
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), independent
 ciphertexts sharded by rank, no data-path collective ("weak" scaling: per-GPU batch is fixed);
@@ -126,6 +128,10 @@ def main():
         _lib.check(_lib.lib().fhe_bfv_mul_dev(mul._h, C.c_void_p(lhs.data_ptr()), C.c_void_p(rhs.data_ptr()),
                                               C.c_void_p(out.data_ptr()), batch, C.c_void_p(stream)))
 
+    # setup, not a step: the first call on a stream allocates that stream's workspace (hipMalloc of ~3 GiB)
+    # and loads the kernels' code objects -- one-time state, like the tables and the key above
+    step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

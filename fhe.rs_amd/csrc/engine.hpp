@@ -462,23 +462,10 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     }
 }
 
-// Fused tensor + inverse NTT over the extended basis (rows fit LDS: logn <= 14).
-inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s) {
-    const size_t lds = k::lds_words((uint32_t)e.n) * sizeof(u64);
-    const unsigned groups = (unsigned)((e.L * nb + 7) / 8);  // 8 (row, pair) combinations x 3 slots per group
-#define FHE_TI_CASE(LM)                                                                                       \
-    case LM:                                                                                                  \
-        allow_big_lds(k::tensor_intt_kernel<LM>, lds);                                                        \
-        FHE_LAUNCH("tensor_intt", (k::tensor_intt_kernel<LM>), dim3(groups * 24), dim3(k::ntt_threads_c(LM)),  \
-                   lds, s, ts, out, e.dmods(), e.ditw(), e.dninv(), (uint32_t)e.L, (uint32_t)nb);              \
-        break;
-    switch (e.logn) {
-        FHE_TI_CASE(3) FHE_TI_CASE(4) FHE_TI_CASE(5) FHE_TI_CASE(6) FHE_TI_CASE(7) FHE_TI_CASE(8)
-        FHE_TI_CASE(9) FHE_TI_CASE(10) FHE_TI_CASE(11) FHE_TI_CASE(12) FHE_TI_CASE(13) FHE_TI_CASE(14)
-        default: throw StatusError(E_ARG, "unsupported tensor tile size");
-    }
-#undef FHE_TI_CASE
-}
+// Fused tensor + inverse NTT over the extended basis.  Rows that fit LDS (logn <= 14): one kernel.
+// N = 32768 / 65536: the same kernel on 8192-point sub-blocks, then the global inverse stages.
+// (Defined after full_map.)
+inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s);
 
 // all rows of [npolys][rows_in_poly][N], modulus = row index
 inline k::RowMap full_map(const Ctx &c, size_t rows_in_poly) {
@@ -489,6 +476,38 @@ inline k::RowMap full_map(const Ctx &c, size_t rows_in_poly) {
     m.src_row_fixed = -1;
     m.src_poly_stride = m.dst_poly_stride = (u64)rows_in_poly * c.n;
     return m;
+}
+
+inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s) {
+    const uint32_t logn = (uint32_t)e.logn, logm = logn <= 14 ? logn : 13;
+    const size_t lds = k::lds_words(1u << logm) * sizeof(u64);
+    // 8 (row, pair, sub-block) combinations x 3 slots per group
+    const unsigned groups = (unsigned)((((e.L * nb) << (logn - logm)) + 7) / 8);
+#define FHE_TI_LAUNCH(LM, SUB)                                                                                  \
+    allow_big_lds((k::tensor_intt_kernel<LM, SUB>), lds);                                                       \
+    FHE_LAUNCH("tensor_intt", (k::tensor_intt_kernel<LM, SUB>), dim3(groups * 24), dim3(k::ntt_threads_c(LM)),  \
+               lds, s, ts, out, e.dmods(), e.ditw(), e.dninv(), (uint32_t)e.L, (uint32_t)nb, logn);
+#define FHE_TI_CASE(LM) \
+    case LM: { FHE_TI_LAUNCH(LM, false) } break;
+    if (logn > 14) {
+        FHE_TI_LAUNCH(13, true)
+        const unsigned gth = 256, gblocks = (unsigned)(nb * 3 * e.L) * ((1u << logm) / gth);
+        const k::RowMap m = full_map(e, e.L);
+        if (logn - logm == 2)
+            FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 2>), dim3(gblocks), dim3(gth), 0, s, out, out, m,
+                       e.dmods(), e.ditw(), e.dninv(), logn, (uint32_t)k::PRO_NONE);
+        else
+            FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 3>), dim3(gblocks), dim3(gth), 0, s, out, out, m,
+                       e.dmods(), e.ditw(), e.dninv(), logn, (uint32_t)k::PRO_NONE);
+        return;
+    }
+    switch (logn) {
+        FHE_TI_CASE(3) FHE_TI_CASE(4) FHE_TI_CASE(5) FHE_TI_CASE(6) FHE_TI_CASE(7) FHE_TI_CASE(8)
+        FHE_TI_CASE(9) FHE_TI_CASE(10) FHE_TI_CASE(11) FHE_TI_CASE(12) FHE_TI_CASE(13) FHE_TI_CASE(14)
+        default: throw StatusError(E_ARG, "unsupported tensor tile size");
+    }
+#undef FHE_TI_CASE
+#undef FHE_TI_LAUNCH
 }
 
 inline void ntt_polys(const Ctx &c, bool inverse, const u64 *in, u64 *out, size_t npolys, hipStream_t s) {
@@ -1116,7 +1135,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         // TENSOR (mul.rs:198-201) + the inverse NTT of the down-scaler (M/rq/scaler.rs:69-79):
         // ten [3][nb][K][N] ends up in PowerBasis.  Rows that fit LDS: one fused kernel;
         // larger rows: element-wise tensor kernel, then the two-kernel inverse NTT.
-        const bool fused_tensor = e.logn <= 14 && !debug_flag("FHE_NO_TENSOR_FUSION");
+        const bool fused_tensor = e.logn <= 16 && !debug_flag("FHE_NO_TENSOR_FUSION");
         if (fused_tensor) {
             require(nb <= 32768, E_ARG, "chunk too large for the fused tensor kernel");  // 3*K*nb blocks in a 1-D grid
             k::TensorSrc ts{extL.u(), extR.u(), skip_copy ? l : nullptr, skip_copy ? r : nullptr, (uint32_t)L,

@@ -527,38 +527,47 @@ struct TensorSrc {
     const u64 *extL, *extR, *lhs, *rhs;
     uint32_t ncommon, lrows;
 };
-template <int LOGM>
+// SUB (rows larger than LDS, N = 2^logn > M): a workgroup handles one M-point sub-block -- tensor product
+// in the loader, the inverse stages that stay inside the sub-block -- and leaves values below 2p for
+// ntt_global_kernel<true, .>, which finishes the transform (so the Ntt-domain tensor never touches HBM
+// at N = 32768 / 65536 either).
+template <int LOGM, bool SUB = false>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     tensor_intt_kernel(TensorSrc ts, u64 *__restrict__ out, const DevMod *__restrict__ mods,
-                       const u64x2 *__restrict__ itw, const u64x2 *__restrict__ ninv, uint32_t nrows, uint32_t nb) {
+                       const u64x2 *__restrict__ itw, const u64x2 *__restrict__ ninv, uint32_t nrows, uint32_t nb,
+                       uint32_t logn_arg) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ntt_threads_c(LOGM);
     constexpr int M = 1 << LOGM;
     constexpr int CH = tile_chunks_c(LOGM, T);
     const uint32_t tid = threadIdx.x;
+    const uint32_t logn = SUB ? logn_arg : (uint32_t)LOGM;
+    const uint32_t lsub = logn - LOGM;  // log2(sub-blocks per row); 0 unless SUB
     // XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (id mod 8), each with its
     // own L2.  The three slots of one (row, ciphertext) pair read the same four operand rows, so their
     // ids are 8 apart: same XCD, dispatched back to back, and the re-reads hit that L2 instead of HBM
     // (a (row, pair, slot) 3-D grid put them nb*K blocks apart: 1.8x the algorithmic HBM traffic).
     const uint32_t t8 = blockIdx.x >> 3, grp = t8 / 3, slot = t8 - 3 * grp;
     const uint32_t combo = grp * 8 + (blockIdx.x & 7);
-    if (combo >= nrows * nb) return;  // (block-uniform) tail of the rounded-up grid
-    const uint32_t b = to_sgpr(combo / nrows), r = combo - b * nrows;
+    if (combo >= (nrows * nb) << lsub) return;  // (block-uniform) tail of the rounded-up grid
+    const uint32_t sub = combo & ((1u << lsub) - 1), rowb = combo >> lsub;
+    const uint32_t b = to_sgpr(rowb / nrows), r = rowb - b * nrows;
     const DevMod md = mods[r];
     const u64 p = md.p;
     const PM pm = make_pm(md);
-    const u64 pk = (u64)nrows << LOGM;
+    const u64 pk = (u64)nrows << logn;
+    const u64 roff = ((u64)r << logn) + (u64)sub * M;  // this tile inside a polynomial
     const u64 *a0, *a1, *b0, *b1;  // rows of c00, c01, c10, c11
     if (ts.lhs && r < ts.ncommon) {
-        const u64 pl = (u64)ts.lrows << LOGM;
-        a0 = ts.lhs + (u64)b * 2 * pl + (u64)r * M;
+        const u64 pl = (u64)ts.lrows << logn;
+        a0 = ts.lhs + (u64)b * 2 * pl + roff;
         a1 = a0 + pl;
-        b0 = ts.rhs + (u64)b * 2 * pl + (u64)r * M;
+        b0 = ts.rhs + (u64)b * 2 * pl + roff;
         b1 = b0 + pl;
     } else {
-        a0 = ts.extL + (u64)b * 2 * pk + (u64)r * M;
+        a0 = ts.extL + (u64)b * 2 * pk + roff;
         a1 = a0 + pk;
-        b0 = ts.extR + (u64)b * 2 * pk + (u64)r * M;
+        b0 = ts.extR + (u64)b * 2 * pk + roff;
         b1 = b0 + pk;
     }
     auto prod = [&](u64 x00, u64 x01, u64 x10, u64 x11) -> u64 {
@@ -611,14 +620,18 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     } else {
         for (uint32_t i = tid; i < M; i += T) lds[padi(i)] = prod(a0[i], a1[i], b0[i], b1[i]);
     }
+    const u64x2 *twr = itw + ((u64)r << logn);
     InvTwFirst<LOGM, T> tw0;
-    inv_tw_load(tw0, itw + (u64)r * M, LOGM, 0, tid);   // in flight across the barrier (the loader needs the registers)
+    inv_tw_load(tw0, twr, logn, sub, tid);   // in flight across the barrier (the loader needs the registers)
     __syncthreads();
-    u64 *dst = out + ((u64)slot * nb + b) * pk + (u64)r * M;
+    u64 *dst = out + ((u64)slot * nb + b) * pk + roff;
     // (a block-uniform branch to the narrow inverse passes for this launch's 60-bit rows was measured:
     // 128 VGPRs, spills and twice the code -- 2 % slower)
-    ntt_inv_lds<LOGM, T>(lds, itw + (u64)r * M, LOGM, 0, pm, tid, true, ninv[2 * r], ninv[2 * r + 1], tw0);
-    lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
+    ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, pm, tid, !SUB, ninv[2 * r], ninv[2 * r + 1], tw0);
+    if constexpr (SUB)
+        lds_to_tile<CH, M, T>(lds, dst, tid, [](u64 v) { return v; });  // < 2p, the global pass finishes
+    else
+        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
 }
 
 // Radix stages that span sub-blocks, done straight on global memory (coalesced along the

@@ -84,6 +84,28 @@ def check_mul(fhe, n, sizes, batch, relin, cfg, sample=None, mod_switch=False):
         assert np.array_equal(u64(out[i]), want), f"ciphertext {i} differs from the oracle"
 
 
+def check_mul_host(fhe, n, sizes, batch, relin, cfg, mod_switch=False):
+    """check_mul through the host-pointer entry points (numpy in / out): what the CPU-side emulation of
+    the kernel sources can run."""
+    q = obfv.generate_moduli(sizes, n)
+    t = plaintext_modulus(n)
+    seed = synth.seed_for_config(cfg)
+    par = fhe.BfvParameters(n, t, moduli=q)
+    ctx = par.context_at_level(0)
+    o = oracle_level(n, q, t, 0)
+    rk, crk = None, None
+    if relin:
+        crk = host_key(o["cb"], seed, len(q))
+        rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, crk.c0, crk.c1))
+    m = fhe.Multiplicator.default(par, rk, 0, mod_switch)
+    lhs = np.stack([np.stack([o["cb"].synth_poly(seed, i, 0), o["cb"].synth_poly(seed, i, 1)]) for i in range(batch)])
+    rhs = np.stack([np.stack([o["cb"].synth_poly(seed, i, 2), o["cb"].synth_poly(seed, i, 3)]) for i in range(batch)])
+    out = m.multiply(lhs, rhs)
+    cm = coracle.CMul(o["cb"], o["cm"], o["cel"], o["cel"], o["cdn"], crk, mod_switch)
+    for i in range(batch):
+        assert np.array_equal(np.asarray(out[i]).view(np.uint64), cm.multiply(lhs[i], rhs[i])), f"ciphertext {i} differs"
+
+
 def check_batch_properties(fhe, n, sizes, batch, cfg):
     import torch
     q = obfv.generate_moduli(sizes, n)

@@ -87,6 +87,14 @@ def test_ntt_split_kernels(fhe, n):
     cases.case_ntt(fhe, False, n, moduli=mods, batch=1, coracle_ctx=coracle.CCtx(OCtx(mods, n)))
 
 
+@pytest.mark.parametrize("n", [32768, 65536])
+def test_multiply_split_rows(fhe, n):
+    """N >= 32768: rows larger than LDS -- fused tensor + inverse NTT on 8192-point sub-blocks followed by the
+    global inverse stages, split fused key switch, split NTTs -- against the C oracle."""
+    import full_size
+    full_size.check_mul_host(fhe, n=n, sizes=[60, 60], batch=1, relin=True, cfg=7)
+
+
 def test_multiply_custom_factors(fhe):
     cases.case_multiply_custom_factors(fhe, False)
 

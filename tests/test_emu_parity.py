@@ -95,6 +95,22 @@ def test_multiply_split_rows(fhe, n):
     full_size.check_mul_host(fhe, n=n, sizes=[60, 60], batch=1, relin=True, cfg=7)
 
 
+def test_random_parameter_shapes(fhe):
+    """48 pseudo-random shapes (degree 8..4096, 1-6 moduli of mixed widths 36..62 bits, ragged batches 1..11):
+    multiply (+relinearise, +modulus switch on every other shape) against the C oracle.  Ragged batches hit
+    the tails of the XCD-grouped grids; mixed widths hit both the narrow and the general transforms."""
+    import random
+    import full_size
+    for idx in range(48):
+        rng = random.Random(0xBEEF + idx)
+        n = 1 << rng.randrange(3, 13)
+        L = rng.randrange(1, 7)
+        sizes = [rng.choice([36, 45, 50, 54, 58, 59, 60, 61, 62]) for _ in range(L)]
+        batch = rng.randrange(1, 12)
+        full_size.check_mul_host(fhe, n=n, sizes=sizes, batch=batch, relin=L >= 2, cfg=300 + idx,
+                                 mod_switch=(L >= 2 and idx % 2 == 0))
+
+
 def test_multiply_custom_factors(fhe):
     cases.case_multiply_custom_factors(fhe, False)
 

@@ -1349,7 +1349,7 @@ __global__ void tensor_kernel(const u64 *__restrict__ extL, const u64 *__restric
 // reduced once (the reference's periodic reduce_u128 gives the same canonical sum).
 // Streaming, HBM bound.
 template <int NP>
-__global__ void dot_kernel(const u64 *__restrict__ cts, u64 ct_batch_stride, const u64 *__restrict__ pts,
+__global__ void __launch_bounds__(256, 8) dot_kernel(const u64 *__restrict__ cts, u64 ct_batch_stride, const u64 *__restrict__ pts,
                            u64 pt_batch_stride, u64 *__restrict__ out, const DevMod *__restrict__ mods,
                            const u64x2 *__restrict__ pow2 /* {2^64, 2^128} mod q */, uint32_t nparts, uint32_t count,
                            uint32_t logn, u64 pl /* L*N */) {

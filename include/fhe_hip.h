@@ -320,7 +320,8 @@ fhe_status fhe_generate_moduli(const size_t *sizes, size_t count, size_t degree,
  * out[b][part_local][row][coeff], ct = ct0 + b, part = part0 + part_local. */
 fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0, uint64_t part0, size_t nparts,
                                  uint64_t *out, size_t batch, void *stream);
-/* Chunk (ciphertexts per pipeline pass) used by the batched BFV entry points; 0 = default. */
+/* Chunk (ciphertext pairs per pipeline pass) used by fhe_bfv_mul(_dev); 0 = default: the batch is split into
+ * equal chunks of at most 3 GiB of workspace (512 pairs at N = 8192, 4 moduli).  Process-wide tuning knob. */
 void fhe_set_chunk(size_t chunk);
 /* The engine keeps its scratch buffers (grow-only, reused in stream order per device) between calls;
  * this frees every idle one and returns the number of bytes released. */

@@ -18,6 +18,36 @@ __device__ __forceinline__ u64 opaque_neg(u64 v) {
     asm("" : "+s"(r));
     return r;
 }
+// Hand-written lazy Shoup multiplication a*w - floor(a*ws/2^64)*p (mod 2^64), as a*w + q*np.
+// v_mad_u64_u32 wants even-aligned 64-bit addends, so the compiler spends v_movs on zero-extending partial
+// words; here a scratch pair keeps its high word at zero / at the carry instead.  Scratch: v[120:125].
+__device__ __forceinline__ u64 shoup_asm(u64 a, u64 w, u64 ws, u64 np) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32), n0 = (uint32_t)np, n1 = (uint32_t)(np >> 32);
+    u64 t;
+    uint32_t h;
+    asm volatile(
+        "v_mul_hi_u32 v120, %[a0], %[s0]\n\t"
+        "v_mov_b32 v121, 0\n\t"
+        "v_mad_u64_u32 v[122:123], vcc, %[a0], %[s1], v[120:121]\n\t"   // m = a0*s1 + hi(a0*s0)
+        "v_mad_u64_u32 v[122:123], vcc, %[a1], %[s0], v[122:123]\n\t"   // m += a1*s0, carry -> vcc
+        "v_mov_b32 v120, v123\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32 v121, 0, 1, vcc\n\t"                              // {m.hi, carry}
+        "v_mad_u64_u32 v[120:121], vcc, %[a1], %[s1], v[120:121]\n\t"   // q = a1*s1 + (m >> 32)
+        "v_mad_u64_u32 %[t], vcc, %[a0], %[w0], 0\n\t"                  // a*w low 64 ...
+        "v_mul_lo_u32 v122, %[a0], %[w1]\n\t"
+        "v_mul_lo_u32 v123, %[a1], %[w0]\n\t"
+        "v_mad_u64_u32 %[t], vcc, v120, %[n0], %[t]\n\t"                // ... + q*np low 64
+        "v_mul_lo_u32 v124, v120, %[n1]\n\t"
+        "v_mul_lo_u32 v125, v121, %[n0]\n\t"
+        "v_add3_u32 v122, v122, v123, v124\n\t"
+        "v_add_u32 %[h], v122, v125"
+        : [t] "=&v"(t), [h] "=&v"(h)
+        : [a0] "v"(a0), [a1] "v"(a1), [w0] "v"(w0), [w1] "v"(w1), [s0] "v"(s0), [s1] "v"(s1), [n0] "v"(n0), [n1] "v"(n1)
+        : "vcc", "v120", "v121", "v122", "v123", "v124", "v125");
+    return t + ((u64)h << 32);
+}
 constexpr int ILP = 8;
 constexpr int ITERS = 4096;
 
@@ -46,6 +76,12 @@ __global__ void bench(u64 *out, u64 seed, u64 p, u64 w, u64 ws) {
             if (KIND == 7) inv_butterfly(x[i], y[i], w, ws, pm);                       // Harvey GS butterfly
             if (KIND == 9) {  // CT butterfly without the conditional subtraction (headroom of <= 60-bit moduli)
                 const u64 t = mul_shoup_lazy_n(y[i], w, ws, pm.np);
+                y[i] = x[i] + pm.p2 - t;
+                x[i] = x[i] + t;
+            }
+            if (KIND == 12) x[i] = shoup_asm(x[i], w, ws, pm.np);
+            if (KIND == 13) {  // narrow CT butterfly on the asm Shoup
+                const u64 t = shoup_asm(y[i], w, ws, pm.np);
                 y[i] = x[i] + pm.p2 - t;
                 x[i] = x[i] + t;
             }
@@ -92,6 +128,8 @@ int main() {
     run<8>("mullo64", 1);
     run<9>("fwd_butterfly without conditional subtraction (not used: needs moduli <= 60 bits)", 1);
     run<5>("mul_shoup_lazy", 1);
+    run<12>("mul_shoup_lazy, hand-written asm", 1);
+    run<13>("fwd_butterfly without conditional subtraction, asm Shoup", 1);
     run<6>("fwd_butterfly", 1);
     run<7>("inv_butterfly", 1);
     return 0;

@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="2: chunks alternate between two streams (fhe_set_streams); per-kernel durations then overlap")
     args = ap.parse_args()
 
     import torch
@@ -115,6 +117,7 @@ def main():
     mul = fhe.Multiplicator.default(par, rk, 0)
     if args.chunk:
         fhe.set_chunk(args.chunk)
+    fhe.set_streams(args.streams)
     from fhe_rs_amd.shard import shard_bounds, timed_steps
     ct0, ct1 = shard_bounds(world * batch, rank, world)  # this rank's block of independent ciphertexts
     assert ct1 - ct0 == batch
@@ -177,7 +180,7 @@ def main():
             traffic = None
     roofline = dict(bound="hbm", kernel=dname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    launches=dlaunches, avg_launch_ms=round(dms / max(dlaunches, 1), 4),
+                    launches=dlaunches, avg_launch_ms=round(dms / max(dlaunches, 1), 4), streams=args.streams,
                     algorithmic_bytes_per_launch=int(dbytes_total / max(dlaunches, 1)),
                     whole_op=dict(stage_model_bytes_per_op=stage_model_rows(L, K, L) * R,
                                   achieved=round(stage_model_rows(L, K, L) * R * value / world / 1e9, 1),

@@ -113,6 +113,7 @@ SIGNATURES = {
     "fhe_generate_moduli": (i32, [szp, sz, sz, u64p]),
     "fhe_synth_uniform_dev": (i32, [vp, u64, u64, u64, sz, vp, sz, vp]),
     "fhe_set_chunk": (None, [sz]),
+    "fhe_set_streams": (None, [sz]),
     "fhe_workspace_trim": (sz, []),
     "fhe_get_chunk": (sz, []),
     "fhe_prof_enable": (None, [i32]),

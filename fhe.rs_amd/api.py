@@ -774,3 +774,8 @@ def workspace_trim():
 
 def set_chunk(chunk):
     _lib.lib().fhe_set_chunk(chunk)
+
+
+def set_streams(n):
+    """1 (default): multiply on the caller's stream; 2: chunks alternate with an internal stream (fhe_set_streams)."""
+    _lib.lib().fhe_set_streams(n)

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -1063,6 +1064,30 @@ inline size_t &chunk_setting() {
     static size_t chunk = 0;
     return chunk;
 }
+// 1 (default): the whole pipeline on the caller's stream.  2: the chunks of a multiply alternate between the
+// caller's stream and an internal one (fork / join through events): while one chunk's launch drains, the other
+// chunk's kernels fill the idle workgroup slots, which makes small, cache-friendly chunks affordable.
+inline size_t &streams_setting() {
+    static size_t n = 1;
+    return n;
+}
+struct AuxStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+inline AuxStream &aux_for(int device, hipStream_t user) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, AuxStream> reg;
+    std::lock_guard<std::mutex> lk(mu);
+    AuxStream &a = reg[{device, user}];
+    if (!a.s) {
+        FHE_HIP_CHECK(hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking));
+        FHE_HIP_CHECK(hipEventCreateWithFlags(&a.fork, hipEventDisableTiming));
+        FHE_HIP_CHECK(hipEventCreateWithFlags(&a.join, hipEventDisableTiming));
+    }
+    return a;
+}
+
 inline size_t default_chunk(const Ctx &base, const Ctx &mulc, size_t batch) {
     if (chunk_setting()) return std::min(batch, chunk_setting());
     // Every launch should cover >> 512 workgroup slots (small chunks lose to tail effects: 64 pairs per
@@ -1070,7 +1095,8 @@ inline size_t default_chunk(const Ctx &base, const Ctx &mulc, size_t batch) {
     // reuse in the 256 MiB Infinity Cache is lost (chunks of 256-512 pairs measured 1.5 % ahead of one
     // 1024-pair chunk).  The batch is split into equal chunks under that budget.
     const size_t per_ct = (7 * mulc.L + 7 * base.L) * mulc.n * sizeof(u64);
-    const size_t budget = (size_t)3 << 30;
+    // two streams: 768 MiB per chunk (128 pairs at C2) measured best, see DESIGN.md section 6
+    const size_t budget = streams_setting() >= 2 ? (size_t)768 << 20 : (size_t)3 << 30;
     const size_t cap = std::max<size_t>(1, std::min<size_t>(budget / per_ct, 4096));
     const size_t nchunks = (batch + cap - 1) / cap;
     return (batch + nchunks - 1) / nchunks;
@@ -1112,7 +1138,7 @@ inline void bfv_tensor(const Mul &m, size_t la, size_t lb, const u64 *lhs, const
 // Workspace per chunk of nb pairs (all slot-major so that every step is ONE launch over
 // nb * {2,3} polynomials):  extL/extR [nb][2][K][N] extended operands,  ten [3][nb][K][N]
 // tensor,  d [3][nb][L][N] down-scaled parts (c0, c1 Ntt; c2 PowerBasis for the key switch).
-inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size_t batch, hipStream_t s) {
+inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size_t batch, hipStream_t s0) {
     const Ctx &b = *m.base, &e = *m.mulc;
     b.need_device();
     const size_t L = b.L, K = e.L, N = b.n;
@@ -1123,11 +1149,40 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     // the extenders copy the shared prefix rows verbatim; when both share all L rows the tensor
     // kernel reads those rows from the inputs directly and the copy is skipped
     const bool skip_copy = m.ext_lhs->ncommon == L && m.ext_rhs->ncommon == L && !debug_flag("FHE_NO_SKIP_COPY");
-    WsGuard extL(chunk * 2 * PK * sizeof(u64), s), extR(chunk * 2 * PK * sizeof(u64), s);
-    WsGuard ten(chunk * 3 * PK * sizeof(u64), s), d(chunk * 3 * PL * sizeof(u64), s);
-    WsGuard pre(m.mod_switch ? chunk * parts * PL * sizeof(u64) : 8, s);
-    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+    struct ChunkWs {
+        WsGuard extL, extR, ten, d, pre;
+        ChunkWs(size_t chunk, u64 PK, u64 PL, size_t pre_bytes, hipStream_t st)
+            : extL(chunk * 2 * PK * sizeof(u64), st), extR(chunk * 2 * PK * sizeof(u64), st),
+              ten(chunk * 3 * PK * sizeof(u64), st), d(chunk * 3 * PL * sizeof(u64), st), pre(pre_bytes, st) {}
+    };
+    const size_t pre_bytes = m.mod_switch ? chunk * parts * PL * sizeof(u64) : 8;
+    const size_t nchunks = (batch + chunk - 1) / chunk;
+    const bool dual = streams_setting() >= 2 && nchunks >= 2;
+    hipStream_t lanes[2] = {s0, s0};
+    AuxStream *aux = nullptr;
+    struct Join {  // the internal stream always rejoins the caller's, also on an error path
+        AuxStream *a;
+        hipStream_t to;
+        ~Join() {
+            if (a && hipEventRecord(a->join, a->s) == hipSuccess) (void)hipStreamWaitEvent(to, a->join, 0);
+        }
+    };
+    if (dual) {
+        aux = &aux_for(b.device, s0);
+        lanes[1] = aux->s;
+        FHE_HIP_CHECK(hipEventRecord(aux->fork, s0));
+        FHE_HIP_CHECK(hipStreamWaitEvent(aux->s, aux->fork, 0));
+    }
+    Join join{aux, s0};
+    ChunkWs ws0(chunk, PK, PL, pre_bytes, lanes[0]);
+    std::unique_ptr<ChunkWs> ws1;
+    if (dual) ws1 = std::make_unique<ChunkWs>(chunk, PK, PL, pre_bytes, lanes[1]);
+    size_t ci = 0;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk, ci++) {
         const size_t nb = std::min(chunk, batch - b0);
+        const hipStream_t s = lanes[dual ? ci & 1 : 0];
+        ChunkWs &w = (dual && (ci & 1)) ? *ws1 : ws0;
+        WsGuard &extL = w.extL, &extR = w.extR, &ten = w.ten, &d = w.d, &pre = w.pre;
         const u64 *l = lhs + b0 * 2 * PL, *r = rhs + b0 * 2 * PL;
         // EXTEND (mul.rs:192-195): both parts of every lhs (rhs) ciphertext in one go
         scale_polys(*m.ext_lhs, l, extL.u(), nb * 2, true, s, !skip_copy);

@@ -1243,6 +1243,7 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
     });
 }
 void fhe_set_chunk(size_t chunk) { chunk_setting() = chunk; }
+void fhe_set_streams(size_t n) { streams_setting() = n < 1 ? 1 : (n > 2 ? 2 : n); }
 size_t fhe_workspace_trim(void) { return Workspace::get().trim(); }
 size_t fhe_get_chunk(void) { return chunk_setting(); }
 void fhe_prof_enable(int on) { Profiler::get().enabled = on != 0; }

@@ -323,6 +323,11 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
 /* Chunk (ciphertext pairs per pipeline pass) used by fhe_bfv_mul(_dev); 0 = default: the batch is split into
  * equal chunks of at most 3 GiB of workspace (512 pairs at N = 8192, 4 moduli).  Process-wide tuning knob. */
 void fhe_set_chunk(size_t chunk);
+/* Streams used by fhe_bfv_mul(_dev) (F/bfv/ops/mul.rs:165-243 on a batch): 1 (default) = the caller's stream only;
+ * 2 = the chunks of a batch alternate between the caller's stream and an internal one, forked from and joined
+ * back into the caller's stream with events (stream-ordered for the caller exactly as with 1; capturable).
+ * Smaller chunks (768 MiB of workspace each) are then used.  Process-wide tuning knob. */
+void fhe_set_streams(size_t n);
 /* The engine keeps its scratch buffers (grow-only, reused in stream order per device) between calls;
  * this frees every idle one and returns the number of bytes released. */
 size_t fhe_workspace_trim(void);

@@ -313,7 +313,7 @@ def case_galois(fhe, dev, nmod=3, n=16):
         assert err.code == -10
 
 
-def case_multiply(fhe, dev, nmod=3, n=16, batch=3, level=0, chunk=0):
+def case_multiply(fhe, dev, nmod=3, n=16, batch=3, level=0, chunk=0, streams=1):
     """ops/mul.rs:165-243, 263-367 and ops/mod.rs:259-358: Multiplicator::default with
     relinearisation (+/- modulus switching) and the `&ct * &ct` tensor without it; results
     equal the oracle bit for bit AND decrypt to the plaintext product."""
@@ -331,6 +331,7 @@ def case_multiply(fhe, dev, nmod=3, n=16, batch=3, level=0, chunk=0):
     lhs, rhs = x.to(np.stack([ct_arr(c) for c in A])), x.to(np.stack([ct_arr(c) for c in B]))
     if chunk:
         fhe.set_chunk(chunk)
+    fhe.set_streams(streams)
     try:
         for mod_switch in ([False, True] if level < opar.max_level() else [False]):
             om = obfv.Multiplicator.default(ork)
@@ -347,6 +348,7 @@ def case_multiply(fhe, dev, nmod=3, n=16, batch=3, level=0, chunk=0):
             assert np.array_equal(got[i], ct_arr(A[i].mul(B[i])))
     finally:
         fhe.set_chunk(0)
+        fhe.set_streams(1)
 
 
 def case_multiply_custom_factors(fhe, dev, n=16):

@@ -170,6 +170,15 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
     return hipSuccess;
 }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+enum { hipEventDisableTiming = 2, hipStreamNonBlocking = 1 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
+    static char pool[64];
+    static int next = 0;
+    *s = (hipStream_t)&pool[next++ % 64];  // distinct non-null handles; the emulator runs everything in order
+    return hipSuccess;
+}
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;

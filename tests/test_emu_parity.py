@@ -67,6 +67,13 @@ def test_multiply(fhe, nmod, level, chunk):
     cases.case_multiply(fhe, False, nmod=nmod, level=level, chunk=chunk)
 
 
+def test_multiply_two_streams(fhe):
+    """fhe_set_streams(2): chunks alternate between the caller's stream and the internal one (5 pairs in chunks
+    of 2 and 1: three and five chunks, odd counts included); same results."""
+    cases.case_multiply(fhe, False, nmod=3, level=0, chunk=2, streams=2, batch=5)
+    cases.case_multiply(fhe, False, nmod=2, level=0, chunk=1, streams=2, batch=5)
+
+
 @pytest.mark.parametrize("n", [128, 512])
 def test_multiply_vector_tile_paths(fhe, n):
     """Sizes whose tiles take the 16-byte-chunk (CH > 0) load/MAC/store paths of the kernels."""

@@ -289,3 +289,45 @@ def test_dev_entry_points_are_graph_capturable(fhe):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(got_m, want2)
+
+
+def test_multiply_two_streams(fhe):
+    """fhe_set_streams(2) at C2's shape: chunks of 128 pairs alternating between two streams give bit-identical
+    ciphertexts to the single-stream pipeline (which the other tests tie to the oracle), repeatedly, also when
+    the call is captured into a hipGraph (the internal stream forks from / joins the capturing stream)."""
+    import torch
+    import full_size
+    from fhe_oracle import bfv as obfv
+    n, sizes, batch = 8192, [60] * 4, 600          # 600 pairs: five chunks of 120
+    q = obfv.generate_moduli(sizes, n)
+    par = fhe.BfvParameters(n, full_size.plaintext_modulus(n), moduli=q)
+    ctx = par.context_at_level(0)
+    c0, c1 = full_size.device_key(ctx, 11, len(q))
+    m = fhe.Multiplicator.default(par, fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1)), 0)
+    a, b = ctx.synth_uniform(21, 0, 0, 2, batch), ctx.synth_uniform(21, 0, 2, 2, batch)
+    want = m.multiply(a, b)
+    torch.cuda.synchronize()
+    fhe.set_streams(2)
+    try:
+        for _ in range(3):
+            got = m.multiply(a, b)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
+        # stream order for the caller: work enqueued right after the call sees the complete result
+        got = m.multiply(a, b)
+        chk = (got != want).sum()
+        assert int(chk.item()) == 0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m.multiply(a, b)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = m.multiply(a, b)
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+    finally:
+        fhe.set_streams(1)

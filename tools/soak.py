@@ -26,15 +26,17 @@ def main():
     mul = fhe.Multiplicator.default(par, fhe.RelinearizationKey(ksk), 0)
     gk = fhe.GaloisKey(ksk, 3)
     a, b = ctx.synth_uniform(7, 0, 0, 2, 1024), ctx.synth_uniform(7, 0, 2, 2, 1024)
-    ref_m, ref_r = mul.multiply(a, b), gk.relinearize(a)
+    ref_m, ref_r = mul.multiply(a, b), gk.relinearize(a)   # single-stream reference
     torch.cuda.synchronize()
+    streams = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    fhe.set_streams(streams)                               # 2: chunks alternate between two streams
     bad, t0 = 0, time.time()
     for i in range(reps):
         m, r = mul.multiply(a, b), gk.relinearize(a)
         if not (torch.equal(m, ref_m) and torch.equal(r, ref_r)):
             bad += 1
     torch.cuda.synchronize()
-    print(json.dumps(dict(repetitions=reps, ops=reps * 2048, mismatches=bad, seconds=round(time.time() - t0, 1))))
+    print(json.dumps(dict(repetitions=reps, streams=streams, ops=reps * 2048, mismatches=bad, seconds=round(time.time() - t0, 1))))
     sys.exit(1 if bad else 0)
 
 

@@ -188,9 +188,11 @@ def test_max_degree_n65536(fhe):
     full_size.check_mul(fhe, n=65536, sizes=[60, 60], batch=2, relin=True, cfg=6)
 
 
-def test_concurrent_streams_share_handles(fhe):
+@pytest.mark.parametrize("streams", [1, 2])
+def test_concurrent_streams_share_handles(fhe, streams):
     """Handles are immutable and may be shared by concurrent callers working on different
-    buffers (one HIP stream per calling thread) -- SURVEY.md 8(b) threading contract."""
+    buffers (one HIP stream per calling thread) -- SURVEY.md 8(b) threading contract.  streams = 2: every
+    caller's multiply also forks onto its own internal stream (chunks of 5 pairs)."""
     import threading
     import torch
     import full_size
@@ -205,6 +207,9 @@ def test_concurrent_streams_share_handles(fhe):
     want = [m.multiply(a, b) for a, b in ins]
     torch.cuda.synchronize()
     got, errs = [None] * 4, []
+    fhe.set_streams(streams)
+    if streams == 2:
+        fhe.set_chunk(5)
 
     def worker(i):
         try:
@@ -216,8 +221,12 @@ def test_concurrent_streams_share_handles(fhe):
         except Exception as e:  # pragma: no cover
             errs.append(e)
     th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
-    [t.start() for t in th]
-    [t.join() for t in th]
+    try:
+        [t.start() for t in th]
+        [t.join() for t in th]
+    finally:
+        fhe.set_streams(1)
+        fhe.set_chunk(0)
     assert not errs, errs
     for i in range(4):
         assert torch.equal(got[i], want[i])

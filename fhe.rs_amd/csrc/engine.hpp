@@ -479,27 +479,25 @@ inline k::RowMap full_map(const Ctx &c, size_t rows_in_poly) {
     return m;
 }
 
-inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s) {
+inline void launch_tensor_intt_rows(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, uint32_t row_begin,
+                                    uint32_t lrows, bool narrow, hipStream_t s) {
     const uint32_t logn = (uint32_t)e.logn, logm = logn <= 14 ? logn : 13;
     const size_t lds = k::lds_words(1u << logm) * sizeof(u64);
     // 8 (row, pair, sub-block) combinations x 3 slots per group
-    const unsigned groups = (unsigned)((((e.L * nb) << (logn - logm)) + 7) / 8);
-#define FHE_TI_LAUNCH(LM, SUB)                                                                                  \
-    allow_big_lds((k::tensor_intt_kernel<LM, SUB>), lds);                                                       \
-    FHE_LAUNCH("tensor_intt", (k::tensor_intt_kernel<LM, SUB>), dim3(groups * 24), dim3(k::ntt_threads_c(LM)),  \
-               lds, s, ts, out, e.dmods(), e.ditw(), e.dninv(), (uint32_t)e.L, (uint32_t)nb, logn);
-#define FHE_TI_CASE(LM) \
-    case LM: { FHE_TI_LAUNCH(LM, false) } break;
+    const unsigned groups = (unsigned)(((((size_t)lrows * nb) << (logn - logm)) + 7) / 8);
+#define FHE_TI_LAUNCH(LM, SUB, NRW)                                                                              \
+    allow_big_lds((k::tensor_intt_kernel<LM, SUB, NRW>), lds);                                                   \
+    FHE_LAUNCH("tensor_intt", (k::tensor_intt_kernel<LM, SUB, NRW>), dim3(groups * 24),                          \
+               dim3(k::ntt_threads_c(LM)), lds, s, ts, out, e.dmods(), e.ditw(), e.dninv(), (uint32_t)e.L,       \
+               (uint32_t)nb, logn, row_begin, lrows);
+#define FHE_TI_CASE(LM)                               \
+    case LM:                                          \
+        if (narrow) { FHE_TI_LAUNCH(LM, false, true) } \
+        else { FHE_TI_LAUNCH(LM, false, false) }       \
+        break;
     if (logn > 14) {
-        FHE_TI_LAUNCH(13, true)
-        const unsigned gth = 256, gblocks = (unsigned)(nb * 3 * e.L) * ((1u << logm) / gth);
-        const k::RowMap m = full_map(e, e.L);
-        if (logn - logm == 2)
-            FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 2>), dim3(gblocks), dim3(gth), 0, s, out, out, m,
-                       e.dmods(), e.ditw(), e.dninv(), logn, (uint32_t)k::PRO_NONE);
-        else
-            FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 3>), dim3(gblocks), dim3(gth), 0, s, out, out, m,
-                       e.dmods(), e.ditw(), e.dninv(), logn, (uint32_t)k::PRO_NONE);
+        if (narrow) { FHE_TI_LAUNCH(13, true, true) }
+        else { FHE_TI_LAUNCH(13, true, false) }
         return;
     }
     switch (logn) {
@@ -509,6 +507,31 @@ inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, s
     }
 #undef FHE_TI_CASE
 #undef FHE_TI_LAUNCH
+}
+
+inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s) {
+    // maximal runs of rows of the same kind (moduli below 2^60 or not): one launch each
+    const bool allow = !debug_flag("FHE_NO_NARROW");
+    uint32_t r0 = 0;
+    while (r0 < e.L) {
+        const bool nr = allow && (e.moduli[r0] >> 60) == 0;
+        uint32_t r1 = r0 + 1;
+        while (r1 < e.L && (allow && (e.moduli[r1] >> 60) == 0) == nr) r1++;
+        launch_tensor_intt_rows(e, ts, out, nb, r0, r1 - r0, nr, s);
+        r0 = r1;
+    }
+    const uint32_t logn = (uint32_t)e.logn;
+    if (logn > 14) {  // the global inverse stages finish every row
+        const uint32_t logm = 13;
+        const unsigned gth = 256, gblocks = (unsigned)(nb * 3 * e.L) * ((1u << logm) / gth);
+        const k::RowMap m = full_map(e, e.L);
+        if (logn - logm == 2)
+            FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 2>), dim3(gblocks), dim3(gth), 0, s, out, out, m,
+                       e.dmods(), e.ditw(), e.dninv(), logn, (uint32_t)k::PRO_NONE);
+        else
+            FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 3>), dim3(gblocks), dim3(gth), 0, s, out, out, m,
+                       e.dmods(), e.ditw(), e.dninv(), logn, (uint32_t)k::PRO_NONE);
+    }
 }
 
 inline void ntt_polys(const Ctx &c, bool inverse, const u64 *in, u64 *out, size_t npolys, hipStream_t s) {

@@ -531,11 +531,14 @@ struct TensorSrc {
 // in the loader, the inverse stages that stay inside the sub-block -- and leaves values below 2p for
 // ntt_global_kernel<true, .>, which finishes the transform (so the Ntt-domain tensor never touches HBM
 // at N = 32768 / 65536 either).
-template <int LOGM, bool SUB = false>
+// A launch covers the rows [row_begin, row_begin + lrows) of the nrows-row extended basis; NARROW (all of them
+// below 2^60) selects the inverse passes with tracked bounds (inv_pass): the ciphertext primes of the extended
+// basis are 60-bit, the extension primes 62-bit, so bfv_mul issues one launch for each group.
+template <int LOGM, bool SUB = false, bool NARROW = false>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     tensor_intt_kernel(TensorSrc ts, u64 *__restrict__ out, const DevMod *__restrict__ mods,
                        const u64x2 *__restrict__ itw, const u64x2 *__restrict__ ninv, uint32_t nrows, uint32_t nb,
-                       uint32_t logn_arg) {
+                       uint32_t logn_arg, uint32_t row_begin, uint32_t lrows) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ntt_threads_c(LOGM);
     constexpr int M = 1 << LOGM;
@@ -549,9 +552,9 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     // (a (row, pair, slot) 3-D grid put them nb*K blocks apart: 1.8x the algorithmic HBM traffic).
     const uint32_t t8 = blockIdx.x >> 3, grp = t8 / 3, slot = t8 - 3 * grp;
     const uint32_t combo = grp * 8 + (blockIdx.x & 7);
-    if (combo >= (nrows * nb) << lsub) return;  // (block-uniform) tail of the rounded-up grid
+    if (combo >= (lrows * nb) << lsub) return;  // (block-uniform) tail of the rounded-up grid
     const uint32_t sub = combo & ((1u << lsub) - 1), rowb = combo >> lsub;
-    const uint32_t b = to_sgpr(rowb / nrows), r = rowb - b * nrows;
+    const uint32_t b = to_sgpr(rowb / lrows), r = row_begin + (rowb - b * lrows);
     const DevMod md = mods[r];
     const u64 p = md.p;
     const PM pm = make_pm(md);
@@ -625,9 +628,9 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     inv_tw_load(tw0, twr, logn, sub, tid);   // in flight across the barrier (the loader needs the registers)
     __syncthreads();
     u64 *dst = out + ((u64)slot * nb + b) * pk + roff;
-    // (a block-uniform branch to the narrow inverse passes for this launch's 60-bit rows was measured:
-    // 128 VGPRs, spills and twice the code -- 2 % slower)
-    ntt_inv_lds<LOGM, T>(lds, twr, logn, sub, pm, tid, !SUB, ninv[2 * r], ninv[2 * r + 1], tw0);
+    // (a block-uniform branch between the narrow and the general inverse passes inside one kernel was measured:
+    // 128 VGPRs, spills and twice the code -- 2 % slower; hence one launch per row group)
+    ntt_inv_lds<LOGM, T, 0, 0, NARROW>(lds, twr, logn, sub, pm, tid, !SUB, ninv[2 * r], ninv[2 * r + 1], tw0);
     if constexpr (SUB)
         lds_to_tile<CH, M, T>(lds, dst, tid, [](u64 v) { return v; });  // < 2p, the global pass finishes
     else

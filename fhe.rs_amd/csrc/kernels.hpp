@@ -1107,8 +1107,13 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
     scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,
                              u64 out_poly_stride, ScalerDev s, const DevMod *__restrict__ to_mods, uint32_t logn,
                              u64 total) {
-    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
+    // Columns are handed out from the LAST polynomial backwards: the kernel that wrote `in` (an inverse NTT, the
+    // fused tensor kernel) went through the polynomials in ascending order, so its most recent output is what
+    // still sits in the 256 MiB Infinity Cache; and the forward NTT that follows this kernel (ascending again)
+    // starts on what was written here last.  Same-box A/B: -1.2 % per ct x ct step, -3 % on that forward NTT.
+    gid = total - 1 - gid;
     const uint32_t n = 1u << logn;
     const uint32_t col = (uint32_t)(gid & (n - 1));
     const u64 poly = gid >> logn;

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Random-shape parity sweep on the GPU beyond the 48 shapes of tests/test_gpu_parity.py: every shape's multiply
+(+relinearise / modulus switch), relinearise and rotations against the C oracle (tests/full_size.py).
+Test infrastructure: this is the only thing here that touches oracle/.  Usage: random_sweep_gpu.py [seconds]"""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+from helpers import load_engine
+import full_size
+fhe = load_engine("hip")
+t0 = time.time(); done = 0; fails = []
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 400
+for idx in range(48, 2000):
+    try:
+        full_size.check_random_shape(fhe, idx)
+        done += 1
+    except Exception as e:
+        fails.append((idx, full_size.random_shape(idx), repr(e)[:200]))
+        break
+    if time.time() - t0 > budget: break
+print(json.dumps({"shapes_checked": done, "first_idx": 48, "failures": fails, "seconds": round(time.time() - t0)}))

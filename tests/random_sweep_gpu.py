@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random-shape parity sweep on the GPU beyond the 48 shapes of tests/test_gpu_parity.py: every shape's multiply
 (+relinearise / modulus switch), relinearise and rotations against the C oracle (tests/full_size.py).
-Test infrastructure: this is the only thing here that touches oracle/.  Usage: random_sweep_gpu.py [seconds]"""
+Test infrastructure (lives in tests/ because it uses the oracle).  Usage: python tests/random_sweep_gpu.py [seconds]"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]

@@ -90,6 +90,25 @@ __device__ __forceinline__ uint32_t to_sgpr(uint32_t v) {
     return v;
 #endif
 }
+// Exchange through LDS between lanes of ONE wavefront: LDS instructions of a wave execute in order, so all that
+// is needed is that the compiler keeps the reads behind the writes -- no s_barrier, the other waves of the
+// workgroup run on.  Used between radix passes whose groups stay inside the wave's own block of the tile
+// (wave_local_exchange below).  Host emulation (fibers per thread): the workgroup barrier.
+__device__ __forceinline__ void wave_sync() {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_NO_WAVE_SYNC)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#else
+    __syncthreads();
+#endif
+}
+// Pass p hands thread t the groups {g0 + t}; a group of pass (skip, G) is {base + (e << skip)} with
+// base = (grp >> skip) << (skip + G) | (grp & (2^skip - 1)).  When 2^skip <= 64 the 64 consecutive groups of a
+// wave cover the contiguous elements [(g0 + 64 w) 2^G, + 64 * 2^G); two passes with the same G and both skips
+// <= 6 therefore read and write the same per-wave ranges, and the exchange between them is wave-local.
+constexpr bool wave_local_exchange(int skip_a, int g_a, int skip_b, int g_b) {
+    return g_a == g_b && skip_a <= 6 && skip_b <= 6;
+}
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
@@ -103,6 +122,10 @@ __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) {
 // of 2^G coefficients per thread.  NTT: 16 coefficients per thread (one radix-16 group);
 // key switch: 8 per thread (leaves registers for the two accumulator sets).
 constexpr int ntt_threads_c(int logm) { return (1 << logm) / 16 > 64 ? ((1 << logm) / 16 > 1024 ? 1024 : (1 << logm) / 16) : 64; }
+#ifndef FHE_KS_LATE
+#define FHE_KS_LATE true
+#endif
+constexpr bool KS_LATE = FHE_KS_LATE;  // key-switch transforms: wider radix passes last (wave-local exchanges)
 constexpr int KS_GMAX = 3;  // radix-8 passes inside the key switch: room for the accumulators
 constexpr int ks_threads_c(int logn) { return (1 << logn) / 8 > 64 ? ((1 << logn) / 8 > 1024 ? 1024 : (1 << logn) / 8) : 64; }
 // 16-byte chunks per thread (0: tile smaller than one chunk per thread -> scalar loop)
@@ -226,36 +249,46 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
 
 // All stages of a size-2^LOGM forward transform on an LDS tile (values < 4p on exit); the
 // pass plan is resolved at compile time.  Early passes (scalar twiddles) take the wider radix.
-template <int LOGM, int GM, int PASS>
-constexpr int fwd_plan_g() { return plan_base(LOGM, GM) + (PASS < plan_rem(LOGM, GM) ? 1 : 0); }
+// LATE = false: the wider passes come first (they run on scalar twiddles); LATE = true: last, so that the trailing
+// passes share one radix and their exchanges are wave-local (the key switch at N = 8192: 2+2+3+3+3, two workgroup
+// barriers per digit transform instead of four).
+template <int LOGM, int GM, int PASS, bool LATE = false>
+constexpr int fwd_plan_g() {
+    return plan_base(LOGM, GM) +
+           ((LATE ? PASS >= plan_np(LOGM, GM) - plan_rem(LOGM, GM) : PASS < plan_rem(LOGM, GM)) ? 1 : 0);
+}
 // TWPF: fetch the next pass's per-lane twiddles before the barrier (costs their registers across
 // it: the key-switch kernels, which also hold accumulators, leave it off).
 // FSYNC = false: the caller places the barrier after the last pass itself (it has loads to issue first).
-template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, int NARROW, int PASS, int S0, class W, class Src>
+template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, int NARROW, int PASS, int S0, bool LATE, class W, class Src>
 __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                                 uint32_t tid, const W &tw_regs, Src src) {
-    constexpr int G = fwd_plan_g<LOGM, GM, PASS>();
+    constexpr int G = fwd_plan_g<LOGM, GM, PASS, LATE>();
     if constexpr (PASS == 0)
         fwd_pass<G, LOGM, S0, T, TWPF, NARROW, Src>(lds, tw, kbase, pm, tid, tw_regs, src);   // (Src != NoSrc: reads `src`, not LDS)
     else
         fwd_pass<G, LOGM, S0, T, TWPF, NARROW>(lds, tw, kbase, pm, tid, tw_regs);
     if constexpr (PASS + 1 < plan_np(LOGM, GM)) {
-        constexpr int GN = fwd_plan_g<LOGM, GM, PASS + 1>();
+        constexpr int GN = fwd_plan_g<LOGM, GM, PASS + 1, LATE>();
         FwdTw<GN, LOGM, S0 + G, T> next;
         if constexpr (TWPF) fwd_tw_load(next, tw, kbase, tid);   // in flight across the barrier
-        __syncthreads();
-        ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, PASS + 1, S0 + G>(lds, tw, kbase, pm, tid, next, NoSrc{});
+        if constexpr (wave_local_exchange(LOGM - S0 - G, G, LOGM - S0 - G - GN, GN))
+            wave_sync();
+        else
+            __syncthreads();
+        ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, PASS + 1, S0 + G, LATE>(lds, tw, kbase, pm, tid, next, NoSrc{});
     } else {
         if constexpr (FSYNC) __syncthreads();
     }
 }
-template <int LOGM, int T, int GM = GMAX, bool TWPF = true, bool FSYNC = true, int NARROW = 0, class Src = NoSrc>
+template <int LOGM, int T, int GM = GMAX, bool TWPF = true, bool FSYNC = true, int NARROW = 0, class Src = NoSrc,
+          bool LATE = false>
 __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                             uint32_t tid, Src src = Src{}) {
-    constexpr int G = fwd_plan_g<LOGM, GM, 0>();
+    constexpr int G = fwd_plan_g<LOGM, GM, 0, LATE>();
     FwdTw<G, LOGM, 0, T> first;
     if constexpr (TWPF) fwd_tw_load(first, tw, kbase, tid);
-    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, 0, 0>(lds, tw, kbase, pm, tid, first, src);
+    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, 0, 0, LATE>(lds, tw, kbase, pm, tid, first, src);
 }
 
 // ---------------------------------------------------------------- inverse passes ----
@@ -402,7 +435,10 @@ __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ 
     if constexpr (PASS + 1 < plan_np(LOGM, GMAX)) {
         InvTw<inv_plan_g<LOGM, PASS + 1>(), LOGM, V0 + G, T> next;
         inv_tw_load(next, itw, logn, sub, tid);   // in flight across the barrier
-        __syncthreads();
+        if constexpr (wave_local_exchange(V0, G, V0 + G, inv_plan_g<LOGM, PASS + 1>()))
+            wave_sync();
+        else
+            __syncthreads();
         ntt_inv_lds<LOGM, T, PASS + 1, V0 + G, NARROW>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, next);
     } else {
         __syncthreads();
@@ -805,7 +841,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
             // transform, so their L2 latency is spent waiting for the other waves, not after them
             constexpr bool KPF = PREFETCH && CH >= 2;
             // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
-            ntt_fwd_lds<LOGN, T, KS_GMAX, false, !KPF, (NARROW ? 1 : 0)>(lds, twr, 1, pm, tid);
+            ntt_fwd_lds<LOGN, T, KS_GMAX, false, !KPF, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
             u64x2 kq[KPF ? 8 : 1];
             if constexpr (KPF) {
 #pragma unroll
@@ -839,13 +875,15 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                 if (c & 1) sched_fence();  // at most two chunks of key loads (32 VGPRs) in flight
             }
         } else {
-            ntt_fwd_lds<LOGN, T, KS_GMAX, false, true, (NARROW ? 1 : 0)>(lds, twr, 1, pm, tid);
+            ntt_fwd_lds<LOGN, T, KS_GMAX, false, true, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
             if (tid < N) {
             const u64 v = lds[padi(tid)];
             acc0[0] = csub_n(acc0[0] + mul_shoup_lazy_n(v, k0[koff + tid], k0s[koff + tid], pm.np), p2, pm.np2);
             acc1[0] = csub_n(acc1[0] + mul_shoup_lazy_n(v, k1[koff + tid], k1s[koff + tid], pm.np), p2, pm.np2);
             }
         }
+        // (wave-contiguous chunk ownership, which makes this barrier and the one before the MAC wave-local as
+        // well, was measured: nothing beyond what the late pass plan already gives)
         __syncthreads();
     }
     const uint32_t tid = opaque(tid0);  // keeps the epilogue's address arithmetic below the digit loop
@@ -960,7 +998,7 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
         }
         __syncthreads();
         // (NARROW: the folded loader stages leave values below 4p)
-        ntt_fwd_lds<LOGM, T, KS_GMAX, false, true, (NARROW ? 4 : 0)>(lds, twr, NS + sub, pm, tid);
+        ntt_fwd_lds<LOGM, T, KS_GMAX, false, true, (NARROW ? 4 : 0), NoSrc, KS_LATE>(lds, twr, NS + sub, pm, tid);
         const u64 koff = ((u64)i * lk + j) * N + (u64)sub * M;
         const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
         const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);

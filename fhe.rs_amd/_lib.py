@@ -22,6 +22,9 @@ sz = C.c_size_t
 u64 = C.c_uint64
 i32 = C.c_int
 
+# fhe_ntt_tables_fn: int (*)(void *user, uint64_t modulus, size_t degree, 4 x uint64_t *[degree], 2 x uint64_t *)
+NTT_TABLES_FN = C.CFUNCTYPE(C.c_int, vp, u64, sz, u64p, u64p, u64p, u64p, u64p, u64p)
+
 # name -> (restype, argtypes); mirrors include/fhe_hip.h one to one
 SIGNATURES = {
     "fhe_last_error": (C.c_char_p, []),
@@ -95,11 +98,16 @@ SIGNATURES = {
     "fhe_mul_create": (i32, [vp, vp, vp, vp, i32, C.POINTER(vp)]),
     "fhe_mul_destroy": (None, [vp]),
     "fhe_mul_out_shape": (i32, [vp, szp, szp]),
+    "fhe_mul_basis": (i32, [vp, szp, u64p]),
+    "fhe_mul_set_chunk": (i32, [vp, sz]),
+    "fhe_mul_set_streams": (i32, [vp, sz]),
+    "fhe_mul_get_options": (i32, [vp, szp, szp]),
     "fhe_bfv_mul": (i32, [vp, u64p, u64p, u64p, sz]),
     "fhe_bfv_mul_dev": (i32, [vp, vp, vp, vp, sz, vp]),
     "fhe_bfv_tensor": (i32, [vp, sz, sz, u64p, u64p, u64p, sz]),
     "fhe_bfv_tensor_dev": (i32, [vp, sz, sz, vp, vp, vp, sz, vp]),
     "fhe_params_create": (i32, [i32, sz, sz, u64p, u64, C.POINTER(vp)]),
+    "fhe_params_create_with_tables": (i32, [i32, sz, sz, u64p, u64, NTT_TABLES_FN, vp, C.POINTER(vp)]),
     "fhe_params_destroy": (None, [vp]),
     "fhe_params_max_level": (sz, [vp]),
     "fhe_params_ctx": (i32, [vp, sz, C.POINTER(vp)]),
@@ -112,10 +120,7 @@ SIGNATURES = {
     "fhe_is_prime": (i32, [u64]),
     "fhe_generate_moduli": (i32, [szp, sz, sz, u64p]),
     "fhe_synth_uniform_dev": (i32, [vp, u64, u64, u64, sz, vp, sz, vp]),
-    "fhe_set_chunk": (None, [sz]),
-    "fhe_set_streams": (None, [sz]),
     "fhe_workspace_trim": (sz, []),
-    "fhe_get_chunk": (sz, []),
     "fhe_prof_enable": (None, [i32]),
     "fhe_prof_reset": (None, []),
     "fhe_prof_count": (sz, []),

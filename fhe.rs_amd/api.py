@@ -574,7 +574,10 @@ class BfvParameters:
     """The device-table part of bfv::BfvParameters (crates/fhe/src/bfv/parameters.rs:560-738):
     per-level contexts, the extended multiplication basis and per-level mul parameters."""
 
-    def __init__(self, degree, plaintext_modulus, moduli=None, moduli_sizes=None, device=0):
+    def __init__(self, degree, plaintext_modulus, moduli=None, moduli_sizes=None, device=0, tables_fn=None):
+        """tables_fn(modulus, degree) -> dict(omegas, omegas_shoup, zetas_inv, zetas_inv_shoup, size_inv,
+        size_inv_shoup): the host's NttOperator tables for every modulus the parameter set builds a context over
+        (fhe_params_create_with_tables); None: the engine's own psi (fhe_params_create)."""
         L = _lib.lib()
         if moduli_sizes:
             sizes = (C.c_size_t * len(moduli_sizes))(*moduli_sizes)
@@ -583,7 +586,22 @@ class BfvParameters:
             moduli = [int(x) for x in out]
         m = _np(moduli)
         h = C.c_void_p()
-        check(L.fhe_params_create(device, degree, len(m), _ptr(m), plaintext_modulus, C.byref(h)))
+        if tables_fn is None:
+            check(L.fhe_params_create(device, degree, len(m), _ptr(m), plaintext_modulus, C.byref(h)))
+        else:
+            def _cb(_user, modulus, deg, om, oms, zi, zis, si, sis):
+                try:
+                    t = tables_fn(int(modulus), int(deg))
+                    for dst, key in ((om, "omegas"), (oms, "omegas_shoup"), (zi, "zetas_inv"), (zis, "zetas_inv_shoup")):
+                        C.memmove(dst, _np(t[key]).ctypes.data, 8 * deg)
+                    si[0], sis[0] = int(t["size_inv"]), int(t["size_inv_shoup"])
+                    return 0
+                except Exception:
+                    return 1
+            cb = _lib.NTT_TABLES_FN(_cb)
+            check(L.fhe_params_create_with_tables(device, degree, len(m), _ptr(m), plaintext_modulus, cb, None,
+                                                  C.byref(h)))
+            self._cb = cb   # fhe_mul_create_default may call it again (a level-specific extended basis)
         self._h = h
         self.degree, self.plaintext, self.moduli, self.device = degree, plaintext_modulus, [int(x) for x in m], device
         self.max_level = L.fhe_params_max_level(h)
@@ -682,6 +700,29 @@ class Multiplicator:
         if getattr(self, "_h", None) is not None and _lib._lib is not None:
             _lib._lib.fhe_mul_destroy(self._h)
 
+    def basis(self):
+        """Moduli of the multiplication context (Multiplicator::mul_ctx)."""
+        n = C.c_size_t()
+        check(_lib.lib().fhe_mul_basis(self._h, C.byref(n), None))
+        out = np.zeros(n.value, dtype=np.uint64)
+        check(_lib.lib().fhe_mul_basis(self._h, C.byref(n), _ptr(out)))
+        return [int(x) for x in out]
+
+    def set_chunk(self, chunk):
+        """Ciphertext pairs per pipeline pass (0 = default); an option of this handle (fhe_mul_set_chunk)."""
+        check(_lib.lib().fhe_mul_set_chunk(self._h, chunk))
+        return self
+
+    def set_streams(self, n):
+        """2 (default): chunks alternate between the caller's stream and an internal one; 1: caller's stream only."""
+        check(_lib.lib().fhe_mul_set_streams(self._h, n))
+        return self
+
+    def options(self):
+        c, s = C.c_size_t(), C.c_size_t()
+        check(_lib.lib().fhe_mul_get_options(self._h, C.byref(c), C.byref(s)))
+        return dict(chunk=c.value, streams=s.value)
+
     def multiply(self, lhs, rhs):
         """Multiplicator::multiply: lhs, rhs [..., 2, L, N] Ntt -> [..., parts, rows, N] Ntt."""
         L = _lib.lib()
@@ -770,12 +811,3 @@ def prof_report():
 def workspace_trim():
     """Frees the engine's idle scratch buffers; returns the bytes released."""
     return int(_lib.lib().fhe_workspace_trim())
-
-
-def set_chunk(chunk):
-    _lib.lib().fhe_set_chunk(chunk)
-
-
-def set_streams(n):
-    """1 (default): multiply on the caller's stream; 2: chunks alternate with an internal stream (fhe_set_streams)."""
-    _lib.lib().fhe_set_streams(n)

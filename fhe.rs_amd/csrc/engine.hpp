@@ -5,6 +5,7 @@
 // this image; the C ABI in fhe_hip.cpp is a thin layer over these classes.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -224,10 +225,19 @@ private:
     std::vector<Block> blocks;
     std::mutex mu;
 };
+// `wipe`: the block held secret-dependent data (decryption intermediates, which the reference keeps in
+// Zeroizing buffers, F/bfv/keys/secret_key.rs:198-226): it is cleared on its stream before it returns to the pool.
 struct WsGuard {
     void *p;
-    WsGuard(size_t bytes, hipStream_t s) : p(Workspace::get().acquire(bytes, s)) {}
-    ~WsGuard() { Workspace::get().release(p); }
+    size_t bytes;
+    hipStream_t stream;
+    bool wipe;
+    WsGuard(size_t bytes_, hipStream_t s, bool wipe_ = false)
+        : p(Workspace::get().acquire(bytes_, s)), bytes(bytes_), stream(s), wipe(wipe_) {}
+    ~WsGuard() {
+        if (wipe && bytes) (void)hipMemsetAsync(p, 0, bytes, stream);
+        Workspace::get().release(p);
+    }
     u64 *u() const { return (u64 *)p; }
 };
 
@@ -1021,7 +1031,8 @@ inline void decrypt(const Scaler &sc, u64 t, const u64 *s_ntt, const u64 *ct, si
     const ModConsts tm = make_mod_consts(t);
     const u64 PL = (u64)cc.L * cc.n;
 
-    WsGuard ph(batch * PL * sizeof(u64), s), d(batch * pc.L * cc.n * sizeof(u64), s);
+    // phase and scaled plaintext are secret-dependent: cleared before the blocks go back to the pool
+    WsGuard ph(batch * PL * sizeof(u64), s, true), d(batch * pc.L * cc.n * sizeof(u64), s, true);
     FHE_LAUNCH("phase", k::phase_kernel, dim3(blocks_for(PL, EW_THREADS), (unsigned)batch), dim3(EW_THREADS), 0, s, ct,
                s_ntt, ph.u(), cc.dmods(), (uint32_t)nparts, (uint32_t)cc.logn, PL);
     launch_ntt(cc, true, ph.u(), ph.u(), full_map(cc, cc.L), batch, k::PRO_NONE, s);
@@ -1074,26 +1085,22 @@ inline void expand(const Ksk *const *gks, size_t nlevels, const u64 *ct, u64 *ou
 }
 
 // --------------------------------------------------------------------- Multiplicator ----
+// Execution options live on the handle (not in process globals): concurrent callers that share a Mul all see the
+// same, atomically read values, and a call reads them exactly once on entry.
+//   chunk   ciphertext pairs per pipeline pass; 0 = default (equal chunks under a workspace budget)
+//   streams 2 (default): the chunks of a multiply alternate between the caller's stream and an internal one
+//           (fork / join through events): while one chunk's launch drains, the other chunk's kernels fill the
+//           idle workgroup slots, which makes small, cache-friendly chunks affordable (+4.5 % at C2).
+//           1: the whole pipeline on the caller's stream (exact per-kernel attribution for profiling).
 struct Mul {
     const Scaler *ext_lhs = nullptr, *ext_rhs = nullptr, *down = nullptr;
     const Ksk *rk = nullptr;
     bool mod_switch = false;
     const Ctx *base = nullptr, *mulc = nullptr;
+    std::atomic<size_t> chunk{0}, streams{2};
     size_t out_parts() const { return rk ? 2 : 3; }
     size_t out_rows() const { return mod_switch ? base->L - 1 : base->L; }
 };
-
-inline size_t &chunk_setting() {
-    static size_t chunk = 0;
-    return chunk;
-}
-// 1 (default): the whole pipeline on the caller's stream.  2: the chunks of a multiply alternate between the
-// caller's stream and an internal one (fork / join through events): while one chunk's launch drains, the other
-// chunk's kernels fill the idle workgroup slots, which makes small, cache-friendly chunks affordable.
-inline size_t &streams_setting() {
-    static size_t n = 1;
-    return n;
-}
 struct AuxStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
@@ -1111,15 +1118,15 @@ inline AuxStream &aux_for(int device, hipStream_t user) {
     return a;
 }
 
-inline size_t default_chunk(const Ctx &base, const Ctx &mulc, size_t batch) {
-    if (chunk_setting()) return std::min(batch, chunk_setting());
+inline size_t default_chunk(const Ctx &base, const Ctx &mulc, size_t batch, size_t chunk_opt, size_t streams_opt) {
+    if (chunk_opt) return std::min(batch, chunk_opt);
     // Every launch should cover >> 512 workgroup slots (small chunks lose to tail effects: 64 pairs per
     // chunk is 15 % slower at C2), but beyond ~3 GiB of workspace nothing is gained and the step-to-step
     // reuse in the 256 MiB Infinity Cache is lost (chunks of 256-512 pairs measured 1.5 % ahead of one
     // 1024-pair chunk).  The batch is split into equal chunks under that budget.
     const size_t per_ct = (7 * mulc.L + 7 * base.L) * mulc.n * sizeof(u64);
     // two streams: 768 MiB per chunk (128 pairs at C2) measured best, see DESIGN.md section 6
-    const size_t budget = streams_setting() >= 2 ? (size_t)768 << 20 : (size_t)3 << 30;
+    const size_t budget = streams_opt >= 2 ? (size_t)768 << 20 : (size_t)3 << 30;
     const size_t cap = std::max<size_t>(1, std::min<size_t>(budget / per_ct, 4096));
     const size_t nchunks = (batch + cap - 1) / cap;
     return (batch + nchunks - 1) / nchunks;
@@ -1168,7 +1175,8 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     const u64 PL = (u64)L * N, PK = (u64)K * N;
     const size_t parts = m.out_parts();
     if (!batch) return;
-    const size_t chunk = default_chunk(b, e, batch);
+    const size_t streams_opt = m.streams.load(std::memory_order_relaxed);
+    const size_t chunk = default_chunk(b, e, batch, m.chunk.load(std::memory_order_relaxed), streams_opt);
     // the extenders copy the shared prefix rows verbatim; when both share all L rows the tensor
     // kernel reads those rows from the inputs directly and the copy is skipped
     const bool skip_copy = m.ext_lhs->ncommon == L && m.ext_rhs->ncommon == L && !debug_flag("FHE_NO_SKIP_COPY");
@@ -1180,7 +1188,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     };
     const size_t pre_bytes = m.mod_switch ? chunk * parts * PL * sizeof(u64) : 8;
     const size_t nchunks = (batch + chunk - 1) / chunk;
-    const bool dual = streams_setting() >= 2 && nchunks >= 2;
+    const bool dual = streams_opt >= 2 && nchunks >= 2;
     hipStream_t lanes[2] = {s0, s0};
     AuxStream *aux = nullptr;
     struct Join {  // the internal stream always rejoins the caller's, also on an error path

@@ -30,6 +30,9 @@ struct fhe_mul {
     std::vector<std::unique_ptr<fhe_scaler>> scalers;
 };
 struct fhe_params {
+    int device = -1;
+    fhe_ntt_tables_fn tables = nullptr;  // the host's NTT tables (NULL: the engine's own psi)
+    void *tables_user = nullptr;
     size_t degree = 0;
     u64 plaintext = 0;
     std::vector<u64> moduli;
@@ -89,8 +92,14 @@ void set_device(const Ctx &c) {
 // Host-pointer convenience: copy in, run `body(device_ptrs...)` on the null stream, copy out.
 struct HostIO {
     std::vector<void *> bufs;
+    std::vector<std::pair<void *, size_t>> secrets;  // staging copies cleared before they are freed
     ~HostIO() {
+        for (auto &s : secrets) (void)hipMemset(s.first, 0, s.second);
         for (void *p : bufs) (void)hipFree(p);
+    }
+    u64 *secret(u64 *d, size_t count) {
+        secrets.emplace_back(d, std::max<size_t>(count, 1) * sizeof(u64));
+        return d;
     }
     u64 *in(const u64 *h, size_t count) {
         u64 *d = out(count);
@@ -118,6 +127,18 @@ std::unique_ptr<Ksk> make_ksk(const Ctx &ct, const Ctx &kc, size_t ndigits, size
     k_->ndigits = ndigits;
     k_->log_base = log_base;
     return k_;
+}
+// Context over `moduli` whose NTT tables come from the host's callback (NULL: the engine's own psi).
+std::unique_ptr<Ctx> ctx_create_cb(int device, size_t degree, const std::vector<u64> &moduli, fhe_ntt_tables_fn fn,
+                                   void *user) {
+    if (!fn) return ctx_create(device, degree, moduli, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    const size_t L = moduli.size();
+    std::vector<u64> om(L * degree), oms(L * degree), zi(L * degree), zis(L * degree), si(L), sis(L);
+    for (size_t i = 0; i < L; i++)
+        if (fn(user, moduli[i], degree, &om[i * degree], &oms[i * degree], &zi[i * degree], &zis[i * degree], &si[i],
+               &sis[i]) != 0)
+            throw StatusError(FHE_E_NTT_UNAVAILABLE, "NttOperatorUnavailable: the host's table callback failed");
+    return ctx_create(device, degree, moduli, om.data(), oms.data(), zi.data(), zis.data(), si.data(), sis.data());
 }
 }  // namespace
 
@@ -615,7 +636,9 @@ fhe_status fhe_ksk_create(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, size_t 
             d.alloc(count);
             FHE_HIP_CHECK(hipMemcpy(d.p, src, count * sizeof(u64), hipMemcpyHostToDevice));
         };
-        auto shoup_of = [&](const u64 *src) {
+        // every coefficient must be a canonical residue (the Shoup quotient of an unreduced value does not fit
+        // 64 bits and the key would silently give wrong results); supplied twins must be the twins
+        auto shoup_of = [&](const u64 *src, const u64 *given) {
             std::vector<u64> v(count);
             for (size_t i = 0; i < ndigits; i++)
                 for (size_t r = 0; r < kc.L; r++)
@@ -623,19 +646,19 @@ fhe_status fhe_ksk_create(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, size_t 
                         const size_t x = (i * kc.L + r) * kc.n + j;
                         if (src[x] >= kc.moduli[r]) throw StatusError(FHE_E_ARG, "key coefficient not reduced");
                         v[x] = shoup(src[x], kc.moduli[r]);
+                        if (given && given[x] != v[x])
+                            throw StatusError(FHE_E_ARG, "Shoup twin is not floor(c * 2^64 / q)");
                     }
             return v;
         };
         up(h->k->c0, c0);
         up(h->k->c1, c1);
-        if (c0_shoup) up(h->k->c0s, c0_shoup);
-        else {
-            auto v = shoup_of(c0);
+        {
+            auto v = shoup_of(c0, c0_shoup);
             up(h->k->c0s, v.data());
         }
-        if (c1_shoup) up(h->k->c1s, c1_shoup);
-        else {
-            auto v = shoup_of(c1);
+        {
+            auto v = shoup_of(c1, c1_shoup);
             up(h->k->c1s, v.data());
         }
         *out = h.release();
@@ -664,6 +687,8 @@ fhe_status fhe_ksk_create_dev(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, siz
             for (size_t r = 0; r < kc.L; r++)
                 for (size_t j = 0; j < kc.n; j++) {
                     const size_t x = (i * kc.L + r) * kc.n + j;
+                    if (h0[x] >= kc.moduli[r] || h1[x] >= kc.moduli[r])
+                        throw StatusError(FHE_E_ARG, "key coefficient not reduced");
                     s0[x] = shoup(h0[x], kc.moduli[r]);
                     s1[x] = shoup(h1[x], kc.moduli[r]);
                 }
@@ -970,7 +995,10 @@ fhe_status fhe_bfv_decrypt(const fhe_scaler *sc, uint64_t t, const uint64_t *s_n
         set_device(cc);
         const size_t pe = cc.L * cc.n;
         HostIO io;
-        u64 *ds = io.in(s_ntt, pe), *di = io.in(ct, batch * nparts * pe), *dout = io.out(batch * cc.n);
+        // the staged secret key and the plaintext are cleared on the device before their buffers are freed
+        // (the reference wraps s, c and the result in Zeroizing, F/bfv/keys/secret_key.rs:198-226)
+        u64 *ds = io.secret(io.in(s_ntt, pe), pe), *di = io.in(ct, batch * nparts * pe);
+        u64 *dout = io.secret(io.out(batch * cc.n), batch * cc.n);
         decrypt(*sc->s, t, ds, di, nparts, dout, batch, nullptr);
         io.back(out, dout, batch * cc.n);
     });
@@ -1060,6 +1088,34 @@ fhe_status fhe_mul_out_shape(const fhe_mul *m, size_t *parts, size_t *rows) {
         if (rows) *rows = m->m->out_rows();
     });
 }
+fhe_status fhe_mul_basis(const fhe_mul *m, size_t *count, uint64_t *moduli) {
+    return guard([&] {
+        need(m, "mul");
+        need(count, "count");
+        *count = m->m->mulc->L;
+        if (moduli) std::copy(m->m->mulc->moduli.begin(), m->m->mulc->moduli.end(), moduli);
+    });
+}
+fhe_status fhe_mul_set_chunk(fhe_mul *m, size_t chunk) {
+    return guard([&] {
+        need(m, "mul");
+        m->m->chunk.store(chunk, std::memory_order_relaxed);
+    });
+}
+fhe_status fhe_mul_set_streams(fhe_mul *m, size_t streams) {
+    return guard([&] {
+        need(m, "mul");
+        require(streams == 1 || streams == 2, E_ARG, "streams must be 1 or 2");
+        m->m->streams.store(streams, std::memory_order_relaxed);
+    });
+}
+fhe_status fhe_mul_get_options(const fhe_mul *m, size_t *chunk, size_t *streams) {
+    return guard([&] {
+        need(m, "mul");
+        if (chunk) *chunk = m->m->chunk.load(std::memory_order_relaxed);
+        if (streams) *streams = m->m->streams.load(std::memory_order_relaxed);
+    });
+}
 fhe_status fhe_bfv_mul_dev(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out, size_t batch,
                            void *stream) {
     return guard([&] {
@@ -1131,8 +1187,9 @@ fhe_status fhe_bfv_tensor(const fhe_mul *m, size_t lhs_parts, size_t rhs_parts, 
 }
 
 // -------------------------------------------------------------------------- params ----
-fhe_status fhe_params_create(int device, size_t degree, size_t nmoduli, const uint64_t *moduli,
-                             uint64_t plaintext_modulus, fhe_params **out) {
+fhe_status fhe_params_create_with_tables(int device, size_t degree, size_t nmoduli, const uint64_t *moduli,
+                                         uint64_t plaintext_modulus, fhe_ntt_tables_fn tables, void *user,
+                                         fhe_params **out) {
     return guard([&] {
         need(out, "out");
         *out = nullptr;
@@ -1140,11 +1197,14 @@ fhe_status fhe_params_create(int device, size_t degree, size_t nmoduli, const ui
         need(moduli, "moduli");
         require(plaintext_modulus >= 2, E_ARG, "plaintext modulus must be >= 2");
         auto p = std::make_unique<fhe_params>();
+        p->device = device;
+        p->tables = tables;
+        p->tables_user = user;
         p->degree = degree;
         p->plaintext = plaintext_modulus;
         p->moduli.assign(moduli, moduli + nmoduli);
         for (u64 q : p->moduli) p->moduli_sizes.push_back(64 - (size_t)__builtin_clzll(q | 1));
-        p->top = wrap_ctx(ctx_create(device, degree, p->moduli, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+        p->top = wrap_ctx(ctx_create_cb(device, degree, p->moduli, tables, user));
         // extended basis: n+1 primes of 62 bits (parameters.rs:660-676)
         std::vector<u64> ext = extended_basis_primes(degree, p->moduli, nmoduli + 1);
         BigUint t(plaintext_modulus);
@@ -1155,7 +1215,7 @@ fhe_status fhe_params_create(int device, size_t degree, size_t nmoduli, const ui
             const size_t n_moduli = (modulus_size + 60 + 61) / 62;  // div_ceil
             std::vector<u64> mm(p->moduli.begin(), p->moduli.begin() + nl);
             mm.insert(mm.end(), ext.begin(), ext.begin() + n_moduli);
-            auto mc = wrap_ctx(ctx_create(device, degree, mm, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+            auto mc = wrap_ctx(ctx_create_cb(device, degree, mm, tables, user));
             const Ctx &base = *p->top->c->at_level(level);
             RnsContext rb(base.moduli);
             auto e = std::make_unique<fhe_scaler>();
@@ -1168,6 +1228,10 @@ fhe_status fhe_params_create(int device, size_t degree, size_t nmoduli, const ui
         }
         *out = p.release();
     });
+}
+fhe_status fhe_params_create(int device, size_t degree, size_t nmoduli, const uint64_t *moduli,
+                             uint64_t plaintext_modulus, fhe_params **out) {
+    return fhe_params_create_with_tables(device, degree, nmoduli, moduli, plaintext_modulus, nullptr, nullptr, out);
 }
 void fhe_params_destroy(fhe_params *p) { delete p; }
 size_t fhe_params_max_level(const fhe_params *p) { return p ? p->moduli.size() - 1 : 0; }
@@ -1204,11 +1268,35 @@ fhe_status fhe_mul_create_default(const fhe_params *p, size_t level, const fhe_k
     return guard([&] {
         FHE_PARAMS_LEVEL_CHECK();
         *out = nullptr;
-        // Multiplicator::default (mul.rs:101-138) derives the same extended basis as
-        // BfvParameters::build does for this level, so the per-level scalers are reused.
         auto h = std::make_unique<fhe_mul>();
-        h->m = make_mul(p->extender[level]->s.get(), p->extender[level]->s.get(), p->down[level]->s.get(),
-                        rk_or_null ? rk_or_null->k.get() : nullptr, mod_switch != 0);
+        const Scaler *ext = p->extender[level]->s.get(), *down = p->down[level]->s.get();
+        if (rk_or_null) {
+            // Multiplicator::default (mul.rs:101-138): the extension primes skip only the moduli of rk's level
+            // (parameters.rs:660-676 skips every top-level modulus).  Where the two bases differ -- a dropped
+            // top-level modulus is itself one of the first 62-bit NTT primes -- the handle gets its own
+            // multiplication context and scalers, exactly the reference's new_leveled_internal.
+            const Ctx &base = *p->top->c->at_level(level);
+            size_t modulus_size = 0;
+            for (size_t i = 0; i < base.L; i++) modulus_size += p->moduli_sizes[i];
+            const size_t n_moduli = (modulus_size + 60 + 61) / 62;
+            std::vector<u64> mm = base.moduli;
+            const std::vector<u64> extp = extended_basis_primes(p->degree, base.moduli, n_moduli);
+            mm.insert(mm.end(), extp.begin(), extp.end());
+            if (mm != p->mul_ctx[level]->c->moduli) {
+                auto mc = wrap_ctx(ctx_create_cb(p->device, p->degree, mm, p->tables, p->tables_user));
+                RnsContext rb(base.moduli);
+                auto e = std::make_unique<fhe_scaler>();
+                e->s = scaler_create(base, *mc->c, BigUint(1), BigUint(1));
+                auto d = std::make_unique<fhe_scaler>();
+                d->s = scaler_create(*mc->c, base, BigUint(p->plaintext), rb.product);
+                ext = e->s.get();
+                down = d->s.get();
+                h->ctxs.push_back(std::move(mc));
+                h->scalers.push_back(std::move(e));
+                h->scalers.push_back(std::move(d));
+            }
+        }
+        h->m = make_mul(ext, ext, down, rk_or_null ? rk_or_null->k.get() : nullptr, mod_switch != 0);
         *out = h.release();
     });
 }
@@ -1242,10 +1330,7 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
                    part0, total);
     });
 }
-void fhe_set_chunk(size_t chunk) { chunk_setting() = chunk; }
-void fhe_set_streams(size_t n) { streams_setting() = n < 1 ? 1 : (n > 2 ? 2 : n); }
 size_t fhe_workspace_trim(void) { return Workspace::get().trim(); }
-size_t fhe_get_chunk(void) { return chunk_setting(); }
 void fhe_prof_enable(int on) { Profiler::get().enabled = on != 0; }
 void fhe_prof_reset(void) {
     try {

@@ -235,7 +235,11 @@ fhe_status fhe_bfv_mul_plain_dev(const fhe_ctx *ctx, size_t nparts, const uint64
  * ((d_0 + t) mod q_0) mod t.  `cipher_plain_scaler`: from = the ciphertext context, to = the plaintext
  * context (a prefix of the moduli).  s_ntt [L][N]: the secret key polynomial over the ciphertext
  * context in Ntt form (the host builds it from its ternary coefficients, secret_key.rs:200-203).
- * ct [batch][nparts][L][N] Ntt -> out [batch][N], the plaintext polynomial's coefficients in [0, t). */
+ * ct [batch][nparts][L][N] Ntt -> out [batch][N], the plaintext polynomial's coefficients in [0, t).
+ * Secret hygiene (the reference wraps s, the phase and the scaled plaintext in Zeroizing, secret_key.rs:198-226):
+ * the engine's intermediates (phase, scaled plaintext) are cleared on the stream before their scratch blocks
+ * are reused; the host-pointer variant also clears its staged copies of s_ntt and of the result.  The `_dev`
+ * variant's s_ntt and out are caller-owned device buffers: clearing them is the caller's job. */
 fhe_status fhe_bfv_decrypt(const fhe_scaler *cipher_plain_scaler, uint64_t plaintext_modulus, const uint64_t *s_ntt,
                            const uint64_t *ct, size_t nparts, uint64_t *out, size_t batch);
 fhe_status fhe_bfv_decrypt_dev(const fhe_scaler *cipher_plain_scaler, uint64_t plaintext_modulus,
@@ -273,6 +277,21 @@ fhe_status fhe_mul_create(const fhe_scaler *extender_lhs, const fhe_scaler *exte
 void fhe_mul_destroy(fhe_mul *m);
 /* Output geometry: parts (2 with rk, else 3) and rows per part (L, or L-1 with mod switch). */
 fhe_status fhe_mul_out_shape(const fhe_mul *m, size_t *parts, size_t *rows);
+/* The multiplication basis (Multiplicator::mul_ctx moduli, mul.rs:84): *count = its length; moduli may be NULL. */
+fhe_status fhe_mul_basis(const fhe_mul *m, size_t *count, uint64_t *moduli);
+/* Execution options of fhe_bfv_mul(_dev), kept on the handle (there are no process-wide knobs): atomics, read
+ * once on entry of every call, so they may be set while other threads use the handle -- calls already running
+ * keep the values they started with.  (The reference's Multiplicator has no such state; these only choose how
+ * the same values are computed.)
+ *   chunk   ciphertext pairs per pipeline pass; 0 (default) = equal chunks under a workspace budget
+ *           (3 GiB with one stream: 512 pairs at N = 8192, 4 moduli; 768 MiB with two: 128 pairs)
+ *   streams 2 (default) = the chunks of a batch alternate between the caller's stream and an internal one,
+ *           forked from and joined back into the caller's stream with events: stream-ordered for the caller
+ *           exactly as with 1, capturable into a hipGraph, bit-identical results, +4.5 % at C2;
+ *           1 = the caller's stream only (per-kernel durations do not overlap: what profilers want). */
+fhe_status fhe_mul_set_chunk(fhe_mul *m, size_t chunk);
+fhe_status fhe_mul_set_streams(fhe_mul *m, size_t streams);
+fhe_status fhe_mul_get_options(const fhe_mul *m, size_t *chunk, size_t *streams);
 /* Multiplicator::multiply (F/bfv/ops/mul.rs:165-243), the metric's unit of work:
  * lhs, rhs [batch][2][L][N] Ntt -> out [batch][parts][rows][N] Ntt. */
 fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out, size_t batch);
@@ -295,14 +314,32 @@ fhe_status fhe_bfv_tensor_dev(const fhe_mul *m, size_t lhs_parts, size_t rhs_par
  * moduli may be generated first with fhe_generate_moduli. */
 fhe_status fhe_params_create(int device, size_t degree, size_t nmoduli, const uint64_t *moduli,
                              uint64_t plaintext_modulus, fhe_params **out);
+/* NTT tables of the host.  fhe_params_create derives its own primitive root psi per modulus (the smallest
+ * generator), so its handles agree only with Ntt-form data produced through THIS engine.  The reference draws
+ * psi from ChaCha8Rng::seed_from_u64(0) (M/ntt/native.rs:320-336; third-party RNG, not reproducible here), and
+ * every Ntt-form ciphertext or key made by the Rust host is in that evaluation order: a host that brings its own
+ * Ntt-form data MUST create the parameter set with fhe_params_create_with_tables.  The engine calls `tables`
+ * once for every modulus it builds a context over -- the ciphertext moduli and the 62-bit extension primes of
+ * parameters.rs:660-676 -- and the host fills the four [degree] tables and the two scalars of
+ * NttOperator::new(modulus, degree) (M/ntt/native.rs:16-26, same meaning as in fhe_ctx_create).  A non-zero
+ * return aborts creation with FHE_E_NTT_UNAVAILABLE.  tables == NULL behaves like fhe_params_create. */
+typedef int (*fhe_ntt_tables_fn)(void *user, uint64_t modulus, size_t degree, uint64_t *omegas,
+                                 uint64_t *omegas_shoup, uint64_t *zetas_inv, uint64_t *zetas_inv_shoup,
+                                 uint64_t *size_inv, uint64_t *size_inv_shoup);
+fhe_status fhe_params_create_with_tables(int device, size_t degree, size_t nmoduli, const uint64_t *moduli,
+                                         uint64_t plaintext_modulus, fhe_ntt_tables_fn tables, void *user,
+                                         fhe_params **out);
 void fhe_params_destroy(fhe_params *p);
 size_t fhe_params_max_level(const fhe_params *p);
 fhe_status fhe_params_ctx(const fhe_params *p, size_t level, const fhe_ctx **out);      /* context_at_level */
 fhe_status fhe_params_mul_ctx(const fhe_params *p, size_t level, const fhe_ctx **out);  /* mul_params.to    */
 fhe_status fhe_params_extender(const fhe_params *p, size_t level, const fhe_scaler **out);
 fhe_status fhe_params_down_scaler(const fhe_params *p, size_t level, const fhe_scaler **out);
-/* Multiplicator::default(rk) (F/bfv/ops/mul.rs:101-138) at rk's ciphertext level; rk == NULL
- * gives the `&ct * &ct` strategy without relinearisation (F/bfv/ops/mod.rs:259-358). */
+/* Multiplicator::default(rk) (F/bfv/ops/mul.rs:101-138) at rk's ciphertext level: the extension primes are
+ * the first 62-bit NTT primes that are not moduli OF THAT LEVEL (mul.rs:110-126) -- at level > 0 this can differ
+ * from the level's mul_params basis, which skips every top-level modulus (parameters.rs:660-676); the handle then
+ * owns its own multiplication context and scalers.  rk == NULL gives the `&ct * &ct` strategy without
+ * relinearisation (F/bfv/ops/mod.rs:259-358), which uses the level's mul_params as the reference does. */
 fhe_status fhe_mul_create_default(const fhe_params *p, size_t level, const fhe_ksk *rk_or_null, int mod_switch,
                                   fhe_mul **out);
 
@@ -320,18 +357,9 @@ fhe_status fhe_generate_moduli(const size_t *sizes, size_t count, size_t degree,
  * out[b][part_local][row][coeff], ct = ct0 + b, part = part0 + part_local. */
 fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0, uint64_t part0, size_t nparts,
                                  uint64_t *out, size_t batch, void *stream);
-/* Chunk (ciphertext pairs per pipeline pass) used by fhe_bfv_mul(_dev); 0 = default: the batch is split into
- * equal chunks of at most 3 GiB of workspace (512 pairs at N = 8192, 4 moduli).  Process-wide tuning knob. */
-void fhe_set_chunk(size_t chunk);
-/* Streams used by fhe_bfv_mul(_dev) (F/bfv/ops/mul.rs:165-243 on a batch): 1 (default) = the caller's stream only;
- * 2 = the chunks of a batch alternate between the caller's stream and an internal one, forked from and joined
- * back into the caller's stream with events (stream-ordered for the caller exactly as with 1; capturable).
- * Smaller chunks (768 MiB of workspace each) are then used.  Process-wide tuning knob. */
-void fhe_set_streams(size_t n);
 /* The engine keeps its scratch buffers (grow-only, reused in stream order per device) between calls;
  * this frees every idle one and returns the number of bytes released. */
 size_t fhe_workspace_trim(void);
-size_t fhe_get_chunk(void);
 /* Per-kernel HIP-event timing (events recorded on the launching stream). */
 void fhe_prof_enable(int on);
 void fhe_prof_reset(void);

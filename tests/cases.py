@@ -229,6 +229,89 @@ def case_params(fhe, nmod=3, n=16):
                                            od.theta_garner_shift, 0]
 
 
+def case_mul_default_level_basis(fhe, nmod=3, n=16):
+    """ops/mul.rs:101-138 vs parameters.rs:660-676: Multiplicator::default skips only the moduli of rk's level
+    when it picks its 62-bit extension primes; with 62-bit ciphertext moduli a dropped top-level modulus is
+    itself one of those primes, so at level > 0 the basis differs from the level's mul_params basis."""
+    opar, par = _params(fhe, nmod, n)
+    rng = random.Random(5)
+    sk = obfv.SecretKey.random(opar, rng)
+    differs = 0
+    for level in range(nmod - 1):
+        ork = obfv.RelinearizationKey(sk, rng, level, level)
+        c0, c0s, c1, c1s = ksk_arrays(ork.ksk)
+        ctx = par.context_at_level(level)
+        rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1, c0s, c1s))
+        want = obfv.Multiplicator.default_extended_basis(opar, level)
+        assert fhe.Multiplicator.default(par, rk, level).basis() == want
+        # `&ct * &ct` (no key) uses the level's mul_params, as the reference does (ops/mod.rs:259-358)
+        assert fhe.Multiplicator.default(par, None, level).basis() == opar.mul_params[level].to.moduli
+        differs += want != opar.mul_params[level].to.moduli
+    assert differs > 0, "the shape was meant to exercise differing bases"
+
+
+def case_params_with_tables(fhe, dev, nmod=3, n=16):
+    """fhe_params_create_with_tables: the host supplies NttOperator tables for every modulus (here built from a
+    psi that is NOT the engine's default -- psi^3 is another primitive 2N-th root), and every Ntt-form result
+    follows that evaluation order: a forward NTT equals the oracle's under the same tables, and the multiply
+    pipeline run on ciphertexts transformed under those tables decrypts/compares like the default one."""
+    from fhe_oracle import ntt as ontt
+    from fhe_oracle.rq import Context as OCtx
+    from fhe_oracle.zq import Modulus
+    x = Xfer(dev)
+    opar = obfv.BfvParameters.default_arc(nmod, n)
+    seen = []
+
+    def alt_op(modulus, degree):
+        op = ontt.NttOperator(Modulus(modulus), degree)
+        return ontt.NttOperator(Modulus(modulus), degree, psi=pow(op.psi, 3, modulus))
+
+    def alt_tables(modulus, degree):
+        seen.append(modulus)
+        alt = alt_op(modulus, degree)
+        return dict(omegas=alt.omegas, omegas_shoup=alt.omegas_shoup, zetas_inv=alt.zetas_inv,
+                    zetas_inv_shoup=alt.zetas_inv_shoup, size_inv=alt.size_inv, size_inv_shoup=alt.size_inv_shoup)
+
+    par = fhe.BfvParameters(n, opar.plaintext, moduli=opar.moduli, tables_fn=alt_tables)
+    assert set(opar.moduli) <= set(seen) and len(set(seen)) > nmod   # ciphertext moduli and extension primes
+    ref = fhe.BfvParameters(n, opar.plaintext, moduli=opar.moduli)
+    ctx, rctx = par.context_at_level(0), ref.context_at_level(0)
+    assert not np.array_equal(ctx.table(0), rctx.table(0))
+    rng = random.Random(77)
+    octx = OCtx(opar.moduli, n)
+    pb = np.stack([arr(rand_poly(octx, POWER_BASIS, rng)) for _ in range(4)]).reshape(2, 2, nmod, n)
+    # the same PowerBasis ciphertexts taken to Ntt form under each table set
+    a_alt = x.back(ctx.ntt_forward(x.to(pb.copy())))
+    a_ref = x.back(rctx.ntt_forward(x.to(pb.copy())))
+    assert not np.array_equal(a_alt, a_ref)
+    for r in range(nmod):   # explicit check of one row against the oracle operator with the alternative psi
+        assert a_alt[0, 0, r].tolist() == alt_op(opar.moduli[r], n).forward([int(v) for v in pb[0, 0, r]])
+    # multiply without relinearisation: PowerBasis results are psi-independent
+    m_alt, m_ref = fhe.Multiplicator.default(par, None, 0), fhe.Multiplicator.default(ref, None, 0)
+    o_alt = x.back(ctx.ntt_backward(m_alt.multiply(x.to(a_alt), x.to(a_alt))))
+    o_ref = x.back(rctx.ntt_backward(m_ref.multiply(x.to(a_ref), x.to(a_ref))))
+    assert np.array_equal(o_alt, o_ref)
+
+
+def case_ksk_validation(fhe, nmod=3, n=16):
+    """Key coefficients must be canonical and supplied Shoup twins must be the twins, in every creation path."""
+    opar, par = _params(fhe, nmod, n)
+    ctx = par.context_at_level(0)
+    rng = random.Random(3)
+    sk = obfv.SecretKey.random(opar, rng)
+    c0, c0s, c1, c1s = ksk_arrays(obfv.RelinearizationKey(sk, rng).ksk)
+    fhe.KeySwitchingKey(ctx, ctx, c0, c1, c0s, c1s)
+    bad = c0.copy()
+    bad[1, 2, 3] += np.uint64(opar.moduli[2])
+    for args in ((bad, c1, None, None), (bad, c1, c0s, c1s), (c0, c1, c1s, c1s)):
+        try:
+            fhe.KeySwitchingKey(ctx, ctx, *args)
+        except fhe.FheError as e:
+            assert e.code == -1, e
+        else:
+            raise AssertionError("unreduced key / wrong twin accepted")
+
+
 def case_key_switch_levels(fhe, dev, nmod=4, n=16):
     """key_switching_key.rs:241-320, 532-598 and relinearization_key.rs:219-273: every
     (ciphertext level, key level) pair; relinearizes incl. the switch_down_to fix-up."""
@@ -329,26 +412,20 @@ def case_multiply(fhe, dev, nmod=3, n=16, batch=3, level=0, chunk=0, streams=1):
     A = [sk.encrypt([rng.randrange(t) for _ in range(n)], rng, level) for _ in range(batch)]
     B = [sk.encrypt([rng.randrange(t) for _ in range(n)], rng, level) for _ in range(batch)]
     lhs, rhs = x.to(np.stack([ct_arr(c) for c in A])), x.to(np.stack([ct_arr(c) for c in B]))
-    if chunk:
-        fhe.set_chunk(chunk)
-    fhe.set_streams(streams)
-    try:
-        for mod_switch in ([False, True] if level < opar.max_level() else [False]):
-            om = obfv.Multiplicator.default(ork)
-            if mod_switch:
-                om.enable_mod_switching()
-            m = fhe.Multiplicator.default(par, rk, level, mod_switch)
-            got = x.back(m.multiply(lhs, rhs))
-            for i in range(batch):
-                want = om.multiply(A[i], B[i])
-                assert np.array_equal(got[i], ct_arr(want)), (mod_switch, i)
-        m3 = fhe.Multiplicator.default(par, None, level)
-        got = x.back(m3.multiply(lhs, rhs))
+    for mod_switch in ([False, True] if level < opar.max_level() else [False]):
+        om = obfv.Multiplicator.default(ork)
+        if mod_switch:
+            om.enable_mod_switching()
+        m = fhe.Multiplicator.default(par, rk, level, mod_switch).set_chunk(chunk).set_streams(streams)
+        assert m.options() == dict(chunk=chunk, streams=streams)
+        got = x.back(m.multiply(lhs, rhs))
         for i in range(batch):
-            assert np.array_equal(got[i], ct_arr(A[i].mul(B[i])))
-    finally:
-        fhe.set_chunk(0)
-        fhe.set_streams(1)
+            want = om.multiply(A[i], B[i])
+            assert np.array_equal(got[i], ct_arr(want)), (mod_switch, i)
+    m3 = fhe.Multiplicator.default(par, None, level).set_chunk(chunk).set_streams(streams)
+    got = x.back(m3.multiply(lhs, rhs))
+    for i in range(batch):
+        assert np.array_equal(got[i], ct_arr(A[i].mul(B[i])))
 
 
 def case_multiply_custom_factors(fhe, dev, n=16):

@@ -151,6 +151,10 @@ inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind
     memcpy(d, s, n);
     return hipSuccess;
 }
+inline hipError_t hipMemset(void *d, int v, size_t n) {
+    memset(d, v, n);
+    return hipSuccess;
+}
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
     memset(d, v, n);
     return hipSuccess;

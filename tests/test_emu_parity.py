@@ -68,7 +68,7 @@ def test_multiply(fhe, nmod, level, chunk):
 
 
 def test_multiply_two_streams(fhe):
-    """fhe_set_streams(2): chunks alternate between the caller's stream and the internal one (5 pairs in chunks
+    """fhe_mul_set_streams(2): chunks alternate between the caller's stream and the internal one (5 pairs in chunks
     of 2 and 1: three and five chunks, odd counts included); same results."""
     cases.case_multiply(fhe, False, nmod=3, level=0, chunk=2, streams=2, batch=5)
     cases.case_multiply(fhe, False, nmod=2, level=0, chunk=1, streams=2, batch=5)
@@ -155,6 +155,18 @@ def test_workspace_trim(fhe):
     assert fhe.workspace_trim() > 0
     assert fhe.workspace_trim() == 0
     cases.case_multiply(fhe, False, nmod=2)
+
+
+def test_mul_default_level_basis(fhe):
+    cases.case_mul_default_level_basis(fhe)
+
+
+def test_params_with_tables(fhe):
+    cases.case_params_with_tables(fhe, False)
+
+
+def test_ksk_validation(fhe):
+    cases.case_ksk_validation(fhe)
 
 
 def test_errors(fhe):

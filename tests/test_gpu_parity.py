@@ -136,6 +136,18 @@ def test_wire_format(fhe, dev):
     cases.case_wire_format(fhe, dev, n=8192)
 
 
+def test_mul_default_level_basis(fhe):
+    cases.case_mul_default_level_basis(fhe)
+
+
+def test_params_with_tables(fhe):
+    cases.case_params_with_tables(fhe, True)
+
+
+def test_ksk_validation(fhe):
+    cases.case_ksk_validation(fhe)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 
@@ -207,9 +219,10 @@ def test_concurrent_streams_share_handles(fhe, streams):
     want = [m.multiply(a, b) for a, b in ins]
     torch.cuda.synchronize()
     got, errs = [None] * 4, []
-    fhe.set_streams(streams)
+    # options live on the handle: set once here, read atomically by every concurrent call
+    m.set_streams(streams)
     if streams == 2:
-        fhe.set_chunk(5)
+        m.set_chunk(5)
 
     def worker(i):
         try:
@@ -221,12 +234,11 @@ def test_concurrent_streams_share_handles(fhe, streams):
         except Exception as e:  # pragma: no cover
             errs.append(e)
     th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
-    try:
-        [t.start() for t in th]
-        [t.join() for t in th]
-    finally:
-        fhe.set_streams(1)
-        fhe.set_chunk(0)
+    [t.start() for t in th]
+    # flipping the handle's options while calls are in flight is allowed (each call reads them once on entry)
+    for k in range(6):
+        m.set_chunk((0, 5, 7)[k % 3])
+    [t.join() for t in th]
     assert not errs, errs
     for i in range(4):
         assert torch.equal(got[i], want[i])
@@ -301,7 +313,7 @@ def test_dev_entry_points_are_graph_capturable(fhe):
 
 
 def test_multiply_two_streams(fhe):
-    """fhe_set_streams(2) at C2's shape: chunks of 128 pairs alternating between two streams give bit-identical
+    """Two-stream mode (the handle's default; fhe_mul_set_streams) at C2's shape: chunks of 128 pairs alternating between two streams give bit-identical
     ciphertexts to the single-stream pipeline (which the other tests tie to the oracle), repeatedly, also when
     the call is captured into a hipGraph (the internal stream forks from / joins the capturing stream)."""
     import torch
@@ -314,29 +326,28 @@ def test_multiply_two_streams(fhe):
     c0, c1 = full_size.device_key(ctx, 11, len(q))
     m = fhe.Multiplicator.default(par, fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1)), 0)
     a, b = ctx.synth_uniform(21, 0, 0, 2, batch), ctx.synth_uniform(21, 0, 2, 2, batch)
+    m.set_streams(1)
     want = m.multiply(a, b)
     torch.cuda.synchronize()
-    fhe.set_streams(2)
-    try:
-        for _ in range(3):
-            got = m.multiply(a, b)
-            torch.cuda.synchronize()
-            assert torch.equal(got, want)
-        # stream order for the caller: work enqueued right after the call sees the complete result
+    m.set_streams(2)
+    assert m.options()["streams"] == 2
+    for _ in range(3):
         got = m.multiply(a, b)
-        chk = (got != want).sum()
-        assert int(chk.item()) == 0
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            m.multiply(a, b)
-        side.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
-            out = m.multiply(a, b)
-        out.zero_()
-        g.replay()
         torch.cuda.synchronize()
-        assert torch.equal(out, want)
-    finally:
-        fhe.set_streams(1)
+        assert torch.equal(got, want)
+    # stream order for the caller: work enqueued right after the call sees the complete result
+    got = m.multiply(a, b)
+    chk = (got != want).sum()
+    assert int(chk.item()) == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.multiply(a, b)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out = m.multiply(a, b)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)

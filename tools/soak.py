@@ -23,13 +23,13 @@ def main():
     L = ctx.nmoduli
     kk = ctx.synth_uniform(7, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, n)
     ksk = fhe.KeySwitchingKey(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous())
-    mul = fhe.Multiplicator.default(par, fhe.RelinearizationKey(ksk), 0)
+    mul = fhe.Multiplicator.default(par, fhe.RelinearizationKey(ksk), 0).set_streams(1)
     gk = fhe.GaloisKey(ksk, 3)
     a, b = ctx.synth_uniform(7, 0, 0, 2, 1024), ctx.synth_uniform(7, 0, 2, 2, 1024)
     ref_m, ref_r = mul.multiply(a, b), gk.relinearize(a)   # single-stream reference
     torch.cuda.synchronize()
     streams = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    fhe.set_streams(streams)                               # 2: chunks alternate between two streams
+    mul.set_streams(streams)                               # 2 (the default): chunks alternate between two streams
     bad, t0 = 0, time.time()
     for i in range(reps):
         m, r = mul.multiply(a, b), gk.relinearize(a)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Exploration behind fhe_set_streams(2): the C2 batch of 1024 pairs split into `parts` calls issued round-robin
+"""Exploration behind fhe_mul_set_streams(2): the C2 batch of 1024 pairs split into `parts` calls issued round-robin
 on `ns` torch streams, against the single call.  (The library-internal version is what ships; this stays as the
 measurement recipe.)"""
 import os, sys, json

@@ -55,7 +55,9 @@ def host_key(cctx, seed, ndigits):
     return coracle.CKsk(c0, c0s, c1, c1s, cctx, cctx)
 
 
-def check_mul(fhe, n, sizes, batch, relin, cfg, sample=None, mod_switch=False):
+def check_mul(fhe, n, sizes, batch, relin, cfg, sample=None, mod_switch=False, ct0=0):
+    """ct0: index of the first ciphertext of this batch in the global synthetic stream (a rank's shard of a
+    sharded batch starts at rank * batch_per_gpu, fhe.rs_amd/shard.py)."""
     import torch
     q = obfv.generate_moduli(sizes, n)
     t = plaintext_modulus(n)
@@ -71,14 +73,14 @@ def check_mul(fhe, n, sizes, batch, relin, cfg, sample=None, mod_switch=False):
         rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1))
         crk = host_key(o["cb"], seed, len(q))
     m = fhe.Multiplicator.default(par, rk, 0, mod_switch)
-    lhs = ctx.synth_uniform(seed, 0, 0, 2, batch)
-    rhs = ctx.synth_uniform(seed, 0, 2, 2, batch)
+    lhs = ctx.synth_uniform(seed, ct0, 0, 2, batch)
+    rhs = ctx.synth_uniform(seed, ct0, 2, 2, batch)
     out = m.multiply(lhs, rhs)
     torch.cuda.synchronize()
     cm = coracle.CMul(o["cb"], o["cm"], o["cel"], o["cel"], o["cdn"], crk, mod_switch)
     for i in (sample or range(batch)):
-        l = np.stack([o["cb"].synth_poly(seed, i, 0), o["cb"].synth_poly(seed, i, 1)])
-        r = np.stack([o["cb"].synth_poly(seed, i, 2), o["cb"].synth_poly(seed, i, 3)])
+        l = np.stack([o["cb"].synth_poly(seed, ct0 + i, 0), o["cb"].synth_poly(seed, ct0 + i, 1)])
+        r = np.stack([o["cb"].synth_poly(seed, ct0 + i, 2), o["cb"].synth_poly(seed, ct0 + i, 3)])
         assert np.array_equal(u64(lhs[i]), l), "device generator != oracle generator"
         want = cm.multiply(l, r)
         assert np.array_equal(u64(out[i]), want), f"ciphertext {i} differs from the oracle"
@@ -143,7 +145,7 @@ def check_batch_properties(fhe, n, sizes, batch, cfg):
     assert bool((out < mods).all()) and bool((out >= 0).all())
 
 
-def check_relin_rotate(fhe, n, sizes, batch, cfg):
+def check_relin_rotate(fhe, n, sizes, batch, cfg, sample=None):
     import torch
     q = obfv.generate_moduli(sizes, n)
     seed = synth.seed_for_config(cfg)
@@ -158,7 +160,7 @@ def check_relin_rotate(fhe, n, sizes, batch, cfg):
     got = fhe.RelinearizationKey(ksk).relinearizes(ct3)
     rots = {e: fhe.GaloisKey(ksk, e).relinearize(ct3[:, :2].contiguous()) for e in (3, 2 * n - 1)}
     torch.cuda.synchronize()
-    for i in sorted({0, batch - 1}):
+    for i in (sample or sorted({0, batch - 1})):
         parts = [cc.synth_poly(seed, i, p) for p in range(3)]
         k0, k1 = ck.key_switch(cc.poly_ntt_backward(parts[2]))
         want = np.stack([cc.poly_add(parts[0], k0), cc.poly_add(parts[1], k1)])

@@ -1,0 +1,51 @@
+"""bench.py's multi-rank launch paths, on CPU: `python bench.py --gpus 2` must start its own two ranks (it used to
+assume an external torchrun and die in init_process_group), and the torchrun form the driver uses must keep
+working.  `--spawn-check` stops after the rendezvous (init_process_group over gloo, an all-reduce of the ranks and
+a barrier) -- the GPU work itself needs a GPU and is covered by tests/test_gpu_parity.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _line(stdout):
+    return json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_spawns_its_own_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--spawn-check"], capture_output=True, text=True,
+                       timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _line(r.stdout)
+    assert line["spawn_check"] == "ok" and line["n_gpus"] == 2 and line["dist_backend"] == "gloo"
+
+
+def test_bench_under_torchrun():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2",
+                        "--spawn-check"], capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _line(r.stdout)["n_gpus"] == 2
+
+
+def test_bench_rank_failure_is_reported():
+    """A rank that dies must fail the whole launch (non-zero exit), not hang the other rank."""
+    env = _env()
+    env["BENCH_DIST_BACKEND"] = "no-such-backend"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--spawn-check"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0

@@ -186,11 +186,49 @@ def test_config_c3_relin_rotate_n16384(fhe):
     full_size.check_relin_rotate(fhe, n=16384, sizes=[60] * 8, batch=6, cfg=3)
 
 
-def test_config_c5_chain_n32768(fhe):
-    """configs[4]: N=32768, 16x60-bit moduli, multiply + relinearise + modulus switch for the
-    first levels of the chain (RNS basis-conversion stress; the row does not fit LDS)."""
+def test_config_c3_bench_batch_n16384(fhe):
+    """configs[2] at the batch the bench line's `other_configs` times it at (512: other grid / wave counts than a
+    handful of ciphertexts): 33 ciphertexts spread over the batch against the C oracle, all three operations."""
     import full_size
-    full_size.check_chain(fhe, n=32768, sizes=[60] * 16, batch=2, levels=2, cfg=5)
+    full_size.check_relin_rotate(fhe, n=16384, sizes=[60] * 8, batch=512, cfg=3,
+                                 sample=tuple(range(0, 512, 16)) + (511,))
+
+
+def test_config_c4_per_gpu_shard_n8192(fhe):
+    """configs[3]: batch 65,536 sharded over 8 GPUs = 8,192 pairs per GPU.  One rank's shard (rank 3: global
+    ciphertexts 24,576...32,767 of the synthetic stream) on this GPU: 8 GiB of ciphertexts in, 4 GiB out, 64
+    chunks on two streams; 70 ciphertexts incl. the first / last of the shard and both sides of chunk boundaries,
+    each whole output against the C oracle."""
+    import full_size
+    per_gpu, rank = 8192, 3
+    sample = (0, 1, 127, 128, 129, 255, 256, 4095, 4096, 4097, 8063, 8064, 8190, 8191) + tuple(range(37, 8192, 146))
+    full_size.check_mul(fhe, n=8192, sizes=[60] * 4, batch=per_gpu, relin=True, cfg=4, sample=sample,
+                        ct0=rank * per_gpu)
+    fhe.workspace_trim()
+
+
+def test_config_c5_chain_n32768(fhe):
+    """configs[4]: N=32768, 16x60-bit moduli, the deep chain: multiply + relinearise + modulus switch at EVERY
+    level 0...14 (L_l = 16...2 moduli, K_l = 33...5: every scaler instantiation, rows that do not fit LDS),
+    each level's output feeding the next, 4 ciphertexts, every one against the C oracle at every level."""
+    import full_size
+    full_size.check_chain(fhe, n=32768, sizes=[60] * 16, batch=4, levels=15, cfg=5)
+    fhe.workspace_trim()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` starts its own two ranks; on a one-GPU box they share the device and
+    rendezvous over gloo (RCCL needs one device per rank).  The line must say n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "128", "--no-cpu", "--no-extras"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256 and line["value"] > 0
 
 
 def test_max_degree_n65536(fhe):

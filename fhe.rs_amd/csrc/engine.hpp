@@ -815,10 +815,56 @@ inline void ksk_validate(const Ctx &ct_ctx, const Ctx &ksk_ctx, size_t ndigits, 
     }
 }
 
+#ifdef FHE_KS_EXPERIMENTS
+// Experiment builds only (kernels.hpp, ks_pair_kernel): FHE_KS_VARIANT = 0 (default) ks_fused_kernel, 1 two digits
+// per round, 2 the same with 16 coefficients per thread, 3 one digit per round on the pair kernel's structure.
+inline int ks_variant() {
+    static const int v = [] {
+        const char *e = std::getenv("FHE_KS_VARIANT");
+        return e ? std::atoi(e) : 0;
+    }();
+    return v;
+}
+#endif
+
 template <int LOGN>
 inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
                             const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s) {
     const Ctx &kc = *k_.ksk_ctx;
+#ifdef FHE_KS_EXPERIMENTS
+    if constexpr (k::ks_pair_ok_c(LOGN)) {
+        const uint32_t lm = k_.lift_mode();   // 1 / 2: RNS digits below 2 / 4 q_j (what the pair kernel lifts)
+        if (ks_variant() >= 1 && ks_variant() <= 3 && k_.ndigits >= 2 && (lm == 1 || lm == 2)) {
+            const size_t lds2 = 2 * k::lds_words(1u << LOGN) * sizeof(u64);
+            bool nrw = !debug_flag("FHE_NO_NARROW");
+            for (u64 q : kc.moduli) nrw = nrw && (q >> 60) == 0;
+#define FHE_KS_PAIR_LAUNCH(NW, CPT, ...)                                                                             \
+    allow_big_lds((k::ks_pair_kernel<LOGN, NW, CPT, ##__VA_ARGS__>), lds2);                                          \
+    FHE_LAUNCH("key_switch_fused", (k::ks_pair_kernel<LOGN, NW, CPT, ##__VA_ARGS__>), dim3((unsigned)(npolys * kc.L)), \
+               dim3(k::ks_pair_threads_c(LOGN, CPT)), lds2, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride,    \
+               k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L)
+            if (ks_variant() == 3) {
+                if (nrw) {
+                    FHE_KS_PAIR_LAUNCH(true, 8, 1);
+                } else {
+                    FHE_KS_PAIR_LAUNCH(false, 8, 1);
+                }
+            } else if (ks_variant() == 2 && LOGN >= 11) {
+                if (nrw) {
+                    FHE_KS_PAIR_LAUNCH(true, 16);
+                } else {
+                    FHE_KS_PAIR_LAUNCH(false, 16);
+                }
+            } else if (nrw) {
+                FHE_KS_PAIR_LAUNCH(true, 8);
+            } else {
+                FHE_KS_PAIR_LAUNCH(false, 8);
+            }
+#undef FHE_KS_PAIR_LAUNCH
+            return;
+        }
+    }
+#endif
     const size_t lds = (k::lds_words(1u << LOGN) + (k::ks_acc1_in_lds_c(LOGN) ? (size_t)1 << LOGN : 0)) * sizeof(u64);
     // key moduli below 2^60: the transform runs without most conditional subtractions (fwd_butterfly_narrow)
     bool narrow = !debug_flag("FHE_NO_NARROW");
@@ -846,7 +892,10 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     const Ctx &kc = *k_.ksk_ctx;
     kc.need_device();
     if (!npolys) return;
-    if (kc.logn <= 14) {  // (sub-block variants measured: N = 16384 82.6 k vs 77.8 k relin/s; N = 8192 as 2 x 4096 +-1 %)
+    // N = 16384: whole-row kernel (1024 threads x 16 coefficients, 24 VGPRs spilled) or two 8192-point sub-blocks
+    // with the first stage folded into the loader (FHE_KS_SPLIT14=1)
+    static const bool split14 = std::getenv("FHE_KS_SPLIT14") != nullptr && std::atoi(std::getenv("FHE_KS_SPLIT14")) != 0;
+    if (kc.logn <= 13 || (kc.logn == 14 && !split14)) {  // (N = 8192 as 2 x 4096 measured +-1 %)
 #define FHE_KS_CASE(LN) \
     case LN: launch_ks_fused<LN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s); break;
         switch (kc.logn) {
@@ -876,7 +925,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
         }                                                                                                          \
         break;
     switch (kc.logn) {
-        FHE_KS_SPLIT_CASE(2) FHE_KS_SPLIT_CASE(3)
+        FHE_KS_SPLIT_CASE(1) FHE_KS_SPLIT_CASE(2) FHE_KS_SPLIT_CASE(3)
         default: throw StatusError(E_ARG, "unsupported key-switch row size");
     }
 #undef FHE_KS_SPLIT_CASE

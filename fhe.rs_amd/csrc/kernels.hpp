@@ -186,9 +186,12 @@ __device__ __forceinline__ void fwd_tw_load(FwdTw<G, LOGM, S0, T> &tw_regs, cons
 // own right before use (fewer live registers).
 // NARROW = b0 > 0: moduli below 2^60 and input to stage 0 below b0*p (1: canonical) --
 // fwd_butterfly_narrow (zq_dev.hpp); values are below 16p on exit instead of 4p.
-template <int G, int LOGM, int S0, int T, bool PRE, int NARROW = 0, class Src = NoSrc>
+// NT > 1: the same pass on NT tiles that lie `tile_words` apart in LDS (the key switch transforms two digits
+// under one modulus at once): addresses and twiddles are formed once and serve every tile.
+template <int G, int LOGM, int S0, int T, bool PRE, int NARROW = 0, class Src = NoSrc, int NT = 1>
 __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
-                                         uint32_t tid, const FwdTw<G, LOGM, S0, T> &tw_regs, Src src = Src{}) {
+                                         uint32_t tid, const FwdTw<G, LOGM, S0, T> &tw_regs, Src src = Src{},
+                                         uint32_t tile_words = 0) {
     constexpr bool DIRECT = !std::is_same<Src, NoSrc>::value;
     constexpr uint32_t R = 1u << G;
     constexpr uint32_t lo_bits = LOGM - S0 - G;
@@ -214,7 +217,9 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
         // padi(base + off) = padi(base) + padi(off) for every element of a group (no carry out
         // of the low four bits: a group never straddles a 16-element pad block unless off is a
         // multiple of 16), so the per-element LDS offsets are compile-time constants.
-        u64 *const g = lds + padi(base);
+#pragma unroll
+        for (int tl = 0; tl < NT; tl++) {
+        u64 *const g = lds + (NT > 1 ? tl * tile_words : 0u) + padi(base);
         u64 x[R];
         if constexpr (DIRECT) {
 #pragma unroll
@@ -244,6 +249,8 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
         }
 #pragma unroll
         for (uint32_t e = 0; e < R; e++) g[padi(e << lo_bits)] = x[e];
+        if constexpr (NT > 1) sched_fence();   // one tile's group in registers at a time
+        }
     }
 }
 
@@ -260,14 +267,14 @@ constexpr int fwd_plan_g() {
 // TWPF: fetch the next pass's per-lane twiddles before the barrier (costs their registers across
 // it: the key-switch kernels, which also hold accumulators, leave it off).
 // FSYNC = false: the caller places the barrier after the last pass itself (it has loads to issue first).
-template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, int NARROW, int PASS, int S0, bool LATE, class W, class Src>
+template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, int NARROW, int PASS, int S0, bool LATE, int NT, class W, class Src>
 __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
-                                                uint32_t tid, const W &tw_regs, Src src) {
+                                                uint32_t tid, const W &tw_regs, Src src, uint32_t tile_words) {
     constexpr int G = fwd_plan_g<LOGM, GM, PASS, LATE>();
     if constexpr (PASS == 0)
-        fwd_pass<G, LOGM, S0, T, TWPF, NARROW, Src>(lds, tw, kbase, pm, tid, tw_regs, src);   // (Src != NoSrc: reads `src`, not LDS)
+        fwd_pass<G, LOGM, S0, T, TWPF, NARROW, Src, NT>(lds, tw, kbase, pm, tid, tw_regs, src, tile_words);   // (Src != NoSrc: reads `src`, not LDS)
     else
-        fwd_pass<G, LOGM, S0, T, TWPF, NARROW>(lds, tw, kbase, pm, tid, tw_regs);
+        fwd_pass<G, LOGM, S0, T, TWPF, NARROW, NoSrc, NT>(lds, tw, kbase, pm, tid, tw_regs, NoSrc{}, tile_words);
     if constexpr (PASS + 1 < plan_np(LOGM, GM)) {
         constexpr int GN = fwd_plan_g<LOGM, GM, PASS + 1, LATE>();
         FwdTw<GN, LOGM, S0 + G, T> next;
@@ -276,19 +283,20 @@ __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restric
             wave_sync();
         else
             __syncthreads();
-        ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, PASS + 1, S0 + G, LATE>(lds, tw, kbase, pm, tid, next, NoSrc{});
+        ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, PASS + 1, S0 + G, LATE, NT>(lds, tw, kbase, pm, tid, next, NoSrc{},
+                                                                                      tile_words);
     } else {
         if constexpr (FSYNC) __syncthreads();
     }
 }
 template <int LOGM, int T, int GM = GMAX, bool TWPF = true, bool FSYNC = true, int NARROW = 0, class Src = NoSrc,
-          bool LATE = false>
+          bool LATE = false, int NT = 1>
 __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
-                                            uint32_t tid, Src src = Src{}) {
+                                            uint32_t tid, Src src = Src{}, uint32_t tile_words = 0) {
     constexpr int G = fwd_plan_g<LOGM, GM, 0, LATE>();
     FwdTw<G, LOGM, 0, T> first;
     if constexpr (TWPF) fwd_tw_load(first, tw, kbase, tid);
-    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, 0, 0, LATE>(lds, tw, kbase, pm, tid, first, src);
+    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, 0, 0, LATE, NT>(lds, tw, kbase, pm, tid, first, src, tile_words);
 }
 
 // ---------------------------------------------------------------- inverse passes ----
@@ -923,6 +931,206 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
         out1[ooff + tid] = r1;
     }
 }
+
+// ------------------------------------------- fused key switch, two digits per round ----
+// MEASURED ALTERNATIVE, not part of the default build (compile with -DFHE_KS_EXPERIMENTS, select with
+// FHE_KS_VARIANT; tools/ab_ks.sh).  Round 2 rebuilt the key switch around fewer barriers / more work per LDS
+// exchange as this kernel; on the MI355X every variant lost to ks_fused_kernel (C2, 512 polynomials per launch):
+//   ks_fused_kernel (one digit per round, row prefetch in registers, c1 accumulators in LDS)   0.514 ms
+//   two digits per round, 1024 threads x 8 coefficients, both accumulator sets in registers     0.552 ms (13 VGPRs spilled)
+//   one digit per round on this kernel's structure (MAC stages the coming row, no prefetch regs) 0.543 ms ( 7 VGPRs spilled)
+//   two digits per round, 512 threads x 16 coefficients, radix-16, 236 VGPRs, 2 waves per SIMD  0.707 ms
+// (profiles/r02_ks_variants.txt).  What decides is waves per SIMD and the registers the radix pass leaves: 32
+// VGPRs of accumulators that stay live through the passes do not fit beside a radix-8 pass under the 128-VGPR
+// cap of a 1024-thread workgroup, and trading waves for registers loses outright.
+#ifdef FHE_KS_EXPERIMENTS
+// Same contract as ks_fused_kernel.  The digits of one (ciphertext, key modulus) go through the loop TWO at a time:
+// both lifted rows sit in LDS (two tiles), every radix pass runs on both tiles between the same pair of barriers
+// with one set of addresses and twiddles (the modulus, hence the twiddles, is the same for all digits), and the
+// Shoup MAC folds both into the accumulators.  Per digit this halves the workgroup barriers and the twiddle
+// fetches and doubles the independent work a wave has between two LDS exchanges -- the workgroup is alone on its
+// CU (LDS), so nothing else covers those gaps.  Both accumulator sets live in registers (2 x 2*CH u64; the tiles
+// take the LDS the c1 accumulators had); the MAC loop stages the coming round's lifted rows into the chunks it has
+// just consumed.  An odd digit count ends with one single-tile round.
+// NARROW (key moduli below 2^60): the accumulators are left unreduced -- each lazy product is below 2p, so up to
+// 8 of them fit below 16p < 2^64 -- and are folded back below 2p only every 7 digits (never for <= 8 digits).
+template <int V>
+struct int_c {
+    static constexpr int value = V;
+};
+constexpr bool ks_pair_ok_c(int logn) { return tile_chunks_c(logn, ks_threads_c(logn)) > 0 && logn <= 13; }
+// CPT: coefficients per thread and tile.  8: N/8 threads, radix-8 passes, 128 VGPRs (4 waves per SIMD);
+// 16: N/16 threads, radix-16 passes, both accumulator sets and a 16-point group in a 256-VGPR budget (2 waves per SIMD).
+constexpr int ks_pair_threads_c(int logn, int cpt) { return cpt == 8 ? ks_threads_c(logn) : ((1 << logn) / 16 > 64 ? (1 << logn) / 16 : 64); }
+template <int LOGN, bool NARROW = false, int CPT = 8, int MAXNT = 2>
+__global__ void __launch_bounds__(ks_pair_threads_c(LOGN, CPT), CPT == 8 ? 4 : 2)
+    ks_pair_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
+                   u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
+                   u64 addend_poly_stride, const u64 *__restrict__ k0, const u64 *__restrict__ k0s,
+                   const u64 *__restrict__ k1, const u64 *__restrict__ k1s, const DevMod *__restrict__ mods,
+                   const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk) {
+    FHE_DYN_SMEM(u64, lds);
+    constexpr int T = ks_pair_threads_c(LOGN, CPT);
+    constexpr int GM = CPT == 8 ? KS_GMAX : GMAX;
+    constexpr int N = 1 << LOGN;
+    constexpr int CH = tile_chunks_c(LOGN, T);
+    static_assert(CH > 0, "ks_pair_kernel needs at least one 16-byte chunk per thread");
+    constexpr uint32_t TW = N + (N >> 4) + 2;   // u64 words per tile (= lds_words(N))
+    const uint32_t tid0 = threadIdx.x;
+    const uint32_t b = to_sgpr(blockIdx.x / lk), j = blockIdx.x - b * lk;
+    const DevMod md = mods[j];
+    const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
+    const u64x2 *twr = tw + (u64)j * N;
+    u64 acc0[2 * CH], acc1[2 * CH];
+#pragma unroll
+    for (int e = 0; e < 2 * CH; e++) acc0[e] = acc1[e] = 0;
+    // RNS digits whose source moduli are below 4 q_j only (lift_mode 1 or 2 of ks_fused_kernel; the host sends
+    // everything else -- base-2^k digits, moduli of very different widths -- to that kernel): two conditional
+    // subtractions lift a residue, no branch in the loops.
+    auto lift = [&](u64 v) -> u64 { return csub_n(csub_n(v, p2, pm.np2), p, pm.np); };
+    const u64 *const src0 = pin + (u64)b * src_poly_stride;
+    // The lifted rows of the COMING round are staged by the MAC loop of the current one: once a thread has consumed
+    // chunk c of tile d it owns that slot (nobody else touches a thread's 16-byte chunks outside the passes), so it
+    // writes the lifted chunk of the digit that takes tile d next -- no prefetch registers, the row's load latency
+    // hides behind the Shoup MACs, and no barrier is needed between the MAC and the next round's first pass other
+    // than the one that closes the staging.
+    auto stage = [&](int tile, int c, uint32_t tid, u64x2 raw) {
+        const uint32_t e = 2 * (c * T + tid);
+        lds[tile * TW + padi(e)] = lift(raw.x);
+        lds[tile * TW + padi(e + 1)] = lift(raw.y);
+    };
+    auto row_ptr = [&](uint32_t digit) { return reinterpret_cast<const u64x2 *>(src0 + (u64)digit * N); };
+    {   // first round: straight from global memory
+        u64x2 raw[2][CH];
+#pragma unroll
+        for (int d = 0; d < MAXNT; d++)
+            if ((uint32_t)d < ndigits) {
+#pragma unroll
+                for (int c = 0; c < CH; c++) raw[d][c] = row_ptr(d)[c * T + tid0];
+            }
+#pragma unroll
+        for (int d = 0; d < MAXNT; d++)
+            if ((uint32_t)d < ndigits) {
+#pragma unroll
+                for (int c = 0; c < CH; c++) stage(d, c, tid0, raw[d][c]);
+            }
+    }
+    uint32_t i = 0;        // first digit of the round
+    uint32_t since = 0;    // NARROW: accumulators are below 2p * max(since, 1)
+    auto round = [&](auto ntc) {
+        constexpr int NT = decltype(ntc)::value;
+        const uint32_t tid = opaque(tid0);
+        __syncthreads();   // the round's tiles are complete
+        if constexpr (NARROW) {
+            if (since + NT > 8) {   // (block-uniform) fold the accumulators back below 2p
+                const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
+#pragma unroll
+                for (int e = 0; e < 2 * CH; e++) {
+                    acc0[e] = csub_n(csub_n(csub_n(acc0[e], p8, np8), p4, np4), p2, pm.np2);
+                    acc1[e] = csub_n(csub_n(csub_n(acc1[e], p8, np8), p4, np4), p2, pm.np2);
+                }
+                since = 1;
+            }
+            since += NT;
+        }
+        ntt_fwd_lds<LOGN, T, GM, false, false, (NARROW ? 1 : 0), NoSrc, KS_LATE, NT>(lds, twr, 1, pm, tid, NoSrc{}, TW);
+        // the key words of the first chunk are requested before the barrier that ends the transform
+        const u64 koff0 = ((u64)i * lk + j) * N;
+        u64x2 kq[4];
+        const uint32_t tid_m = opaque(tid0);   // (a fresh opaque copy: the MAC's address arithmetic stays below the passes)
+        {
+            const uint32_t ci = tid_m;
+            kq[0] = reinterpret_cast<const u64x2 *>(k0 + koff0)[ci], kq[1] = reinterpret_cast<const u64x2 *>(k0s + koff0)[ci];
+            kq[2] = reinterpret_cast<const u64x2 *>(k1 + koff0)[ci], kq[3] = reinterpret_cast<const u64x2 *>(k1s + koff0)[ci];
+        }
+        __syncthreads();
+        // MAC of tile d; STAGE: the digit `nxt` takes the tile in the coming round and its lifted row is written
+        // into every chunk right after the chunk has been consumed
+        auto mac_tile = [&](int d, auto stc, uint32_t nxt) {
+            constexpr bool STAGE = decltype(stc)::value != 0;
+            const u64 koff = ((u64)(i + d) * lk + j) * N;
+            const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
+            const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
+            const u64x2 *nrow = row_ptr(STAGE ? nxt : 0);
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t ci = c * T + tid_m;
+                u64x2 q0, q0s, q1, q1s, raw = u64x2{0, 0};
+                if (d == 0 && c == 0) {
+                    q0 = kq[0], q0s = kq[1], q1 = kq[2], q1s = kq[3];
+                } else {
+                    q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+                }
+                if constexpr (STAGE) raw = nrow[ci];
+                const u64 vx = lds[d * TW + padi(2 * ci)], vy = lds[d * TW + padi(2 * ci + 1)];  // any u64: fine for Shoup
+                if constexpr (NARROW) {
+                    acc0[2 * c] += mul_shoup_lazy_n(vx, q0.x, q0s.x, pm.np);
+                    acc0[2 * c + 1] += mul_shoup_lazy_n(vy, q0.y, q0s.y, pm.np);
+                    acc1[2 * c] += mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np);
+                    acc1[2 * c + 1] += mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np);
+                } else {
+                    acc0[2 * c] = csub_n(acc0[2 * c] + mul_shoup_lazy_n(vx, q0.x, q0s.x, pm.np), p2, pm.np2);
+                    acc0[2 * c + 1] = csub_n(acc0[2 * c + 1] + mul_shoup_lazy_n(vy, q0.y, q0s.y, pm.np), p2, pm.np2);
+                    acc1[2 * c] = csub_n(acc1[2 * c] + mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np), p2, pm.np2);
+                    acc1[2 * c + 1] = csub_n(acc1[2 * c + 1] + mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np), p2, pm.np2);
+                }
+                if constexpr (STAGE) stage(d, c, tid_m, raw);
+                sched_fence();  // one chunk's loads (key words + the coming row: 20 VGPRs) at a time
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < NT; d++) {
+            const uint32_t nxt = i + NT + d;          // the digit that takes tile d in the coming round
+            if (nxt < ndigits)                        // (block-uniform)
+                mac_tile(d, int_c<1>{}, nxt);
+            else
+                mac_tile(d, int_c<0>{}, 0u);
+        }
+        i += NT;
+    };
+    if constexpr (MAXNT >= 2) {
+        while (i + 1 < ndigits) round(int_c<2>{});
+        if (i < ndigits) round(int_c<1>{});
+    } else {
+        while (i < ndigits) round(int_c<1>{});   // (MAXNT = 1: one digit per round, tile 1 unused)
+    }
+    const uint32_t tid = opaque(tid0);  // keeps the epilogue's address arithmetic below the digit loop
+    const u64 ooff = (u64)b * out_poly_stride + (u64)j * N;
+    const u64 aoff = (u64)b * addend_poly_stride + (u64)j * N;
+    u64x2 *o0 = reinterpret_cast<u64x2 *>(out0 + ooff), *o1 = reinterpret_cast<u64x2 *>(out1 + ooff);
+    const u64x2 *d0 = reinterpret_cast<const u64x2 *>(addend0 ? addend0 + aoff : nullptr);
+    const u64x2 *d1 = reinterpret_cast<const u64x2 *>(addend1 ? addend1 + aoff : nullptr);
+    auto canon = [&](u64 v) -> u64 {
+        if constexpr (NARROW) {   // below 16p
+            const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
+            v = csub_n(csub_n(csub_n(v, p8, np8), p4, np4), p2, pm.np2);
+        }
+        return csub_n(v, p, pm.np);
+    };
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t ci = c * T + tid;
+        u64x2 r0, r1;
+        r0.x = canon(acc0[2 * c]);
+        r0.y = canon(acc0[2 * c + 1]);
+        r1.x = canon(acc1[2 * c]);
+        r1.y = canon(acc1[2 * c + 1]);
+        if (d0) {
+            const u64x2 a = d0[ci];
+            r0.x = add_mod_n(r0.x, a.x, pm);
+            r0.y = add_mod_n(r0.y, a.y, pm);
+        }
+        if (d1) {
+            const u64x2 a = d1[ci];
+            r1.x = add_mod_n(r1.x, a.x, pm);
+            r1.y = add_mod_n(r1.y, a.y, pm);
+        }
+        o0[ci] = r0;
+        o1[ci] = r1;
+    }
+}
+#endif  // FHE_KS_EXPERIMENTS
 
 // The same for rows that do not fit LDS (N = 2^(13+G0) >= 32768): one workgroup per (ciphertext,
 // key modulus j, 8192-point sub-block).  The first G0 Cooley-Tukey stages (native.rs:142-175,

@@ -7,6 +7,7 @@ import random
 import numpy as np
 
 from fhe_oracle import bfv as obfv
+from fhe_oracle import coracle
 from fhe_oracle.rns import ScalingFactor
 from fhe_oracle.rq import (Context as OCtx, Poly, Scaler as OScaler, Switcher as OSwitcher,
                            SubstitutionExponent, POWER_BASIS, NTT)
@@ -342,6 +343,38 @@ def case_key_switch_levels(fhe, dev, nmod=4, n=16):
             for i, c in enumerate(cts):
                 ork.relinearizes(c)
                 assert np.array_equal(got[i], ct_arr(c))
+
+
+def case_key_switch_many_digits(fhe, dev, n=128, shapes=((50, 10), (58, 17), (62, 5), (60, 9), (45, 2), (61, 3))):
+    """key_switching_key.rs:241-270 with long digit loops: the fused kernels go through the digits two per round
+    (+ one single round for an odd count) and, for moduli below 2^60, leave their accumulators unreduced for up to
+    eight digits before folding them back -- 9, 10 and 17 digits cross that fold once and twice.  Random residues
+    and random key polynomials (the key switch is a fixed function of them) against the C oracle."""
+    x = Xfer(dev)
+    for bits, L in shapes:
+        q = obfv.generate_moduli([bits] * L, n)
+        octx = OCtx(q, n)
+        cc = coracle.CCtx(octx)
+        ctx = fhe.Context(q, n)
+        seed = 1000 + bits * 100 + L
+        c0 = np.stack([cc.synth_poly(seed, 0, 8 + 2 * i) for i in range(L)])
+        c1 = np.stack([cc.synth_poly(seed, 0, 9 + 2 * i) for i in range(L)])
+        ck = coracle.CKsk(c0, np.stack([cc.shoup(v) for v in c0]), c1, np.stack([cc.shoup(v) for v in c1]), cc, cc)
+        ksk = fhe.KeySwitchingKey(ctx, ctx, c0, c1)
+        p = np.stack([cc.synth_poly(seed, 1 + b, 0) for b in range(3)])
+        g0, g1 = ksk.key_switch(x.to(p))
+        g0, g1 = x.back(g0), x.back(g1)
+        for b in range(3):
+            w0, w1 = ck.key_switch(p[b])
+            assert np.array_equal(g0[b], w0) and np.array_equal(g1[b], w1), (bits, L, b)
+        # relinearise (the key switch adds into c0, c1 on the way out) and a rotation
+        ct3 = np.stack([np.stack([cc.synth_poly(seed, 10 + b, part) for part in range(3)]) for b in range(2)])
+        got = x.back(fhe.RelinearizationKey(ksk).relinearizes(x.to(ct3)))
+        rot = x.back(fhe.GaloisKey(ksk, 3).relinearize(x.to(np.ascontiguousarray(ct3[:, :2]))))
+        for b in range(2):
+            k0, k1 = ck.key_switch(cc.poly_ntt_backward(ct3[b, 2]))
+            assert np.array_equal(got[b], np.stack([cc.poly_add(ct3[b, 0], k0), cc.poly_add(ct3[b, 1], k1)])), (bits, L, b)
+            assert np.array_equal(rot[b], ck.galois_relinearize(3, ct3[b, :2])), (bits, L, b)
 
 
 def case_key_switch_decomposition(fhe, dev, n=16):

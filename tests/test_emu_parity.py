@@ -169,6 +169,10 @@ def test_ksk_validation(fhe):
     cases.case_ksk_validation(fhe)
 
 
+def test_key_switch_many_digits(fhe):
+    cases.case_key_switch_many_digits(fhe, False)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 

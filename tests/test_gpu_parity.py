@@ -148,6 +148,11 @@ def test_ksk_validation(fhe):
     cases.case_ksk_validation(fhe)
 
 
+def test_key_switch_many_digits(fhe):
+    cases.case_key_switch_many_digits(fhe, True)
+    cases.case_key_switch_many_digits(fhe, True, n=8192, shapes=((60, 9), (50, 11), (62, 4)))
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 

@@ -48,6 +48,84 @@ __device__ __forceinline__ u64 shoup_asm(u64 a, u64 w, u64 ws, u64 np) {
         : "vcc", "v120", "v121", "v122", "v123", "v124", "v125");
     return t + ((u64)h << 32);
 }
+// All-mad Shoup: v_mad_u64_u32 (a 32x32 multiply with a 64-bit addend) issues faster than v_mul_lo_u32 and much
+// faster than v_mul_hi_u32 (this file's first three lines of output), but the compiler narrows every product whose
+// high half is not demanded to v_mul_lo_u32.  Here the two low products a*w + q*np (mod 2^64) are one chain of six
+// mads: the four cross terms accumulate in a 64-bit register that is made opaque (so that all 64 bits count as
+// demanded), then enter the sum through one v_lshl_add_u64.
+__device__ __forceinline__ u64 opaque64(u64 v) {
+    asm("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ u64 shoup_allmad(u64 a, u64 w, u64 ws, u64 np) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t n0 = (uint32_t)np, n1 = (uint32_t)(np >> 32);
+    const u64 q = mulhi64(a, ws);
+    const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
+    u64 cross = (u64)a0 * w1;
+    cross += (u64)a1 * w0;
+    cross += (u64)q0 * n1;
+    cross += (u64)q1 * n0;
+    cross = opaque64(cross);
+    u64 lo = (u64)a0 * w0;
+    lo += (u64)q0 * n0;
+    return lo + (cross << 32);
+}
+// the same with the 64x64 -> hi64 product written as mads only (the compiler takes v_mul_hi_u32 for a0*s0)
+__device__ __forceinline__ u64 mulhi64_allmad(u64 a, u64 s) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+    const u64 l = opaque64((u64)a0 * s0);
+    const u64 m = opaque64((u64)a0 * s1 + (l >> 32));
+    const u64 m2 = opaque64((u64)a1 * s0 + (uint32_t)m);
+    return (u64)a1 * s1 + (m >> 32) + (m2 >> 32);
+}
+__device__ __forceinline__ u64 shoup_allmad2(u64 a, u64 w, u64 ws, u64 np) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t n0 = (uint32_t)np, n1 = (uint32_t)(np >> 32);
+    const u64 q = mulhi64_allmad(a, ws);
+    const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
+    u64 cross = (u64)a0 * w1;
+    cross += (u64)a1 * w0;
+    cross += (u64)q0 * n1;
+    cross += (u64)q1 * n0;
+    cross = opaque64(cross);
+    u64 lo = (u64)a0 * w0;
+    lo += (u64)q0 * n0;
+    return lo + (cross << 32);
+}
+// quotient from three partial products (a0*s0 dropped): q' in {q - 1, q}, result below 3p
+__device__ __forceinline__ u64 shoup_approx(u64 a, u64 w, u64 ws, u64 np) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+    const uint32_t n0 = (uint32_t)np, n1 = (uint32_t)(np >> 32);
+    const u64 m = opaque64((u64)a0 * s1);
+    const u64 m2 = opaque64((u64)a1 * s0 + (uint32_t)m);
+    const u64 q = (u64)a1 * s1 + (m >> 32) + (m2 >> 32);
+    const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
+    u64 cross = (u64)a0 * w1;
+    cross += (u64)a1 * w0;
+    cross += (u64)q0 * n1;
+    cross += (u64)q1 * n0;
+    cross = opaque64(cross);
+    u64 lo = (u64)a0 * w0;
+    lo += (u64)q0 * n0;
+    return lo + (cross << 32);
+}
+// 64x64 -> hi64 as four mads without any per-use asm: the addend of the first product is a zero the compiler
+// cannot see through (one s_mov at kernel start), so it cannot turn a0*s0 >> 32 into the slow v_mul_hi_u32.
+__device__ __forceinline__ u64 mulhi64_z(u64 a, u64 s, u64 z) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+    const u64 l = (u64)a0 * s0 + z;
+    const u64 m = (u64)a0 * s1 + (l >> 32);
+    const u64 m2 = (u64)a1 * s0 + (uint32_t)m;
+    return (u64)a1 * s1 + (m >> 32) + (m2 >> 32);
+}
+__device__ __forceinline__ u64 mulhi64_approx(u64 a, u64 s) {   // a0*s0 dropped: result in {hi - 1, hi}
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+    const u64 m = (u64)a0 * s1;
+    const u64 m2 = (u64)a1 * s0 + (uint32_t)m;
+    return (u64)a1 * s1 + (m >> 32) + (m2 >> 32);
+}
 constexpr int ILP = 8;
 constexpr int ITERS = 4096;
 
@@ -63,6 +141,8 @@ __global__ void bench(u64 *out, u64 seed, u64 p, u64 w, u64 ws) {
     }
     const u64 p2 = 2 * p;
     const PM pm{p, p2, opaque_neg(p), opaque_neg(p2)};
+    u64 zero = 0;
+    asm("" : "+s"(zero));
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
         for (int i = 0; i < ILP; i++) {
@@ -85,6 +165,60 @@ __global__ void bench(u64 *out, u64 seed, u64 p, u64 w, u64 ws) {
                 y[i] = x[i] + pm.p2 - t;
                 x[i] = x[i] + t;
             }
+            if (KIND == 20) x[i] = shoup_allmad(x[i], w, ws, pm.np);
+            if (KIND == 21) {
+                const u64 t = shoup_allmad(y[i], w, ws, pm.np);
+                y[i] = x[i] + pm.p2 - t;
+                x[i] = x[i] + t;
+            }
+            if (KIND == 22) x[i] = shoup_allmad2(x[i], w, ws, pm.np);
+            if (KIND == 23) {
+                const u64 t = shoup_allmad2(y[i], w, ws, pm.np);
+                y[i] = x[i] + pm.p2 - t;
+                x[i] = x[i] + t;
+            }
+            if (KIND == 24) x[i] = shoup_approx(x[i], w, ws, pm.np);
+            if (KIND == 25) {
+                const u64 t = shoup_approx(y[i], w, ws, pm.np);
+                y[i] = x[i] + pm.p2 + pm.p - t;
+                x[i] = x[i] + t;
+            }
+            if (KIND == 26) {  // full (wide-modulus) butterfly on the all-mad Shoup
+                x[i] = csub_n(x[i], pm.p2, pm.np2);
+                const u64 t = shoup_allmad(y[i], w, ws, pm.np);
+                y[i] = x[i] + pm.p2 - t;
+                x[i] = x[i] + t;
+            }
+            if (KIND == 27) {  // Gentleman-Sande butterfly on the all-mad Shoup
+                const u64 t = x[i];
+                x[i] = csub_n(y[i] + t, pm.p2, pm.np2);
+                y[i] = shoup_allmad(pm.p2 + t - y[i], w, ws, pm.np);
+            }
+            if (KIND == 28) x[i] = x[i] * w + mulhi64_z(x[i], ws, zero) * pm.np;
+            if (KIND == 29) {
+                const u64 t = y[i] * w + mulhi64_z(y[i], ws, zero) * pm.np;
+                y[i] = x[i] + pm.p2 - t;
+                x[i] = x[i] + t;
+            }
+            if (KIND == 30) {
+                x[i] = csub_n(x[i], pm.p2, pm.np2);
+                const u64 t = y[i] * w + mulhi64_z(y[i], ws, zero) * pm.np;
+                y[i] = x[i] + pm.p2 - t;
+                x[i] = x[i] + t;
+            }
+            if (KIND == 31) {
+                const u64 t = x[i];
+                x[i] = csub_n(y[i] + t, pm.p2, pm.np2);
+                const u64 d = pm.p2 + t - y[i];
+                y[i] = d * w + mulhi64_z(d, ws, zero) * pm.np;
+            }
+            if (KIND == 32) x[i] = x[i] * w + mulhi64_approx(x[i], ws) * pm.np;
+            if (KIND == 33) {
+                const u64 t = y[i] * w + mulhi64_approx(y[i], ws) * pm.np;
+                y[i] = x[i] + pm.p2 + pm.p - t;
+                x[i] = x[i] + t;
+            }
+            if (KIND == 34) x[i] = mulhi64_z(x[i], y[i], zero) + 1;
             if (KIND == 8) x[i] = x[i] * y[i] + 1;                                     // 64x64 -> lo64
         }
     }
@@ -130,6 +264,21 @@ int main() {
     run<5>("mul_shoup_lazy", 1);
     run<12>("mul_shoup_lazy, hand-written asm", 1);
     run<13>("fwd_butterfly without conditional subtraction, asm Shoup", 1);
+    run<20>("mul_shoup_lazy, all-mad low products", 1);
+    run<21>("narrow fwd butterfly, all-mad low products", 1);
+    run<22>("mul_shoup_lazy, all-mad low products + all-mad mulhi", 1);
+    run<23>("narrow fwd butterfly, all-mad low + mulhi", 1);
+    run<24>("mul_shoup_lazy, approximate quotient (3 partial products), all-mad", 1);
+    run<25>("narrow fwd butterfly, approximate quotient", 1);
+    run<26>("fwd_butterfly (wide), all-mad low products", 1);
+    run<27>("inv_butterfly, all-mad low products", 1);
+    run<34>("mulhi64, four mads (opaque zero addend)", 1);
+    run<28>("mul_shoup_lazy, mulhi by four mads", 1);
+    run<29>("narrow fwd butterfly, mulhi by four mads", 1);
+    run<30>("fwd_butterfly (wide), mulhi by four mads", 1);
+    run<31>("inv_butterfly, mulhi by four mads", 1);
+    run<32>("mul_shoup_lazy, approximate quotient, compiler's low products", 1);
+    run<33>("narrow fwd butterfly, approximate quotient, compiler's low products", 1);
     run<6>("fwd_butterfly", 1);
     run<7>("inv_butterfly", 1);
     return 0;

@@ -829,7 +829,8 @@ inline int ks_variant() {
 
 template <int LOGN>
 inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
-                            const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s) {
+                            const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s,
+                            const u64 *xhat, u64 xhat_stride) {
     const Ctx &kc = *k_.ksk_ctx;
 #ifdef FHE_KS_EXPERIMENTS
     if constexpr (k::ks_pair_ok_c(LOGN)) {
@@ -874,21 +875,26 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
         FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, true>), dim3((unsigned)(npolys * kc.L)),
                    dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,
                    k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
-                   k_.digit_arg());
+                   k_.digit_arg(), xhat, xhat_stride);
         return;
     }
     allow_big_lds((k::ks_fused_kernel<LOGN, false>), lds);
     FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, false>), dim3((unsigned)(npolys * kc.L)),
                dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,
                k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
-               k_.digit_arg());
+               k_.digit_arg(), xhat, xhat_stride);
 }
 
 // KeySwitchingKey::key_switch (:241-320): p [npolys][L][N] PowerBasis (poly stride p_stride) ->
 // o0,o1 [npolys][Lk][N] Ntt over ksk_ctx (poly stride out_stride).  If a0/a1 are given (and the
 // key lives at the ciphertext level) the result is added to them on the fly.
+// xhat (optional, poly stride xhat_stride): the same polynomials in Ntt form, when the caller has them (it
+// produced p by an inverse transform): row j of xhat is digit j's transform under key modulus j, which the
+// kernels then read instead of recomputing (L of the L * Lk transforms).
 inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
-                             const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s) {
+                             const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s,
+                             const u64 *xhat = nullptr, u64 xhat_stride = 0) {
+    if (debug_flag("FHE_NO_KS_XHAT")) xhat = nullptr;
     const Ctx &kc = *k_.ksk_ctx;
     kc.need_device();
     if (!npolys) return;
@@ -897,7 +903,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     static const bool split14 = std::getenv("FHE_KS_SPLIT14") != nullptr && std::atoi(std::getenv("FHE_KS_SPLIT14")) != 0;
     if (kc.logn <= 13 || (kc.logn == 14 && !split14)) {  // (N = 8192 as 2 x 4096 measured +-1 %)
 #define FHE_KS_CASE(LN) \
-    case LN: launch_ks_fused<LN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s); break;
+    case LN: launch_ks_fused<LN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride); break;
         switch (kc.logn) {
             FHE_KS_CASE(3) FHE_KS_CASE(4) FHE_KS_CASE(5) FHE_KS_CASE(6) FHE_KS_CASE(7) FHE_KS_CASE(8)
             FHE_KS_CASE(9) FHE_KS_CASE(10) FHE_KS_CASE(11) FHE_KS_CASE(12) FHE_KS_CASE(13) FHE_KS_CASE(14)
@@ -915,7 +921,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     allow_big_lds((k::ks_fused_split_kernel<G0, 13, NW>), lds);                                                    \
     FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0, 13, NW>), dim3((unsigned)((npolys * kc.L) << G0)), \
                dim3(1024), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p,  \
-               k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg())
+               k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride)
 #define FHE_KS_SPLIT_CASE(G0)                                                                                      \
     case 13 + G0:                                                                                                  \
         if (narrow) {                                                                                              \
@@ -951,17 +957,18 @@ inline void switch_down_to_ntt(const Ctx &from, size_t iters, const u64 *in, u64
 // key switch followed by the level fix-up and "+= (a0, a1)" used by relinearise / rotate:
 // out0/out1 [npolys][Lct][N] (poly stride out_stride) = a + switch_down_to(key_switch(p), ct_ctx)
 inline void key_switch_add(const Ksk &k_, const u64 *p, u64 p_stride, const u64 *a0, const u64 *a1, u64 a_stride,
-                           u64 *out0, u64 *out1, u64 out_stride, size_t npolys, hipStream_t s) {
+                           u64 *out0, u64 *out1, u64 out_stride, size_t npolys, hipStream_t s,
+                           const u64 *xhat = nullptr, u64 xhat_stride = 0) {
     const Ctx &kc = *k_.ksk_ctx, &cc = *k_.ct_ctx;
     const long iters = kc.niterations_to(cc);
     if (iters == 0) {
-        key_switch_polys(k_, p, p_stride, out0, out1, out_stride, a0, a1, a_stride, npolys, s);
+        key_switch_polys(k_, p, p_stride, out0, out1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride);
         return;
     }
     const u64 kstride = (u64)kc.L * kc.n, cstride = (u64)cc.L * cc.n;
     WsGuard r0(npolys * kstride * sizeof(u64), s), r1(npolys * kstride * sizeof(u64), s);
     WsGuard d0(npolys * cstride * sizeof(u64), s), d1(npolys * cstride * sizeof(u64), s);
-    key_switch_polys(k_, p, p_stride, r0.u(), r1.u(), kstride, nullptr, nullptr, 0, npolys, s);
+    key_switch_polys(k_, p, p_stride, r0.u(), r1.u(), kstride, nullptr, nullptr, 0, npolys, s, xhat, xhat_stride);
     switch_down_to_ntt(kc, (size_t)iters, r0.u(), d0.u(), npolys, s);
     switch_down_to_ntt(kc, (size_t)iters, r1.u(), d1.u(), npolys, s);
     // out = a + d  (strided copy of a -- or of d when there is no addend -- then add)
@@ -1030,7 +1037,8 @@ inline void galois_apply(const Ksk &ks, size_t exponent, const u64 *ct, u64 *out
     m.dst_poly_stride = PL;
     launch_ntt(cc, true, sub.u() + PL, c2.u(), m, batch, k::PRO_NONE, s);
     // out0 = key_switch0 + substitute(c0) ; out1 = key_switch1   (galois_key.rs:66-79)
-    key_switch_add(ks, c2.u(), PL, sub.u(), nullptr, 2 * PL, out, out + PL, 2 * PL, batch, s);
+    // (substitute(c1) in Ntt form doubles as the transforms of digit j under key modulus j)
+    key_switch_add(ks, c2.u(), PL, sub.u(), nullptr, 2 * PL, out, out + PL, 2 * PL, batch, s, sub.u() + PL, 2 * PL);
 }
 
 // `&Ciphertext * &RGSWCiphertext` (F/bfv/rgsw_ciphertext.rs:122-156)
@@ -1045,8 +1053,9 @@ inline void rgsw_mul(const Ksk &k0, const Ksk &k1, const u64 *ct, u64 *out, size
     WsGuard pb(batch * 2 * PL * sizeof(u64), s), t(batch * 2 * PL * sizeof(u64), s);
     launch_ntt(cc, true, ct, pb.u(), full_map(cc, cc.L), batch * 2, k::PRO_NONE, s);   // ct0, ct1 -> PowerBasis
     // (c0, c1) = ksk0.key_switch(ct0);  out = (c0, c1) + ksk1.key_switch(ct1)
-    key_switch_polys(k0, pb.u(), 2 * PL, t.u(), t.u() + PL, 2 * PL, nullptr, nullptr, 0, batch, s);
-    key_switch_polys(k1, pb.u() + PL, 2 * PL, out, out + PL, 2 * PL, t.u(), t.u() + PL, 2 * PL, batch, s);
+    key_switch_polys(k0, pb.u(), 2 * PL, t.u(), t.u() + PL, 2 * PL, nullptr, nullptr, 0, batch, s, ct, 2 * PL);
+    key_switch_polys(k1, pb.u() + PL, 2 * PL, out, out + PL, 2 * PL, t.u(), t.u() + PL, 2 * PL, batch, s, ct + PL,
+                     2 * PL);
 }
 
 // EvaluationKey::computes_inner_sum (F/bfv/keys/evaluation_key.rs:56-100)

@@ -763,7 +763,8 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                     u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
                     u64 addend_poly_stride, const u64 *__restrict__ k0, const u64 *__restrict__ k0s,
                     const u64 *__restrict__ k1, const u64 *__restrict__ k1s, const DevMod *__restrict__ mods,
-                    const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk, uint32_t digit_arg) {
+                    const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk, uint32_t digit_arg,
+                    const u64 *__restrict__ xhat, u64 xhat_poly_stride) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ks_threads_c(LOGN);
     constexpr int N = 1 << LOGN;
@@ -806,6 +807,40 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     const u64 *const src0 = pin + (u64)b * src_poly_stride;
     const u64 dstride = digit_shift_bits ? 0 : (u64)N;
     const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+    // `xhat` (callers that hold the digit polynomial in Ntt form -- relinearise, Galois, RGSW: [digits][N] per
+    // polynomial over the ciphertext moduli, canonical): the RNS digit j reduced mod q_j is row j itself and its
+    // transform under key modulus j IS xhat's row j (the ciphertext moduli are a prefix of the key moduli), so that
+    // one of the L transforms of this workgroup is not computed: its product initialises the accumulators.
+    const bool own = xhat != nullptr && digit_shift_bits == 0 && j < ndigits;   // (block-uniform)
+    if (own) {
+        const u64 koff = ((u64)j * lk + j) * N;
+        const u64 *xr = xhat + (u64)b * xhat_poly_stride + (u64)j * N;
+        if constexpr (CH > 0) {
+            const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
+            const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t ci = c * T + tid0;
+                const u64x2 v = reinterpret_cast<const u64x2 *>(xr)[ci];
+                const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+                acc0[2 * c] = mul_shoup_lazy_n(v.x, q0.x, q0s.x, pm.np);        // below 2p, like every accumulator value
+                acc0[2 * c + 1] = mul_shoup_lazy_n(v.y, q0.y, q0s.y, pm.np);
+                const u64x2 a{mul_shoup_lazy_n(v.x, q1.x, q1s.x, pm.np), mul_shoup_lazy_n(v.y, q1.y, q1s.y, pm.np)};
+                if constexpr (ACC1_LDS) {
+                    acc1_lds[ci] = a;
+                } else {
+                    acc1[ACC1_LDS ? 0 : 2 * c] = a.x;
+                    acc1[ACC1_LDS ? 0 : 2 * c + 1] = a.y;
+                }
+            }
+        } else if (tid0 < N) {
+            const u64 v = xr[tid0];
+            acc0[0] = mul_shoup_lazy_n(v, k0[koff + tid0], k0s[koff + tid0], pm.np);
+            acc1[0] = mul_shoup_lazy_n(v, k1[koff + tid0], k1s[koff + tid0], pm.np);
+        }
+    }
+    const uint32_t nloop = ndigits - (own ? 1u : 0u);          // digits that go through the transform
+    auto digit_of = [&](uint32_t ii) -> uint32_t { return ii + ((own && ii >= j) ? 1u : 0u); };
     // The workgroup is alone on its CU (LDS), so nothing else hides the row load: digit i+1's
     // row is fetched into registers while digit i goes through its passes.
     constexpr bool PREFETCH = ks_acc1_in_lds_c(LOGN);   // (needs the VGPRs the LDS accumulators free)
@@ -813,10 +848,14 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     // measured: 2.5 % slower -- the extra register shuffling outweighs the saved barrier.)
     u64x2 pre[PREFETCH ? CH : 1];
     if constexpr (PREFETCH) {
+        if (nloop > 0) {
+            const u64x2 *first = reinterpret_cast<const u64x2 *>(src0 + (u64)digit_of(0) * dstride);
 #pragma unroll
-        for (int c = 0; c < CH; c++) pre[c] = reinterpret_cast<const u64x2 *>(src0)[c * T + tid0];
+            for (int c = 0; c < CH; c++) pre[c] = first[c * T + tid0];
+        }
     }
-    for (uint32_t i = 0; i < ndigits; i++) {
+    for (uint32_t ii = 0; ii < nloop; ii++) {
+        const uint32_t i = digit_of(ii);
         const uint32_t tid = opaque(tid0);
         const uint32_t sh = i * digit_shift_bits;
         if constexpr (PREFETCH) {
@@ -835,8 +874,8 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
         }
         __syncthreads();
         if constexpr (PREFETCH) {
-            if (i + 1 < ndigits) {
-                const u64x2 *nx = reinterpret_cast<const u64x2 *>(src0 + (u64)(i + 1) * dstride);
+            if (ii + 1 < nloop) {
+                const u64x2 *nx = reinterpret_cast<const u64x2 *>(src0 + (u64)digit_of(ii + 1) * dstride);
 #pragma unroll
                 for (int c = 0; c < CH; c++) pre[c] = nx[c * T + tid];
             }
@@ -1146,7 +1185,7 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
                           const u64 *__restrict__ addend1, u64 addend_poly_stride, const u64 *__restrict__ k0,
                           const u64 *__restrict__ k0s, const u64 *__restrict__ k1, const u64 *__restrict__ k1s,
                           const DevMod *__restrict__ mods, const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk,
-                          uint32_t digit_arg) {
+                          uint32_t digit_arg, const u64 *__restrict__ xhat, u64 xhat_poly_stride) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int M = 1 << LOGM, T = M / 8, CH = M / (2 * T), NS = 1 << G0;
     constexpr u64 N = (u64)M << G0;
@@ -1170,7 +1209,25 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
     for (int e = 0; e < 2 * CH; e++) acc0[e] = 0;
 #pragma unroll
     for (int c = 0; c < CH; c++) acc1_lds[c * T + tid0] = u64x2{0, 0};
-    for (uint32_t i = 0; i < ndigits; i++) {
+    // (see ks_fused_kernel: digit j under key modulus j is the caller's Ntt-form row j -- no transform)
+    const bool own = xhat != nullptr && digit_shift_bits == 0 && j < ndigits;
+    if (own) {
+        const u64 koff = ((u64)j * lk + j) * N + (u64)sub * M;
+        const u64x2 *xr = reinterpret_cast<const u64x2 *>(xhat + (u64)b * xhat_poly_stride + (u64)j * N + (u64)sub * M);
+        const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
+        const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t ci = c * T + tid0;
+            const u64x2 v = xr[ci], q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+            acc0[2 * c] = mul_shoup_lazy_n(v.x, q0.x, q0s.x, pm.np);
+            acc0[2 * c + 1] = mul_shoup_lazy_n(v.y, q0.y, q0s.y, pm.np);
+            acc1_lds[ci] = u64x2{mul_shoup_lazy_n(v.x, q1.x, q1s.x, pm.np), mul_shoup_lazy_n(v.y, q1.y, q1s.y, pm.np)};
+        }
+    }
+    const uint32_t nloop = ndigits - (own ? 1u : 0u);
+    for (uint32_t ii = 0; ii < nloop; ii++) {
+        const uint32_t i = ii + ((own && ii >= j) ? 1u : 0u);
         const uint32_t tid = opaque(tid0);
         const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N);
         const uint32_t sh = i * digit_shift_bits;

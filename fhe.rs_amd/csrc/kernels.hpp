@@ -94,6 +94,9 @@ __device__ __forceinline__ uint32_t to_sgpr(uint32_t v) {
 // is needed is that the compiler keeps the reads behind the writes -- no s_barrier, the other waves of the
 // workgroup run on.  Used between radix passes whose groups stay inside the wave's own block of the tile
 // (wave_local_exchange below).  Host emulation (fibers per thread): the workgroup barrier.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "wave_sync() / wave_local_exchange() assume 64-lane wavefronts (gfx950)"
+#endif
 __device__ __forceinline__ void wave_sync() {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_NO_WAVE_SYNC)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -108,6 +111,16 @@ __device__ __forceinline__ void wave_sync() {
 // <= 6 therefore read and write the same per-wave ranges, and the exchange between them is wave-local.
 constexpr bool wave_local_exchange(int skip_a, int g_a, int skip_b, int g_b) {
     return g_a == g_b && skip_a <= 6 && skip_b <= 6;
+}
+// Host emulation maps wave_sync() to the workgroup barrier, which would hide a violated invariant; so every pass
+// that sits next to a wave-local exchange checks there, element by element, that what a thread touches lies in its
+// own wave's block [(g0 + 64 w) 2^G, + 64 * 2^G) of the tile (g0: first group of the pass iteration, w = tid / 64).
+template <int G>
+__device__ __forceinline__ void wave_block_check(uint32_t g0, uint32_t tid, uint32_t idx) {
+#if defined(FHE_HOST_EMULATION)
+    const uint32_t lo = (g0 + (tid & ~63u)) << G;
+    if (idx < lo || idx >= lo + (64u << G)) __builtin_trap();   // a wave-local exchange would race on the GPU
+#endif
 }
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -188,7 +201,7 @@ __device__ __forceinline__ void fwd_tw_load(FwdTw<G, LOGM, S0, T> &tw_regs, cons
 // fwd_butterfly_narrow (zq_dev.hpp); values are below 16p on exit instead of 4p.
 // NT > 1: the same pass on NT tiles that lie `tile_words` apart in LDS (the key switch transforms two digits
 // under one modulus at once): addresses and twiddles are formed once and serve every tile.
-template <int G, int LOGM, int S0, int T, bool PRE, int NARROW = 0, class Src = NoSrc, int NT = 1>
+template <int G, int LOGM, int S0, int T, bool PRE, int NARROW = 0, class Src = NoSrc, int NT = 1, bool WLX = false>
 __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                          uint32_t tid, const FwdTw<G, LOGM, S0, T> &tw_regs, Src src = Src{},
                                          uint32_t tile_words = 0) {
@@ -205,6 +218,9 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
         uint32_t hi = grp >> lo_bits;
         if (UNIFORM) hi = wave_uniform(hi);
         const uint32_t base = ((grp >> lo_bits) << (LOGM - S0)) + lo;
+        if constexpr (WLX) {   // (emulation: this pass reads or writes across a wave-local exchange)
+            for (uint32_t e = 0; e < R; e++) wave_block_check<G>(g0, tid, base + (e << lo_bits));
+        }
         u64x2 w[UNIFORM || PRE ? 1 : R - 1];
         if constexpr (!UNIFORM && !PRE) {
 #pragma unroll
@@ -264,6 +280,17 @@ constexpr int fwd_plan_g() {
     return plan_base(LOGM, GM) +
            ((LATE ? PASS >= plan_np(LOGM, GM) - plan_rem(LOGM, GM) : PASS < plan_rem(LOGM, GM)) ? 1 : 0);
 }
+constexpr int fwd_plan_g_c(int logm, int gm, int pass, bool late) {
+    return plan_base(logm, gm) + ((late ? pass >= plan_np(logm, gm) - plan_rem(logm, gm) : pass < plan_rem(logm, gm)) ? 1 : 0);
+}
+// is the exchange between forward passes `pass` and `pass + 1` wave-local?
+constexpr bool fwd_wl_after(int logm, int gm, bool late, int pass) {
+    if (pass < 0 || pass + 1 >= plan_np(logm, gm)) return false;
+    int s0 = 0;
+    for (int q = 0; q < pass; q++) s0 += fwd_plan_g_c(logm, gm, q, late);
+    const int g = fwd_plan_g_c(logm, gm, pass, late), gn = fwd_plan_g_c(logm, gm, pass + 1, late);
+    return wave_local_exchange(logm - s0 - g, g, logm - s0 - g - gn, gn);
+}
 // TWPF: fetch the next pass's per-lane twiddles before the barrier (costs their registers across
 // it: the key-switch kernels, which also hold accumulators, leave it off).
 // FSYNC = false: the caller places the barrier after the last pass itself (it has loads to issue first).
@@ -271,14 +298,18 @@ template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, int NARROW, int PASS, 
 __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                                 uint32_t tid, const W &tw_regs, Src src, uint32_t tile_words) {
     constexpr int G = fwd_plan_g<LOGM, GM, PASS, LATE>();
+    constexpr bool WLX = fwd_wl_after(LOGM, GM, LATE, PASS) || fwd_wl_after(LOGM, GM, LATE, PASS - 1);
+    static_assert(!WLX || T % 64 == 0, "wave-local exchanges need whole 64-lane waves");
     if constexpr (PASS == 0)
-        fwd_pass<G, LOGM, S0, T, TWPF, NARROW, Src, NT>(lds, tw, kbase, pm, tid, tw_regs, src, tile_words);   // (Src != NoSrc: reads `src`, not LDS)
+        fwd_pass<G, LOGM, S0, T, TWPF, NARROW, Src, NT, WLX>(lds, tw, kbase, pm, tid, tw_regs, src, tile_words);   // (Src != NoSrc: reads `src`, not LDS)
     else
-        fwd_pass<G, LOGM, S0, T, TWPF, NARROW, NoSrc, NT>(lds, tw, kbase, pm, tid, tw_regs, NoSrc{}, tile_words);
+        fwd_pass<G, LOGM, S0, T, TWPF, NARROW, NoSrc, NT, WLX>(lds, tw, kbase, pm, tid, tw_regs, NoSrc{}, tile_words);
     if constexpr (PASS + 1 < plan_np(LOGM, GM)) {
         constexpr int GN = fwd_plan_g<LOGM, GM, PASS + 1, LATE>();
         FwdTw<GN, LOGM, S0 + G, T> next;
         if constexpr (TWPF) fwd_tw_load(next, tw, kbase, tid);   // in flight across the barrier
+        static_assert(wave_local_exchange(LOGM - S0 - G, G, LOGM - S0 - G - GN, GN) == fwd_wl_after(LOGM, GM, LATE, PASS),
+                      "pass plan bookkeeping");
         if constexpr (wave_local_exchange(LOGM - S0 - G, G, LOGM - S0 - G - GN, GN))
             wave_sync();
         else
@@ -340,7 +371,7 @@ __device__ __forceinline__ void inv_tw_load(InvTw<G, LOGM, V0, T> &tw_regs, cons
 // multiplication and is below 2p again -- and `bnd[]` tracks every register's bound (in units of p)
 // through the fully unrolled stages, so the conditional subtractions shrink to the few needed to keep
 // sums below 16p and to hand the next pass values below 2p (7 instead of 12 per radix-8 group).
-template <int G, int LOGM, int V0, int T, bool NARROW = false>
+template <int G, int LOGM, int V0, int T, bool NARROW = false, bool WLX = false>
 __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
                                          const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv,
                                          const InvTw<G, LOGM, V0, T> &tw_regs) {
@@ -356,6 +387,9 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
         uint32_t hi = grp >> V0;
         if (UNIFORM) hi = wave_uniform(hi);
         const uint32_t base = ((grp >> V0) << (V0 + G)) + lo;
+        if constexpr (WLX) {   // (emulation, see fwd_pass)
+            for (uint32_t e = 0; e < R; e++) wave_block_check<G>(g0, tid, base + (e << V0));
+        }
         u64 *const g = lds + padi(base);  // see fwd_pass: constant per-element offsets
         u64 x[R];
 #pragma unroll
@@ -432,6 +466,16 @@ template <int LOGM, int PASS>
 constexpr int inv_plan_g() {
     return plan_base(LOGM, GMAX) + (PASS >= plan_np(LOGM, GMAX) - plan_rem(LOGM, GMAX) ? 1 : 0);
 }
+constexpr int inv_plan_g_c(int logm, int pass) {
+    return plan_base(logm, GMAX) + (pass >= plan_np(logm, GMAX) - plan_rem(logm, GMAX) ? 1 : 0);
+}
+constexpr bool inv_wl_after(int logm, int pass) {   // exchange between inverse passes `pass` and `pass + 1`
+    if (pass < 0 || pass + 1 >= plan_np(logm, GMAX)) return false;
+    int v0 = 0;
+    for (int q = 0; q < pass; q++) v0 += inv_plan_g_c(logm, q);
+    const int g = inv_plan_g_c(logm, pass);
+    return wave_local_exchange(v0, g, v0 + g, inv_plan_g_c(logm, pass + 1));
+}
 template <int LOGM, int T>
 using InvTwFirst = InvTw<inv_plan_g<LOGM, 0>(), LOGM, 0, T>;
 template <int LOGM, int T, int PASS = 0, int V0 = 0, bool NARROW = false, class W>
@@ -439,10 +483,14 @@ __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ 
                                             const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv,
                                             const W &tw_regs) {
     constexpr int G = inv_plan_g<LOGM, PASS>();
-    inv_pass<G, LOGM, V0, T, NARROW>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, tw_regs);
+    constexpr bool WLX = inv_wl_after(LOGM, PASS) || inv_wl_after(LOGM, PASS - 1);
+    static_assert(!WLX || T % 64 == 0, "wave-local exchanges need whole 64-lane waves");
+    inv_pass<G, LOGM, V0, T, NARROW, WLX>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, tw_regs);
     if constexpr (PASS + 1 < plan_np(LOGM, GMAX)) {
         InvTw<inv_plan_g<LOGM, PASS + 1>(), LOGM, V0 + G, T> next;
         inv_tw_load(next, itw, logn, sub, tid);   // in flight across the barrier
+        static_assert(wave_local_exchange(V0, G, V0 + G, inv_plan_g<LOGM, PASS + 1>()) == inv_wl_after(LOGM, PASS),
+                      "pass plan bookkeeping");
         if constexpr (wave_local_exchange(V0, G, V0 + G, inv_plan_g<LOGM, PASS + 1>()))
             wave_sync();
         else

@@ -80,5 +80,8 @@ def breakdown(fn):
 
 
 if __name__ == "__main__":
-    c3()
-    c5()
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "c3"):
+        c3()
+    if which in ("all", "c5"):
+        c5()

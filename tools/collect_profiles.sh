@@ -10,9 +10,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps $STEPS --warmup 2"
 $BENCH > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $BENCH --no-cpu --no-two-stream > $OUT/stats_bench.json 2> $OUT/stats.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o run -- $BENCH --no-cpu --no-two-stream > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o run -- $BENCH --no-cpu --no-two-stream > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $BENCH --no-cpu --no-extras > $OUT/stats_bench.json 2> $OUT/stats.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o run -- $BENCH --no-cpu --no-extras > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o run -- $BENCH --no-cpu --no-extras > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.log
 # keep only the small summaries (kernel_trace of a PMC pass can be large)
 find $OUT -name '*kernel_trace.csv' -size +8M -delete
 ls -laR $OUT | tail -30

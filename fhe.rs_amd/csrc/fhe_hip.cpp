@@ -5,6 +5,7 @@
 #include "../../include/fhe_hip.h"
 
 #include <cstdio>
+#include <map>
 
 #include "engine.hpp"
 
@@ -29,10 +30,14 @@ struct fhe_mul {
     std::vector<std::unique_ptr<fhe_ctx>> ctxs;
     std::vector<std::unique_ptr<fhe_scaler>> scalers;
 };
+struct HostTables {  // one NttOperator's tables as the host's callback filled them
+    std::vector<u64> om, oms, zi, zis;
+    u64 si = 0, sis = 0;
+};
 struct fhe_params {
     int device = -1;
-    fhe_ntt_tables_fn tables = nullptr;  // the host's NTT tables (NULL: the engine's own psi)
-    void *tables_user = nullptr;
+    bool host_tables = false;               // created with the host's NTT tables (callback)
+    std::map<u64, HostTables> table_cache;  // modulus -> tables, filled while the callback was alive
     size_t degree = 0;
     u64 plaintext = 0;
     std::vector<u64> moduli;
@@ -128,16 +133,31 @@ std::unique_ptr<Ksk> make_ksk(const Ctx &ct, const Ctx &kc, size_t ndigits, size
     k_->log_base = log_base;
     return k_;
 }
-// Context over `moduli` whose NTT tables come from the host's callback (NULL: the engine's own psi).
+// Context over `moduli` whose NTT tables come from the host's callback (NULL: the engine's own psi).  Every table
+// is cached per modulus, so handles made later from the parameter set (a level-specific multiplication basis) never
+// call back into the host: `fn` is only invoked while fhe_params_create_with_tables runs.
 std::unique_ptr<Ctx> ctx_create_cb(int device, size_t degree, const std::vector<u64> &moduli, fhe_ntt_tables_fn fn,
-                                   void *user) {
-    if (!fn) return ctx_create(device, degree, moduli, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                                   void *user, bool host_tables, std::map<u64, HostTables> &cache) {
+    if (!host_tables) return ctx_create(device, degree, moduli, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     const size_t L = moduli.size();
     std::vector<u64> om(L * degree), oms(L * degree), zi(L * degree), zis(L * degree), si(L), sis(L);
-    for (size_t i = 0; i < L; i++)
-        if (fn(user, moduli[i], degree, &om[i * degree], &oms[i * degree], &zi[i * degree], &zis[i * degree], &si[i],
-               &sis[i]) != 0)
-            throw StatusError(FHE_E_NTT_UNAVAILABLE, "NttOperatorUnavailable: the host's table callback failed");
+    for (size_t i = 0; i < L; i++) {
+        auto it = cache.find(moduli[i]);
+        if (it == cache.end()) {
+            if (!fn) throw StatusError(FHE_E_NTT_UNAVAILABLE, "NttOperatorUnavailable: no host table cached for this modulus");
+            HostTables t;
+            t.om.resize(degree), t.oms.resize(degree), t.zi.resize(degree), t.zis.resize(degree);
+            if (fn(user, moduli[i], degree, t.om.data(), t.oms.data(), t.zi.data(), t.zis.data(), &t.si, &t.sis) != 0)
+                throw StatusError(FHE_E_NTT_UNAVAILABLE, "NttOperatorUnavailable: the host's table callback failed");
+            it = cache.emplace(moduli[i], std::move(t)).first;
+        }
+        const HostTables &t = it->second;
+        std::copy(t.om.begin(), t.om.end(), om.begin() + i * degree);
+        std::copy(t.oms.begin(), t.oms.end(), oms.begin() + i * degree);
+        std::copy(t.zi.begin(), t.zi.end(), zi.begin() + i * degree);
+        std::copy(t.zis.begin(), t.zis.end(), zis.begin() + i * degree);
+        si[i] = t.si, sis[i] = t.sis;
+    }
     return ctx_create(device, degree, moduli, om.data(), oms.data(), zi.data(), zis.data(), si.data(), sis.data());
 }
 }  // namespace
@@ -1199,13 +1219,12 @@ fhe_status fhe_params_create_with_tables(int device, size_t degree, size_t nmodu
         require(plaintext_modulus >= 2, E_ARG, "plaintext modulus must be >= 2");
         auto p = std::make_unique<fhe_params>();
         p->device = device;
-        p->tables = tables;
-        p->tables_user = user;
+        p->host_tables = tables != nullptr;
         p->degree = degree;
         p->plaintext = plaintext_modulus;
         p->moduli.assign(moduli, moduli + nmoduli);
         for (u64 q : p->moduli) p->moduli_sizes.push_back(64 - (size_t)__builtin_clzll(q | 1));
-        p->top = wrap_ctx(ctx_create_cb(device, degree, p->moduli, tables, user));
+        p->top = wrap_ctx(ctx_create_cb(device, degree, p->moduli, tables, user, p->host_tables, p->table_cache));
         // extended basis: n+1 primes of 62 bits (parameters.rs:660-676)
         std::vector<u64> ext = extended_basis_primes(degree, p->moduli, nmoduli + 1);
         BigUint t(plaintext_modulus);
@@ -1216,7 +1235,7 @@ fhe_status fhe_params_create_with_tables(int device, size_t degree, size_t nmodu
             const size_t n_moduli = (modulus_size + 60 + 61) / 62;  // div_ceil
             std::vector<u64> mm(p->moduli.begin(), p->moduli.begin() + nl);
             mm.insert(mm.end(), ext.begin(), ext.begin() + n_moduli);
-            auto mc = wrap_ctx(ctx_create_cb(device, degree, mm, tables, user));
+            auto mc = wrap_ctx(ctx_create_cb(device, degree, mm, tables, user, p->host_tables, p->table_cache));
             const Ctx &base = *p->top->c->at_level(level);
             RnsContext rb(base.moduli);
             auto e = std::make_unique<fhe_scaler>();
@@ -1284,7 +1303,9 @@ fhe_status fhe_mul_create_default(const fhe_params *p, size_t level, const fhe_k
             const std::vector<u64> extp = extended_basis_primes(p->degree, base.moduli, n_moduli);
             mm.insert(mm.end(), extp.begin(), extp.end());
             if (mm != p->mul_ctx[level]->c->moduli) {
-                auto mc = wrap_ctx(ctx_create_cb(p->device, p->degree, mm, p->tables, p->tables_user));
+                // (every prime of this basis is a top-level modulus or one of the cached extension primes)
+                auto mc = wrap_ctx(ctx_create_cb(p->device, p->degree, mm, nullptr, nullptr, p->host_tables,
+                                                 const_cast<fhe_params *>(p)->table_cache));
                 RnsContext rb(base.moduli);
                 auto e = std::make_unique<fhe_scaler>();
                 e->s = scaler_create(base, *mc->c, BigUint(1), BigUint(1));

@@ -322,7 +322,9 @@ fhe_status fhe_params_create(int device, size_t degree, size_t nmoduli, const ui
  * once for every modulus it builds a context over -- the ciphertext moduli and the 62-bit extension primes of
  * parameters.rs:660-676 -- and the host fills the four [degree] tables and the two scalars of
  * NttOperator::new(modulus, degree) (M/ntt/native.rs:16-26, same meaning as in fhe_ctx_create).  A non-zero
- * return aborts creation with FHE_E_NTT_UNAVAILABLE.  tables == NULL behaves like fhe_params_create. */
+ * return aborts creation with FHE_E_NTT_UNAVAILABLE.  The callback is invoked only while this call runs (the
+ * tables are cached per modulus for handles made later, e.g. fhe_mul_create_default's level-specific basis).
+ * tables == NULL behaves like fhe_params_create. */
 typedef int (*fhe_ntt_tables_fn)(void *user, uint64_t modulus, size_t degree, uint64_t *omegas,
                                  uint64_t *omegas_shoup, uint64_t *zetas_inv, uint64_t *zetas_inv_shoup,
                                  uint64_t *size_inv, uint64_t *size_inv_shoup);

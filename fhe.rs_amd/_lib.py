@@ -87,6 +87,8 @@ SIGNATURES = {
     "fhe_bfv_dot_product_scalar_dev": (i32, [vp, sz, sz, vp, i32, vp, i32, vp, sz, vp]),
     "fhe_bfv_mul_plain": (i32, [vp, sz, u64p, u64p, i32, u64p, sz]),
     "fhe_bfv_mul_plain_dev": (i32, [vp, sz, vp, vp, i32, vp, sz, vp]),
+    "fhe_poly_from_seed": (i32, [vp, u8p, u64p, sz]),
+    "fhe_poly_from_seed_dev": (i32, [vp, vp, vp, sz, vp]),
     "fhe_bfv_decrypt": (i32, [vp, u64, u64p, u64p, sz, u64p, sz]),
     "fhe_bfv_decrypt_dev": (i32, [vp, u64, vp, vp, sz, vp, sz, vp]),
     "fhe_bfv_rgsw_mul": (i32, [vp, vp, u64p, u64p, sz]),

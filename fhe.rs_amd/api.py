@@ -302,6 +302,20 @@ class Context:
         check(L.fhe_bfv_mul_plain(self._h, parts, _ptr(x), _ptr(y), shared, _ptr(out), batch))
         return out
 
+    def random_from_seed(self, seeds):
+        """Poly::<Ntt>::random_from_seed (rq/mod.rs:276-292) per 32-byte seed: seeds [batch, 32] uint8 ->
+        [batch, L, N]; numpy in -> numpy out, torch CUDA uint8 tensor in -> CUDA tensor out."""
+        L = _lib.lib()
+        if _is_dev(seeds):
+            b = int(seeds.numel() // 32)
+            out = torch.empty((b, self.nmoduli, self.degree), dtype=torch.int64, device=seeds.device)
+            check(L.fhe_poly_from_seed_dev(self._h, _dptr8(seeds), _dptr(out), b, _stream()))
+            return out
+        sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint8)).reshape(-1, 32)
+        out = np.zeros((sd.shape[0], self.nmoduli, self.degree), dtype=np.uint64)
+        check(L.fhe_poly_from_seed(self._h, sd.ctypes.data_as(_lib.u8p), _ptr(out), sd.shape[0]))
+        return out
+
     def synth_uniform(self, seed, ct0, part0, nparts, batch):
         """Device-side synthetic residues [batch, nparts, L, N] (bench / parity inputs)."""
         out = torch.empty((batch, nparts, self.nmoduli, self.degree), dtype=torch.int64, device=f"cuda:{self.device}")

@@ -594,6 +594,15 @@ inline void wire_deserialize(const Ctx &c, const uint8_t *bytes, u64 *polys, siz
     if (to_ntt) launch_ntt(c, false, polys, polys, full_map(c, c.L), npolys, k::PRO_NONE, s);
 }
 
+// Poly::random_from_seed (M/rq/mod.rs:276-292): seeds [npolys][32] -> polys [npolys][L][N]
+inline void polys_from_seeds(const Ctx &c, const uint8_t *seeds, u64 *polys, size_t npolys, hipStream_t s) {
+    c.need_device();
+    if (!npolys) return;
+    FHE_LAUNCH("seed_expand", k::seed_expand_kernel, dim3((unsigned)npolys), dim3(k::SEED_THREADS), k::SEED_SMEM_BYTES, s, seeds,
+               polys,
+               c.dmods(), (uint32_t)c.L, (uint32_t)c.logn);
+}
+
 // ----------------------------------------------------------------------- rq::Scaler ----
 struct Scaler {
     const Ctx *from = nullptr, *to = nullptr;

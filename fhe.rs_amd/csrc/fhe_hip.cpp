@@ -989,6 +989,35 @@ fhe_status fhe_bfv_inner_sum(const fhe_ksk *const *gks, const size_t *exponents,
     });
 }
 
+fhe_status fhe_poly_from_seed_dev(const fhe_ctx *ctx, const uint8_t *seeds, uint64_t *out, size_t batch, void *stream) {
+    return guard([&] {
+        need(ctx, "ctx");
+        if (batch) {
+            need(seeds, "seeds");
+            need(out, "out");
+        }
+        set_device(*ctx->c);
+        polys_from_seeds(*ctx->c, seeds, out, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_poly_from_seed(const fhe_ctx *ctx, const uint8_t *seeds, uint64_t *out, size_t batch) {
+    return guard([&] {
+        need(ctx, "ctx");
+        if (batch) {
+            need(seeds, "seeds");
+            need(out, "out");
+        }
+        const Ctx &c = *ctx->c;
+        c.need_device();
+        set_device(c);
+        const size_t pe = c.L * c.n;
+        HostIO io;
+        u64 *ds = io.out((batch * 32 + 7) / 8), *dout = io.out(batch * pe);
+        if (batch) FHE_HIP_CHECK(hipMemcpy(ds, seeds, batch * 32, hipMemcpyHostToDevice));
+        polys_from_seeds(c, reinterpret_cast<const uint8_t *>(ds), dout, batch, nullptr);
+        io.back(out, dout, batch * pe);
+    });
+}
 fhe_status fhe_bfv_decrypt_dev(const fhe_scaler *sc, uint64_t t, const uint64_t *s_ntt, const uint64_t *ct, size_t nparts,
                                uint64_t *out, size_t batch, void *stream) {
     return guard([&] {

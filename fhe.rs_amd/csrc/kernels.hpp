@@ -1886,6 +1886,143 @@ __global__ void expand_step_kernel(u64 *__restrict__ low, const u64 *__restrict_
     low[idx] = add_mod(lo, sb, m.p);
 }
 
+// ------------------------------------------------------ seeded polynomial (wire c1) ----
+// Poly::random_from_seed (M/rq/mod.rs:276-292), the `c1` a received secret-key ciphertext expands from its 32-byte
+// seed (F/bfv/ciphertext.rs:287-302): key = SHA-256(seed); one ChaCha8 stream (64-bit block counter from 0, stream
+// id 0; a u64 = two consecutive little-endian words); residue row after residue row, `degree` draws each from
+// Uniform[0, q_i) by Lemire's widening-multiply rejection: x -> (hi, lo) = x * q, accept hi when
+// lo >= (2^64 - q) mod q.  The stream position of a coefficient depends on the rejections before it, so one
+// workgroup walks one polynomial: every thread computes one ChaCha block (8 candidates), an exclusive scan of the
+// accept counts places the survivors, and the position after the row's last accepted draw starts the next batch.
+// SHA-256 and the ChaCha block function are pinned by known-answer tests of the oracle; the generator's layout and
+// the sampling rule restate rand_chacha 0.10 / rand 0.10, which are not vendored: PARITY UNPINNED (like psi).
+__device__ __forceinline__ uint32_t rotr32(uint32_t v, int c) { return (v >> c) | (v << (32 - c)); }
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+// SHA-256 of exactly 32 bytes (one padded block); digest as 8 big-endian words
+__device__ inline void sha256_32(const uint8_t *msg, uint32_t h[8]) {
+    const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+        0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+        0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+        0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+        0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 8; i++)
+        w[i] = ((uint32_t)msg[4 * i] << 24) | ((uint32_t)msg[4 * i + 1] << 16) | ((uint32_t)msg[4 * i + 2] << 8) | msg[4 * i + 3];
+    w[8] = 0x80000000u;
+    for (int i = 9; i < 15; i++) w[i] = 0;
+    w[15] = 256;   // message length in bits
+    for (int i = 16; i < 64; i++) {
+        const uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        const uint32_t s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = 0x6a09e667, b = 0xbb67ae85, c = 0x3c6ef372, d = 0xa54ff53a, e = 0x510e527f, f = 0x9b05688c, g = 0x1f83d9ab,
+             hh = 0x5be0cd19;
+    const uint32_t init[8] = {a, b, c, d, e, f, g, hh};
+    for (int i = 0; i < 64; i++) {
+        const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25), ch = (e & f) ^ (~e & g);
+        const uint32_t t1 = hh + S1 + ch + K[i] + w[i];
+        const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22), mj = (a & b) ^ (a & c) ^ (b & c);
+        const uint32_t t2 = S0 + mj;
+        hh = g, g = f, f = e, e = d + t1, d = c, c = b, b = a, a = t1 + t2;
+    }
+    const uint32_t fin[8] = {a, b, c, d, e, f, g, hh};
+    for (int i = 0; i < 8; i++) h[i] = init[i] + fin[i];
+}
+// One ChaCha8 block: key words (little-endian), 64-bit block counter, stream id 0.
+__device__ __forceinline__ void chacha8_block(const uint32_t key[8], u64 counter, uint32_t out[16]) {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                      key[4], key[5], key[6], key[7], (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = s[i];
+#define FHE_CHACHA_QR(a, b, c, d)                  \
+    x[a] += x[b], x[d] = rotl32(x[d] ^ x[a], 16);  \
+    x[c] += x[d], x[b] = rotl32(x[b] ^ x[c], 12);  \
+    x[a] += x[b], x[d] = rotl32(x[d] ^ x[a], 8);   \
+    x[c] += x[d], x[b] = rotl32(x[b] ^ x[c], 7);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {   // 8 rounds = 4 double rounds
+        FHE_CHACHA_QR(0, 4, 8, 12) FHE_CHACHA_QR(1, 5, 9, 13) FHE_CHACHA_QR(2, 6, 10, 14) FHE_CHACHA_QR(3, 7, 11, 15)
+        FHE_CHACHA_QR(0, 5, 10, 15) FHE_CHACHA_QR(1, 6, 11, 12) FHE_CHACHA_QR(2, 7, 8, 13) FHE_CHACHA_QR(3, 4, 9, 14)
+    }
+#undef FHE_CHACHA_QR
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+// grid.x = polynomials; 256 threads; seeds [npolys][32] bytes -> out [npolys][nmod][N].
+constexpr int SEED_THREADS = 256;
+constexpr size_t SEED_SMEM_BYTES = 8 + 8 * 4 + SEED_THREADS * 4;
+__global__ void __launch_bounds__(SEED_THREADS)
+    seed_expand_kernel(const uint8_t *__restrict__ seeds, u64 *__restrict__ out, const DevMod *__restrict__ mods,
+                       uint32_t nmod, uint32_t logn) {
+    FHE_DYN_SMEM(u64, sm);   // SEED_SMEM_BYTES: next position | key[8] | scan[SEED_THREADS]
+    u64 &s_next_pos = sm[0];
+    uint32_t *const s_key = reinterpret_cast<uint32_t *>(sm + 1);
+    uint32_t *const s_scan = s_key + 8;
+    const uint32_t tid = threadIdx.x, n = 1u << logn;
+    if (tid == 0) {
+        uint32_t h[8];
+        sha256_32(seeds + (u64)blockIdx.x * 32, h);
+        // the digest's bytes (big-endian words) are the seed array; ChaCha reads its key as little-endian words
+        for (int i = 0; i < 8; i++) s_key[i] = __builtin_bswap32(h[i]);
+    }
+    __syncthreads();
+    uint32_t key[8];
+    for (int i = 0; i < 8; i++) key[i] = s_key[i];
+    u64 *dst = out + (u64)blockIdx.x * nmod * n;
+    u64 pos = 0;   // index of the next u64 of the stream (uniform)
+    for (uint32_t r = 0; r < nmod; r++) {
+        const u64 q = mods[r].p;
+        const u64 thresh = (0 - q) % q;   // (2^64 - q) mod q
+        uint32_t produced = 0;
+        while (produced < n) {
+            const u64 blk = (pos >> 3) + tid;
+            uint32_t w[16];
+            chacha8_block(key, blk, w);
+            u64 val[8];
+            uint32_t accept = 0;   // bit k: candidate k of this block is drawn (not before `pos`) and accepted
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u64 x = (u64)w[2 * k] | ((u64)w[2 * k + 1] << 32);
+                const u128_t m = (u128_t)x * q;
+                val[k] = (u64)(m >> 64);
+                if (8 * blk + k >= pos && (u64)m >= thresh) accept |= 1u << k;
+            }
+            // exclusive scan of the accept counts over the workgroup (Hillis-Steele in LDS)
+            const uint32_t cnt = (uint32_t)__builtin_popcount(accept);
+            s_scan[tid] = cnt;
+            __syncthreads();
+            for (uint32_t off = 1; off < SEED_THREADS; off <<= 1) {
+                const uint32_t v = tid >= off ? s_scan[tid - off] : 0;
+                __syncthreads();
+                s_scan[tid] += v;
+                __syncthreads();
+            }
+            const uint32_t incl = s_scan[tid], total = s_scan[SEED_THREADS - 1];
+            uint32_t rank = produced + incl - cnt;
+            const uint32_t need = n - produced;   // draws this row still takes
+            if (tid == 0) s_next_pos = 8 * ((pos >> 3) + SEED_THREADS);   // all candidates consumed unless the row ends here
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (accept & (1u << k)) {
+                    if (rank < n) dst[(u64)r * n + rank] = val[k];
+                    if (rank + 1 == n && total >= need) s_next_pos = 8 * blk + k + 1;   // the row's last draw
+                    rank++;
+                }
+            }
+            __syncthreads();
+            pos = s_next_pos;
+            produced = total >= need ? n : produced + total;
+            __syncthreads();
+        }
+    }
+}
+
 // Copies the first `rows` rows of each polynomial: in [npolys][in_rows][N] -> out [npolys][out_rows][N].
 __global__ void copy_rows_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,
                                  u64 out_poly_stride, u64 per_poly, u64 total) {

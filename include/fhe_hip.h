@@ -229,6 +229,15 @@ fhe_status fhe_bfv_mul_plain(const fhe_ctx *ctx, size_t nparts, const uint64_t *
                              uint64_t *out, size_t batch);
 fhe_status fhe_bfv_mul_plain_dev(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, const uint64_t *pt,
                                  int pt_shared, uint64_t *out, size_t batch, void *stream);
+/* Poly::<Ntt>::random_from_seed (M/rq/mod.rs:276-292) as a received ciphertext applies it (F/bfv/ciphertext.rs:
+ * 287-302): seeds [batch][32] bytes -> out [batch][L][N], the polynomial c1 of a seeded ciphertext, taken as Ntt form.
+ * key = SHA-256(seed); one ChaCha8 stream per polynomial; every residue row draws `degree` values from
+ * Uniform[0, q_i).  SHA-256 and the ChaCha block function are public algorithms (known-answer tested); the
+ * generator's word layout and the rejection sampler restate rand_chacha 0.10 / rand 0.10, third-party crates the
+ * reference does not vendor: PARITY UNPINNED against a real fhe.rs run, exactly like the NTT's psi -- a host that
+ * needs certainty expands c1 itself and uploads it. */
+fhe_status fhe_poly_from_seed(const fhe_ctx *ctx, const uint8_t *seeds, uint64_t *out, size_t batch);
+fhe_status fhe_poly_from_seed_dev(const fhe_ctx *ctx, const uint8_t *seeds, uint64_t *out, size_t batch, void *stream);
 /* SecretKey::try_decrypt, small-plaintext branch (F/bfv/keys/secret_key.rs:198-247): phase
  * c0 + c1 s + c2 s^2 + ... over the ciphertext context, PowerBasis, Scaler::scale with the level's
  * cipher-to-plaintext scaler (factor t / q, F/bfv/parameters.rs:636-643), then per coefficient

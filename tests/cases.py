@@ -377,6 +377,26 @@ def case_key_switch_many_digits(fhe, dev, n=128, shapes=((50, 10), (58, 17), (62
             assert np.array_equal(rot[b], ck.galois_relinearize(3, ct3[b, :2])), (bits, L, b)
 
 
+def case_random_from_seed(fhe, dev, n=64):
+    """rq/mod.rs:276-292 + bfv/ciphertext.rs:287-302: the seeded c1 of a wire ciphertext, against the oracle's
+    restatement (SHA-256 -> ChaCha8 -> Lemire rejection per residue row), with moduli whose rejection rate runs
+    from ~0 (a 60-bit NTT prime) over ~2 % (a 61-bit prime far from a power of two) to a 20-bit modulus, so that
+    rejected draws shift the stream inside and across rows; several seeds per call."""
+    from fhe_oracle import seeded
+    from fhe_oracle.zq import generate_prime
+    x = Xfer(dev)
+    for moduli in ([generate_prime(60, 2 * n, 1 << 60)],
+                   [generate_prime(61, 2 * n, 0x1400000000000000), generate_prime(60, 2 * n, 1 << 60),
+                    generate_prime(20, 2 * n, 1 << 20), generate_prime(62, 2 * n, 1 << 62)]):
+        ctx = fhe.Context(moduli, n)
+        seeds = np.array([[(7 * b + i) & 0xFF for i in range(32)] for b in range(5)], dtype=np.uint8)
+        got = x.back(ctx.random_from_seed(x.to_bytes(seeds)))
+        for b in range(5):
+            want = np.array(seeded.random_from_seed(moduli, n, bytes(seeds[b])), dtype=np.uint64)
+            assert np.array_equal(got[b], want), (moduli, b)
+    assert ctx.random_from_seed(x.to_bytes(np.zeros((0, 32), dtype=np.uint8))).shape[0] == 0
+
+
 def case_key_switch_decomposition(fhe, dev, n=16):
     """key_switching_key.rs:323-362, 600-633 (single-modulus key level, base-2^k digits)."""
     x = Xfer(dev)

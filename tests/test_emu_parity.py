@@ -173,6 +173,11 @@ def test_key_switch_many_digits(fhe):
     cases.case_key_switch_many_digits(fhe, False)
 
 
+def test_random_from_seed(fhe):
+    cases.case_random_from_seed(fhe, False)
+    cases.case_random_from_seed(fhe, False, n=2048)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 

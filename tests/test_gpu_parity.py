@@ -153,6 +153,12 @@ def test_key_switch_many_digits(fhe):
     cases.case_key_switch_many_digits(fhe, True, n=8192, shapes=((60, 9), (50, 11), (62, 4)))
 
 
+@pytest.mark.parametrize("dev", [False, True])
+def test_random_from_seed(fhe, dev):
+    cases.case_random_from_seed(fhe, dev)
+    cases.case_random_from_seed(fhe, dev, n=2048)
+
+
 def test_errors(fhe):
     cases.case_errors(fhe)
 

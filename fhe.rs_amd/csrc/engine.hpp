@@ -428,6 +428,20 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
             bool narrow = !debug_flag("FHE_NO_NARROW");
             for (uint32_t r = 0; r < map.rows; r++)
                 narrow = narrow && (c.root->moduli[(size_t)((int32_t)(map.row_begin + r) + map.mod_offset)] >> 60) == 0;
+            static const bool swap_variant = std::getenv("FHE_NTT_SWAP") != nullptr && std::atoi(std::getenv("FHE_NTT_SWAP")) != 0;
+            if (swap_variant && logn == 13) {   // measured alternative: in-wave stages by lane exchange (kernels.hpp)
+                const size_t lds = k::lds_words(1u << 13) * sizeof(u64);
+                if (narrow) {
+                    allow_big_lds((k::ntt_fwd_swap_kernel<true>), lds);
+                    FHE_LAUNCH("ntt_fwd", (k::ntt_fwd_swap_kernel<true>), dim3(rows_total), dim3(512), lds, s, in, out, map,
+                               c.dmods(), c.dtw(), prologue);
+                } else {
+                    allow_big_lds((k::ntt_fwd_swap_kernel<false>), lds);
+                    FHE_LAUNCH("ntt_fwd", (k::ntt_fwd_swap_kernel<false>), dim3(rows_total), dim3(512), lds, s, in, out, map,
+                               c.dmods(), c.dtw(), prologue);
+                }
+                return;
+            }
             if (narrow)
                 launch_ntt_lds<false, true>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(),
                                             logn, prologue);

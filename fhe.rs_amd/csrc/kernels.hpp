@@ -607,6 +607,152 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     }
 }
 
+// ------------------------------- forward NTT with in-wave stages by lane exchange ----
+// north_star's "wavefront shuffles for the inner radix stages", built and measured against ntt_kernel (DESIGN.md
+// section 6; FHE_NTT_SWAP=1 selects it for forward launches over 8192-point rows).  N = 8192, 512 threads x 16
+// coefficients, three passes instead of four:
+//   pass 1  stages 0-2 (position bits 12..10), strided groups straight from global memory, written to the tile;
+//           the ONE workgroup barrier of the transform follows;
+//   pass 2  six stages without touching LDS: wave w owns positions [1024 w, 1024 (w + 1)); a thread's 16 registers
+//           are position bits 9..6, its lane number bits 5..0.  Stages 3-6 run in registers (wave-uniform scalar
+//           twiddles); for stage 7 v_permlane32_swap exchanges register bit 3 with lane bit 5 -- afterwards each
+//           lane holds both ends of its butterflies on bit 5 -- and for stage 8 v_permlane16_swap does the same
+//           with register bit 2 and lane bit 4: one VALU instruction per 32-bit half instead of an LDS round trip;
+//   pass 3  stages 9-12 on 16 consecutive coefficients per thread after a WAVE-LOCAL exchange through the tile
+//           (pass 2 and pass 3 touch only the wave's own 1024 positions), then the usual coalesced store.
+// LDS round trips 3 (4 in ntt_kernel), workgroup barriers 1 + the store's (2 + 1).
+__device__ __forceinline__ void lane_swap64(u64 &a, u64 &b, uint32_t tid, int bit /* 5 or 4 */) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    if (bit == 5) {   // lanes 32..63 of `a` <-> lanes 0..31 of `b`
+        const auto lo = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+        al = lo[0], bl = lo[1], ah = hi[0], bh = hi[1];
+    } else {          // odd 16-lane rows of `a` <-> even rows of `b`
+        const auto lo = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+        al = lo[0], bl = lo[1], ah = hi[0], bh = hi[1];
+    }
+    a = (u64)al | ((u64)ah << 32);
+    b = (u64)bl | ((u64)bh << 32);
+#else
+    // host emulation (one workgroup at a time, fibers): the same exchange through a scratch array
+    static u64 xchg[2][1024];
+    xchg[0][tid] = a, xchg[1][tid] = b;
+    __syncthreads();
+    const uint32_t partner = tid ^ (1u << bit);
+    u64 na = a, nb = b;
+    if ((tid >> bit) & 1)
+        na = xchg[1][partner];   // upper half: a <- partner's b
+    else
+        nb = xchg[0][partner];   // lower half: b <- partner's a
+    __syncthreads();
+    a = na, b = nb;
+#endif
+}
+template <bool NARROW>
+__global__ void __launch_bounds__(512, 4)
+    ntt_fwd_swap_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map, const DevMod *__restrict__ mods,
+                        const u64x2 *__restrict__ tw, uint32_t prologue) {
+    FHE_DYN_SMEM(u64, lds);
+    constexpr int LOGM = 13, T = 512, M = 1 << LOGM, CH = tile_chunks_c(LOGM, T);
+    constexpr int NB = NARROW ? 1 : 0;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t rowb = blockIdx.x;
+    const uint32_t poly = to_sgpr(rowb / map.rows);
+    const uint32_t r = map.row_begin + (rowb - poly * map.rows);
+    const uint32_t mi = (uint32_t)(map.mod_offset + (int32_t)r);
+    const DevMod md = mods[mi];
+    const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
+    const u64 *src = in + (u64)poly * map.src_poly_stride + (u64)(map.src_row_fixed >= 0 ? (uint32_t)map.src_row_fixed : r) * M;
+    u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * M;
+    const u64x2 *twr = tw + (u64)mi * M;
+    auto bfly = [&](u64 &x, u64 &y, const u64x2 wv, int stage) {
+        if constexpr (NARROW)
+            fwd_butterfly_narrow(x, y, wv.x, wv.y, pm, fwd_narrow_corrects(stage, NB));
+        else
+            fwd_butterfly(x, y, wv.x, wv.y, pm);
+    };
+    // ---- pass 1: stages 0-2 from global memory (two groups of 8 per thread)
+    {
+        const bool red = prologue == PRO_REDUCE;
+        FwdTw<3, LOGM, 0, T> none;
+        fwd_pass<3, LOGM, 0, T, true, NB>(lds, twr, 1, pm, tid, none, [&](uint32_t i, uint32_t) {
+            const u64 v = src[i];
+            return red ? reduce_u64(v, md) : v;
+        });
+    }
+    const uint32_t w = wave_uniform(tid >> 6), lane = tid & 63, l5 = lane >> 5, l4 = (lane >> 4) & 1;
+    // per-lane twiddles of the two exchange stages, requested before the barrier
+    u64x2 tw7[8], tw8[8];
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) tw7[e] = twr[128 + (w << 4) + (l5 << 3) + e];   // 2^7 + (bits 12..6)
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {   // c = (f3 f1 f0): 2^8 + (bits 12..5), bit 5 = f3
+        const uint32_t f3 = c >> 2, f10 = c & 3;
+        tw8[c] = twr[256 + (w << 5) + (l5 << 4) + (l4 << 3) + (f10 << 1) + f3];
+    }
+    __syncthreads();
+    // ---- pass 2: stages 3-8 in registers and across lanes
+    u64 x[16];
+    {
+        const u64 *g = lds + padi((w << 10) + lane);
+#pragma unroll
+        for (uint32_t e = 0; e < 16; e++) x[e] = g[padi(e << 6)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {   // stages 3..6: register bits 3..0 = position bits 9..6
+        const uint32_t half = 16u >> (u + 1);
+#pragma unroll
+        for (uint32_t blk = 0; blk < (1u << u); blk++) {
+            const u64x2 wv = twr[(8u << u) + (w << u) + blk];   // 2^(3+u) + (position >> (10 - u)): wave-uniform
+#pragma unroll
+            for (uint32_t j = 0; j < half; j++) bfly(x[blk * 2 * half + j], x[blk * 2 * half + j + half], wv, 3 + u);
+        }
+    }
+    // stage 7 (position bit 5 = lane bit 5): register bit 3 <-> lane bit 5
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) lane_swap64(x[e], x[e + 8], tid, 5);
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) bfly(x[e], x[e + 8], tw7[e], 7);
+    // stage 8 (position bit 4 = lane bit 4): register bit 2 <-> lane bit 4
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        const uint32_t f = ((c >> 2) << 3) | (c & 3);   // register index with bit 2 clear
+        lane_swap64(x[f], x[f + 4], tid, 4);
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        const uint32_t f = ((c >> 2) << 3) | (c & 3);
+        bfly(x[f], x[f + 4], tw8[c], 8);
+    }
+    // registers (f3 f2 f1 f0) = position bits (5 4 7 6); lanes (l5 l4 l3..l0) = bits (9 8 3..0)
+    {
+        const uint32_t base = (w << 10) + (l5 << 9) + (l4 << 8) + (lane & 15);
+#pragma unroll
+        for (uint32_t f = 0; f < 16; f++) {
+            const uint32_t pos = base + ((f & 3) << 6) + ((f >> 3) << 5) + (((f >> 2) & 1) << 4);
+            wave_block_check<4>(0, tid, pos);
+            lds[padi(pos)] = x[f];
+        }
+    }
+    // ---- pass 3: stages 9-12, 16 consecutive coefficients per thread (wave-local exchange before it)
+    FwdTw<4, LOGM, 9, T> tw3;
+    fwd_tw_load(tw3, twr, 1, tid);
+    wave_sync();
+    fwd_pass<4, LOGM, 9, T, true, NB, NoSrc, 1, true>(lds, twr, 1, pm, tid, tw3);
+    __syncthreads();
+    if constexpr (NARROW) {  // < 16p -> canonical
+        const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
+        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) {
+            return csub_n(csub_n(csub_n(csub_n(v, p8, np8), p4, np4), p2, pm.np2), p, pm.np);
+        });
+    } else {
+        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(csub_n(v, p2, pm.np2), p, pm.np); });
+    }
+}
+
 // ------------------------------------------------ fused tensor + inverse NTT ----
 // The tensor step of Multiplicator::multiply (F/bfv/ops/mul.rs:198-201) fused into the loader of
 // the inverse NTT that Scaler::scale applies next (M/rq/scaler.rs:69-79): the products

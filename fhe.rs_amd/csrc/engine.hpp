@@ -893,19 +893,30 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     // key moduli below 2^60: the transform runs without most conditional subtractions (fwd_butterfly_narrow)
     bool narrow = !debug_flag("FHE_NO_NARROW");
     for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
-    if (narrow) {
-        allow_big_lds((k::ks_fused_kernel<LOGN, true>), lds);
-        FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, true>), dim3((unsigned)(npolys * kc.L)),
-                   dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,
-                   k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
-                   k_.digit_arg(), xhat, xhat_stride);
-        return;
+    // N = 16384: radix-4 passes (no spills) unless FHE_KS14_RADIX8=1 (ks_fused_kernel's GM)
+    static const bool radix8_14 = std::getenv("FHE_KS14_RADIX8") != nullptr && std::atoi(std::getenv("FHE_KS14_RADIX8")) != 0;
+#define FHE_KS_LAUNCH(NW, GMV)                                                                                        \
+    allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV>), lds);                                                          \
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV>), dim3((unsigned)(npolys * kc.L)),              \
+               dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,       \
+               k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,               \
+               k_.digit_arg(), xhat, xhat_stride)
+    if constexpr (LOGN == 14) {
+        if (!radix8_14) {
+            if (narrow) {
+                FHE_KS_LAUNCH(true, 2);
+            } else {
+                FHE_KS_LAUNCH(false, 2);
+            }
+            return;
+        }
     }
-    allow_big_lds((k::ks_fused_kernel<LOGN, false>), lds);
-    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, false>), dim3((unsigned)(npolys * kc.L)),
-               dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,
-               k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
-               k_.digit_arg(), xhat, xhat_stride);
+    if (narrow) {
+        FHE_KS_LAUNCH(true, k::KS_GMAX);
+    } else {
+        FHE_KS_LAUNCH(false, k::KS_GMAX);
+    }
+#undef FHE_KS_LAUNCH
 }
 
 // KeySwitchingKey::key_switch (:241-320): p [npolys][L][N] PowerBasis (poly stride p_stride) ->

@@ -951,7 +951,7 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
 // F/bfv/ops/mul.rs:224-225; rotation adds substitute(c0) to c0 only); canonical outputs.
 // ks_threads_c(LOGN) threads; thread t owns the 16-byte chunks {c*T + t}, c < CH (or the single
 // coefficient t when the row is smaller than one chunk per thread).
-template <int LOGN, bool NARROW = false>
+template <int LOGN, bool NARROW = false, int GM = KS_GMAX>
 __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
                     u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
@@ -964,6 +964,9 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     constexpr int N = 1 << LOGN;
     constexpr int CH = tile_chunks_c(LOGN, T);
     constexpr int NE = CH > 0 ? 2 * CH : 1;  // coefficients owned by a thread
+    // GM: radix (log2) of the LDS passes.  8 everywhere but N = 16384, whose 1024 threads hold both accumulator sets in
+    // registers (64 VGPRs): beside a radix-8 pass that spills 24 VGPRs (100 B of scratch per lane, 5 GB of extra HBM
+    // traffic per 512-polynomial launch, PMC); radix-4 passes fit (124 VGPRs) at the price of two more LDS exchanges.
     const uint32_t tid0 = threadIdx.x;
     // (an XCD-aware order that puts the lk workgroups of one polynomial on one L2, as tensor_intt_kernel
     // does, was measured: no change -- this kernel is nowhere near the HBM limit)
@@ -1082,7 +1085,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
             // transform, so their L2 latency is spent waiting for the other waves, not after them
             constexpr bool KPF = PREFETCH && CH >= 2;
             // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
-            ntt_fwd_lds<LOGN, T, KS_GMAX, false, !KPF, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
+            ntt_fwd_lds<LOGN, T, GM, false, !KPF, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
             u64x2 kq[KPF ? 8 : 1];
             if constexpr (KPF) {
 #pragma unroll
@@ -1116,7 +1119,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                 if (c & 1) sched_fence();  // at most two chunks of key loads (32 VGPRs) in flight
             }
         } else {
-            ntt_fwd_lds<LOGN, T, KS_GMAX, false, true, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
+            ntt_fwd_lds<LOGN, T, GM, false, true, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
             if (tid < N) {
             const u64 v = lds[padi(tid)];
             acc0[0] = csub_n(acc0[0] + mul_shoup_lazy_n(v, k0[koff + tid], k0s[koff + tid], pm.np), p2, pm.np2);

@@ -119,23 +119,45 @@ FHE_HD void fwd_butterfly(u64 &x, u64 &y, u64 w, u64 ws, const PM &m) {
 // needed every stage.  With every value below b*p before a stage, both outputs are below (b+2)*p
 // (t < 2p whatever y is); fwd_narrow_bound() tracks b over the stages of a transform whose input is
 // below b0*p (1: canonical) and says where the one strong correction (x < 16p -> x < 4p) has to sit.
+//
+// FHE_APPROX_SHOUP (default on): the headroom also pays for a cheaper quotient.  floor(y * ws / 2^64) is formed
+// from three of its four 32 x 32 partial products (y0 * ws0 only feeds a carry): the estimate is the true quotient
+// or one less, so t = y*w - q'*p is below 3p instead of 2p -- one multiply and its register shuffling less per
+// butterfly -- and every stage grows the bound by 3p: outputs x + t and x + 3p - t are below (b + 3) p.
+#ifndef FHE_APPROX_SHOUP
+#define FHE_APPROX_SHOUP 1
+#endif
+constexpr int FWD_NARROW_STEP = FHE_APPROX_SHOUP ? 3 : 2;
 constexpr int fwd_narrow_bound(int stage, int b0 = 1) {  // b before `stage`, b0 before stage 0
     int b = b0;
-    for (int s = 0; s < stage; s++) b = (b > 14 ? 4 : b) + 2;
+    for (int s = 0; s < stage; s++) b = (b > 16 - FWD_NARROW_STEP ? 4 : b) + FWD_NARROW_STEP;
     return b;
 }
-constexpr bool fwd_narrow_corrects(int stage, int b0 = 1) { return fwd_narrow_bound(stage, b0) > 14; }
+constexpr bool fwd_narrow_corrects(int stage, int b0 = 1) { return fwd_narrow_bound(stage, b0) > 16 - FWD_NARROW_STEP; }
+// floor(a * s / 2^64) or one less: the partial product a0 * s0 is left out (it contributes at most a carry of 1)
+FHE_HD u64 mulhi64_approx(u64 a, u64 s) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+    const u64 m = (u64)a0 * s1;
+    const u64 m2 = (u64)a1 * s0 + (uint32_t)m;
+    return (u64)a1 * s1 + (m >> 32) + (m2 >> 32);
+}
 FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, bool correct) {
     if (correct) {  // x < 16p -> < 4p
         const u64 p4 = m.p2 << 1, p8 = m.p2 << 2, np4 = m.np2 << 1, np8 = m.np2 << 2;
         x = csub_n(x, p8, np8);
         x = csub_n(x, p4, np4);
     }
+#if FHE_APPROX_SHOUP
+    const u64 t = y * w + mulhi64_approx(y, ws) * m.np;   // below 3p
+    const u64 pk = m.p2 + m.p;
+#else
     const u64 t = mul_shoup_lazy_n(y, w, ws, m.np);
-#if defined(FHE_HOST_EMULATION)
-    if (x > ~0ull - m.p2 || x + m.p2 < t) __builtin_trap();  // range tracking broken
+    const u64 pk = m.p2;
 #endif
-    y = x + m.p2 - t;
+#if defined(FHE_HOST_EMULATION)
+    if (t >= pk || x > ~0ull - pk) __builtin_trap();  // range tracking broken
+#endif
+    y = x + pk - t;
     x = x + t;
 }
 FHE_HD void inv_butterfly(u64 &x, u64 &y, u64 z, u64 zs, const PM &m) {

@@ -1622,11 +1622,11 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
 #pragma unroll
     for (int i = 0; i < NF; i++) rests[i] = (uint32_t)i < s.nfrom ? src[(u64)i * n] : 0;
 
-    Cols256 vc;
+    Cols5 vc;
 #pragma unroll
     for (int i = 0; i < NF; i++)
-        if ((uint32_t)i < s.nfrom) cols_mac_64x128(vc, rests[i], s.theta_garner_lo[i], s.theta_garner_hi[i]);
-    const U256 sum = cols_resolve(vc);
+        if ((uint32_t)i < s.nfrom) cols5_mac_64x128(vc, rests[i], s.theta_garner_lo[i], s.theta_garner_hi[i]);
+    const U256 sum = cols_resolve(cols5_to_cols256(vc));
     u64 vlo, vhi;
     u256_shr_lo128(sum, s.shift - 1, vlo, vhi);
     {  // v = div_ceil(v, 2)
@@ -1641,7 +1641,7 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
     if (!s.is_one) {
         // t = sum_i +/- r_i * theta_omega_i  -/+  v * theta_gamma  (mod 2^256, scaler.rs:278-301): the
         // terms added and the terms subtracted are summed separately, one wrapping subtraction at the end
-        Cols256 pos, neg;
+        Cols5 pos5, neg5;
 #pragma unroll
         for (int i = 0; i < NF; i++)
             if ((uint32_t)i < s.nfrom) {
@@ -1650,18 +1650,20 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
                 const u64 tlo = s.theta_omega_lo[i], thi = s.theta_omega_hi[i];
                 if ((tlo | thi) == 0) continue;
                 if (s.theta_omega_sign[i])
-                    cols_mac_64x128(neg, rests[i], tlo, thi);
+                    cols5_mac_64x128(neg5, rests[i], tlo, thi);
                 else
-                    cols_mac_64x128(pos, rests[i], tlo, thi);
+                    cols5_mac_64x128(pos5, rests[i], tlo, thi);
             }
         // v * theta_gamma (128 x 128 -> 256 wrapping): low word of v, then (high word) << 64
-        if (s.theta_gamma_sign) {
-            cols_mac_64x128(pos, vlo, s.theta_gamma_lo, s.theta_gamma_hi);
+        if (s.theta_gamma_sign)
+            cols5_mac_64x128(pos5, vlo, s.theta_gamma_lo, s.theta_gamma_hi);
+        else
+            cols5_mac_64x128(neg5, vlo, s.theta_gamma_lo, s.theta_gamma_hi);
+        Cols256 pos = cols5_to_cols256(pos5), neg = cols5_to_cols256(neg5);
+        if (s.theta_gamma_sign)
             cols_mac_64x128_shl64(pos, vhi, s.theta_gamma_lo, s.theta_gamma_hi);
-        } else {
-            cols_mac_64x128(neg, vlo, s.theta_gamma_lo, s.theta_gamma_hi);
+        else
             cols_mac_64x128_shl64(neg, vhi, s.theta_gamma_lo, s.theta_gamma_hi);
-        }
         const U256 t = u256_sub(cols_resolve(pos), cols_resolve(neg));
         w_sign = u256_ge_2_191(t);
         if (w_sign) {

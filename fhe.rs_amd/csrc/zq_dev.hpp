@@ -222,6 +222,65 @@ FHE_HD U256 cols_resolve(const Cols256 &c) {
     const u128_t m3 = c.c3 + (m2 >> 64);  // bits >= 2^256 fall off: U256 arithmetic wraps
     return U256{(u128_t)(u64)c.c0 | (m1 << 64), (u128_t)(u64)m2 | (m3 << 64)};
 }
+// The same sums on the device with the carry handling of the multiplier itself: the eight 32 x 32 partial products
+// of r * (lo | hi << 64) go straight into five 64-bit column accumulators (weights 2^0, 2^32, ..., 2^128) THROUGH
+// v_mad_u64_u32's addend, and each accumulator's carry-out is banked in a 32-bit counter by one v_addc -- 17
+// instructions per term, against ~35 (plus wait states) for the u128 formulation above, whose zero-extending adds the
+// compiler expands into add/addc chains and register moves.  The hazard recognizer does not see inside asm: a
+// VALU-written SGPR needs two wait states before a VALU reads it as carry-in; the instruction order provides them
+// (one s_nop before the last addc).  Exact: value = sum_k (c_k + o_k 2^64) 2^(32 k).
+struct Cols5 {
+    u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+};
+FHE_HD void cols5_mac_64x128(Cols5 &a, u64 r, u64 lo, u64 hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t r0 = (uint32_t)r, r1 = (uint32_t)(r >> 32);
+    const uint32_t t0 = (uint32_t)lo, t1 = (uint32_t)(lo >> 32), t2 = (uint32_t)hi, t3 = (uint32_t)(hi >> 32);
+    u64 sa, sb, sc;  // carry-outs (SGPR pairs)
+    asm("v_mad_u64_u32 %[c0], %[sa], %[r0], %[t0], %[c0]\n\t"
+        "v_mad_u64_u32 %[c1], %[sb], %[r0], %[t1], %[c1]\n\t"
+        "v_mad_u64_u32 %[c2], %[sc], %[r0], %[t2], %[c2]\n\t"
+        "v_addc_co_u32 %[o0], vcc, 0, %[o0], %[sa]\n\t"
+        "v_mad_u64_u32 %[c1], %[sa], %[r1], %[t0], %[c1]\n\t"
+        "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[sb]\n\t"
+        "v_addc_co_u32 %[o2], vcc, 0, %[o2], %[sc]\n\t"
+        "v_mad_u64_u32 %[c3], %[sb], %[r0], %[t3], %[c3]\n\t"
+        "v_mad_u64_u32 %[c2], %[sc], %[r1], %[t1], %[c2]\n\t"
+        "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[sa]\n\t"
+        "v_mad_u64_u32 %[c3], %[sa], %[r1], %[t2], %[c3]\n\t"
+        "v_addc_co_u32 %[o3], vcc, 0, %[o3], %[sb]\n\t"
+        "v_addc_co_u32 %[o2], vcc, 0, %[o2], %[sc]\n\t"
+        "v_mad_u64_u32 %[c4], %[sb], %[r1], %[t3], %[c4]\n\t"
+        "v_addc_co_u32 %[o3], vcc, 0, %[o3], %[sa]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 %[o4], vcc, 0, %[o4], %[sb]"
+        : [c0] "+v"(a.c0), [c1] "+v"(a.c1), [c2] "+v"(a.c2), [c3] "+v"(a.c3), [c4] "+v"(a.c4), [o0] "+v"(a.o0),
+          [o1] "+v"(a.o1), [o2] "+v"(a.o2), [o3] "+v"(a.o3), [o4] "+v"(a.o4), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc)
+        : [r0] "v"(r0), [r1] "v"(r1), [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [t3] "v"(t3)
+        : "vcc");
+#else  // host pass / host emulation: the same columns in plain C
+    const u64 rr[2] = {(uint32_t)r, r >> 32}, tt[4] = {(uint32_t)lo, lo >> 32, (uint32_t)hi, hi >> 32};
+    u64 *const cs[5] = {&a.c0, &a.c1, &a.c2, &a.c3, &a.c4};
+    uint32_t *const os[5] = {&a.o0, &a.o1, &a.o2, &a.o3, &a.o4};
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 4; j++) {
+            const u64 t = *cs[i + j] + rr[i] * tt[j];
+            *os[i + j] += t < *cs[i + j];
+            *cs[i + j] = t;
+        }
+#endif
+}
+// -> the 64-bit columns of Cols256 (weights 2^0, 2^64, 2^128, 2^192; each sum stays far below 2^128)
+FHE_HD Cols256 cols5_to_cols256(const Cols5 &a) {
+    Cols256 c;
+    const u64 M32 = 0xffffffffull;
+    c.c0 = (u128_t)a.c0 + ((a.c1 & M32) << 32);
+    c.c1 = (u128_t)(a.c1 >> 32) + a.c2 + ((a.c3 & M32) << 32) + a.o0 + ((u64)a.o1 << 32);
+    c.c2 = (u128_t)(a.c3 >> 32) + a.c4 + a.o2 + ((u64)a.o3 << 32);
+    c.c3 = a.o4;
+    return c;
+}
 FHE_HD U256 u256_sub(const U256 &a, const U256 &b) {  // wrapping
     U256 r;
     const bool borrow = __builtin_sub_overflow(a.lo, b.lo, &r.lo);

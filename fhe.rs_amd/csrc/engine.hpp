@@ -626,6 +626,11 @@ struct Scaler {
     k::ScalerDev dev{};
 };
 
+// NF of the scale_kernel<NF> instance for `nfrom` source moduli (the column's residues live in registers)
+inline size_t scale_kernel_nf(size_t nfrom) {
+    return nfrom <= 4 ? 4 : nfrom <= 9 ? 9 : nfrom <= 17 ? 17 : nfrom <= 33 ? 33 : 64;
+}
+
 inline void scaler_upload(Scaler &s) {
     const ScalerConstants &c = s.c;
     if (s.from->device < 0) return;
@@ -669,11 +674,22 @@ inline void scaler_upload(Scaler &s) {
             }
         }
     }
+    // per-source tables zero-padded to the NF of the scale_kernel instance that serves this scaler (launch_scale):
+    // the kernel's term loops then need no bounds checks
+    const size_t nf = scale_kernel_nf(c.nfrom);
+    auto padded = [&](const std::vector<u64> &v) {
+        std::vector<u64> r(v);
+        r.resize(nf, 0);
+        return r;
+    };
+    std::vector<u64> omega_p(c.nto * nf, 0);
+    for (size_t j = 0; j < c.nto; j++)
+        std::copy(c.omega.begin() + j * c.nfrom, c.omega.begin() + (j + 1) * c.nfrom, omega_p.begin() + j * nf);
     std::vector<u64> sign64(c.theta_omega_sign.begin(), c.theta_omega_sign.end());
     size_t o_fold = push(fold);
-    size_t o_gn = push(gneg), o_om = push(c.omega), o_vt = push(vtab), o_c64 = push(c64), o_c128 = push(c128);
-    size_t o_tol = push(c.theta_omega_lo), o_toh = push(c.theta_omega_hi), o_tos = push(sign64);
-    size_t o_tgl = push(c.theta_garner_lo), o_tgh = push(c.theta_garner_hi);
+    size_t o_gn = push(gneg), o_om = push(omega_p), o_vt = push(vtab), o_c64 = push(c64), o_c128 = push(c128);
+    size_t o_tol = push(padded(c.theta_omega_lo)), o_toh = push(padded(c.theta_omega_hi)), o_tos = push(padded(sign64));
+    size_t o_tgl = push(padded(c.theta_garner_lo)), o_tgh = push(padded(c.theta_garner_hi));
     s.d_all.upload(all);
     u64 *b = s.d_all.p;
     s.dev.gamma_neg = b + o_gn;
@@ -744,12 +760,15 @@ inline void launch_scale(const Scaler &sc, const u64 *in, u64 in_stride, u64 *ou
 #define FHE_SCALE_CASE(NF)                                                                                   \
     FHE_LAUNCH(label, (k::scale_kernel<NF>), grid, block, 0, s, in, out, in_stride, out_stride, sc.dev,      \
                t.dmods(), (uint32_t)f.logn, total)
-    if (f.L <= 4) FHE_SCALE_CASE(4);
-    else if (f.L <= 9) FHE_SCALE_CASE(9);
-    else if (f.L <= 17) FHE_SCALE_CASE(17);
-    else if (f.L <= 33) FHE_SCALE_CASE(33);
-    else if (f.L <= 64) FHE_SCALE_CASE(64);
-    else throw StatusError(E_ARG, "RNS scaler supports at most 64 source moduli");
+    switch (scale_kernel_nf(f.L)) {   // (the same NF scaler_upload padded the tables to)
+        case 4: FHE_SCALE_CASE(4); break;
+        case 9: FHE_SCALE_CASE(9); break;
+        case 17: FHE_SCALE_CASE(17); break;
+        case 33: FHE_SCALE_CASE(33); break;
+        default:
+            require(f.L <= 64, E_ARG, "RNS scaler supports at most 64 source moduli");
+            FHE_SCALE_CASE(64);
+    }
 #undef FHE_SCALE_CASE
 }
 

@@ -1537,6 +1537,8 @@ struct Acc3x64 {
     u64 c0 = 0, c1 = 0, c2 = 0;
     uint32_t o0 = 0, o1 = 0, o2 = 0;
 };
+// x: per-lane value; y: WAVE-UNIFORM constant (scaler tables): its halves are SGPR operands of the multiplies
+// (one constant-bus read per instruction), which saves the two copies into VGPRs a "v" constraint costs per term.
 FHE_HD void mac3x64(Acc3x64 &a, u64 x, u64 y) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
@@ -1551,7 +1553,7 @@ FHE_HD void mac3x64(Acc3x64 &a, u64 x, u64 y) {
         "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[s0]"
         : [c0] "+v"(a.c0), [c1] "+v"(a.c1), [c2] "+v"(a.c2), [o0] "+v"(a.o0), [o1] "+v"(a.o1), [o2] "+v"(a.o2),
           [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
-        : [xl] "v"(xl), [xh] "v"(xh), [yl] "v"(yl), [yh] "v"(yh)
+        : [xl] "v"(xl), [xh] "v"(xh), [yl] "s"(yl), [yh] "s"(yh)   // y: the wave-uniform constant, straight from SGPRs
         : "vcc");
 #else  // host pass / host emulation: the same columns in plain C
     const u64 xl = (uint32_t)x, xh = x >> 32, yl = (uint32_t)y, yh = y >> 32;
@@ -1622,10 +1624,12 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
 #pragma unroll
     for (int i = 0; i < NF; i++) rests[i] = (uint32_t)i < s.nfrom ? src[(u64)i * n] : 0;
 
+    // (all per-source tables are zero-padded to NF entries by the host, scaler_upload: the term loops run without
+    // per-term bounds checks -- a padded term multiplies a zero residue by a zero constant -- so the constants of
+    // a sum are fetched together, one scalar wait per sum instead of one per term)
     Cols5 vc;
 #pragma unroll
-    for (int i = 0; i < NF; i++)
-        if ((uint32_t)i < s.nfrom) cols5_mac_64x128(vc, rests[i], s.theta_garner_lo[i], s.theta_garner_hi[i]);
+    for (int i = 0; i < NF; i++) cols5_mac_64x128(vc, rests[i], s.theta_garner_lo[i], s.theta_garner_hi[i]);
     const U256 sum = cols_resolve(cols5_to_cols256(vc));
     u64 vlo, vhi;
     u256_shr_lo128(sum, s.shift - 1, vlo, vhi);
@@ -1643,8 +1647,7 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
         // terms added and the terms subtracted are summed separately, one wrapping subtraction at the end
         Cols5 pos5, neg5;
 #pragma unroll
-        for (int i = 0; i < NF; i++)
-            if ((uint32_t)i < s.nfrom) {
+        for (int i = 0; i < NF; i++) {
                 // theta_omega_i = 0 whenever the scaled Garner coefficient is an integer -- e.g. every
                 // source modulus outside the denominator when scaling Q*P -> Q by t/Q (5 of C2's 9)
                 const u64 tlo = s.theta_omega_lo[i], thi = s.theta_omega_hi[i];
@@ -1685,7 +1688,7 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
     u64 *o = out + poly * out_poly_stride + col;
     for (uint32_t jt = s.ncommon; jt < s.nto; jt++) {
         const DevMod q = to_mods[jt];
-        const u64 *om = s.omega + (u64)jt * s.nfrom;
+        const u64 *om = s.omega + (u64)jt * NF;   // rows zero-padded to NF
         Acc3x64 a192;
         u128_t extra = 0;                                      // small addends of the sum (< 2^66)
         mac3x64(a192, vlo, s.gamma_neg[jt]);                   // -v_lo * gamma
@@ -1699,8 +1702,7 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
             extra = w_sign ? ((((u128_t)1 << 64) | k_lo) - wlo) : (u128_t)wlo;
         }
 #pragma unroll
-        for (int i = 0; i < NF; i++)
-            if ((uint32_t)i < s.nfrom) mac3x64(a192, rests[i], om[i]);
+        for (int i = 0; i < NF; i++) mac3x64(a192, rests[i], om[i]);
         extra += small;
         // (extra < 2^66 does not fit the u64 parameter: split it)
         u128_t acc;

@@ -233,6 +233,7 @@ struct Cols5 {
     u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
     uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
 };
+// r: per-lane; (lo, hi): a WAVE-UNIFORM constant (SGPR operands, one constant-bus read per multiply).
 FHE_HD void cols5_mac_64x128(Cols5 &a, u64 r, u64 lo, u64 hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t r0 = (uint32_t)r, r1 = (uint32_t)(r >> 32);
@@ -257,7 +258,7 @@ FHE_HD void cols5_mac_64x128(Cols5 &a, u64 r, u64 lo, u64 hi) {
         "v_addc_co_u32 %[o4], vcc, 0, %[o4], %[sb]"
         : [c0] "+v"(a.c0), [c1] "+v"(a.c1), [c2] "+v"(a.c2), [c3] "+v"(a.c3), [c4] "+v"(a.c4), [o0] "+v"(a.o0),
           [o1] "+v"(a.o1), [o2] "+v"(a.o2), [o3] "+v"(a.o3), [o4] "+v"(a.o4), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc)
-        : [r0] "v"(r0), [r1] "v"(r1), [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [t3] "v"(t3)
+        : [r0] "v"(r0), [r1] "v"(r1), [t0] "s"(t0), [t1] "s"(t1), [t2] "s"(t2), [t3] "s"(t3)   // (lo, hi): wave-uniform
         : "vcc");
 #else  // host pass / host emulation: the same columns in plain C
     const u64 rr[2] = {(uint32_t)r, r >> 32}, tt[4] = {(uint32_t)lo, lo >> 32, (uint32_t)hi, hi >> 32};

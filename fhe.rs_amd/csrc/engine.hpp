@@ -719,6 +719,14 @@ inline void scaler_upload(Scaler &s) {
             if (bound < BigUint::pow2(2 * k + 1)) s.dev.narrow_mask |= (u64)1 << j;
         }
     }
+    // for a factor-one scaler v <= sum_i r_i + 2 (see narrow_mask above); when sum_i (q_i - 1) + 2 is below 2^64 the
+    // kernel never needs v's high word
+    s.dev.v_fits_64 = 0;
+    if (c.is_one) {
+        BigUint sum_q(2);
+        for (size_t i = 0; i < c.nfrom; i++) sum_q = sum_q + BigUint(s.from->moduli[i] - 1);
+        if (sum_q < BigUint::pow2(64)) s.dev.v_fits_64 = 1;
+    }
     s.dev.fold_mask = fold_mask;
     s.dev.fold_tab = b + o_fold;
     s.dev.theta_gamma_sign = c.theta_gamma_sign ? 1 : 0;

@@ -1524,6 +1524,7 @@ struct ScalerDev {
     u64 fold_mask;    // bit j: it stays below 2^(2k_j+6): bits >= 2^(2k_j) are folded through fold_tab first
     const u64 *fold_tab;                                 // [nto][64]  i * 2^(2k_j) mod q_j
     uint32_t theta_gamma_sign, is_one, shift, nfrom, nto, ncommon;
+    uint32_t v_fits_64;  // v < 2^64 for every input (factor-one scalers over few moduli): no v_hi term
 };
 
 // Sum of 64x64-bit products on the device: the four 32x32 partial products of a term go straight
@@ -1692,7 +1693,9 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
         Acc3x64 a192;
         u128_t extra = 0;                                      // small addends of the sum (< 2^66)
         mac3x64(a192, vlo, s.gamma_neg[jt]);                   // -v_lo * gamma
-        u64 small = s.vhi_tab[jt * 16 + vh];                   // -v_hi * 2^64 * gamma   (< q)
+        // -v_hi * 2^64 * gamma (< q) through a 16-entry table -- a per-lane load, skipped when the host-side bound
+        // on v (scaler_upload: v <= sum_i (q_i - 1) + 1) says v_hi is always zero
+        u64 small = s.v_fits_64 ? 0 : s.vhi_tab[jt * 16 + vh];
         if (!s.is_one) {
             // +/- w = +/- (w_hi * 2^64 + w_lo): the high part through the table, the low word straight
             // into the 192-bit sum -- as w_lo, or as K - w_lo with K = q * ceil(2^64 / q) = 2^64 + K_lo = 0 (mod q)

@@ -67,6 +67,8 @@ def main():
         if fb is not None and wb is not None:
             traffic[lab] = int(fb + wb)
     json.dump(out, open(os.path.join(prof, f"{rnd}_pmc_hbm.json"), "w"), indent=1)
+    traffic["_source"] = (f"profiles/{rnd}_pmc_hbm.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, "
+                          "separate passes over `bench.py --steps 5 --no-cpu --no-extras`, bytes per launch")
     json.dump(traffic, open(os.path.join(prof, "roofline_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -36,6 +36,28 @@ struct u64x2 {
     u64 x, y;
 };
 
+// Phase timing of one wave (diagnostic builds only: -DFHE_PHASE_TIMING; tools/ks_phase_timing.py).  Thread 0 of
+// workgroup FHE_TS_BLOCK adds the shader-clock time since its previous stamp to slot `k`.
+#if defined(FHE_PHASE_TIMING) && !defined(FHE_HOST_EMULATION)
+__device__ unsigned long long g_phase_ts[64];
+__device__ unsigned long long g_phase_last;
+#endif
+#if defined(FHE_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#ifndef FHE_TS_BLOCK
+#define FHE_TS_BLOCK 777
+#endif
+#define FHE_TS(k)                                                           \
+    do {                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x == FHE_TS_BLOCK) {               \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+            g_phase_ts[(k)] += now_ - g_phase_last;                         \
+            g_phase_last = now_;                                            \
+        }                                                                   \
+    } while (0)
+#else
+#define FHE_TS(k) do { } while (0)
+#endif
+
 // Maps a workgroup index to (polynomial, row) and to source/destination addresses.
 // block b -> poly = b / rows, r = row_begin + b % rows;
 //   src = in  + poly*src_poly_stride + (src_row_fixed >= 0 ? src_row_fixed : r) * N
@@ -304,6 +326,7 @@ __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restric
         fwd_pass<G, LOGM, S0, T, TWPF, NARROW, Src, NT, WLX>(lds, tw, kbase, pm, tid, tw_regs, src, tile_words);   // (Src != NoSrc: reads `src`, not LDS)
     else
         fwd_pass<G, LOGM, S0, T, TWPF, NARROW, NoSrc, NT, WLX>(lds, tw, kbase, pm, tid, tw_regs, NoSrc{}, tile_words);
+    FHE_TS(8 + 2 * PASS);
     if constexpr (PASS + 1 < plan_np(LOGM, GM)) {
         constexpr int GN = fwd_plan_g<LOGM, GM, PASS + 1, LATE>();
         FwdTw<GN, LOGM, S0 + G, T> next;
@@ -314,6 +337,7 @@ __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restric
             wave_sync();
         else
             __syncthreads();
+        FHE_TS(9 + 2 * PASS);
         ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, PASS + 1, S0 + G, LATE, NT>(lds, tw, kbase, pm, tid, next, NoSrc{},
                                                                                       tile_words);
     } else {
@@ -1055,6 +1079,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
         const uint32_t i = digit_of(ii);
         const uint32_t tid = opaque(tid0);
         const uint32_t sh = i * digit_shift_bits;
+        FHE_TS(0);
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int c = 0; c < CH; c++) {
@@ -1069,7 +1094,9 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
             const u64 mask_i = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
             tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return lift((v >> sh) & mask_i); });
         }
+        FHE_TS(1);
         __syncthreads();
+        FHE_TS(2);
         if constexpr (PREFETCH) {
             if (ii + 1 < nloop) {
                 const u64x2 *nx = reinterpret_cast<const u64x2 *>(src0 + (u64)digit_of(ii + 1) * dstride);
@@ -1093,7 +1120,9 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                     const uint32_t ci = c * T + tid;
                     kq[4 * c] = a0[ci], kq[4 * c + 1] = a0s[ci], kq[4 * c + 2] = a1[ci], kq[4 * c + 3] = a1s[ci];
                 }
+                FHE_TS(3);
                 __syncthreads();
+                FHE_TS(4);
             }
 #pragma unroll
             for (int c = 0; c < CH; c++) {
@@ -1128,7 +1157,9 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
         }
         // (wave-contiguous chunk ownership, which makes this barrier and the one before the MAC wave-local as
         // well, was measured: nothing beyond what the late pass plan already gives)
+        FHE_TS(5);
         __syncthreads();
+        FHE_TS(6);
     }
     const uint32_t tid = opaque(tid0);  // keeps the epilogue's address arithmetic below the digit loop
     const u64 ooff = (u64)b * out_poly_stride + (u64)j * N;

@@ -1237,18 +1237,38 @@ inline AuxStream &aux_for(int device, hipStream_t user) {
     return a;
 }
 
-inline size_t default_chunk(const Ctx &base, const Ctx &mulc, size_t batch, size_t chunk_opt, size_t streams_opt) {
-    if (chunk_opt) return std::min(batch, chunk_opt);
-    // Every launch should cover >> 512 workgroup slots (small chunks lose to tail effects: 64 pairs per
-    // chunk is 15 % slower at C2), but beyond ~3 GiB of workspace nothing is gained and the step-to-step
-    // reuse in the 256 MiB Infinity Cache is lost (chunks of 256-512 pairs measured 1.5 % ahead of one
-    // 1024-pair chunk).  The batch is split into equal chunks under that budget.
+// How a batch is cut into chunks, and whether the chunks alternate between two streams.
+// One stream: every launch should cover >> 512 workgroup slots (64-pair chunks are 15 % slower at C2), but beyond
+// ~3 GiB of workspace nothing is gained and the step-to-step reuse in the 256 MiB Infinity Cache is lost (chunks of
+// 256-512 pairs measured 1.5 % ahead of one 1024-pair chunk): equal chunks under that budget.
+// Two streams: while one chunk's launch drains, the other chunk's kernels fill the idle workgroup slots, so small,
+// cache-friendly chunks pay: 384 MiB of workspace per chunk (64 pairs at C2: 168.1 k against 163.4-166.9 k ops/s
+// for 128-pair chunks, same box; 48 pairs 161.8-163.2 k), but at least 8 pairs (C5, 90 MiB per pair: chunks of 8-12
+// 4.46-4.51 k ops/s, chunks of 4 4.31-4.34 k).  Fewer than four such chunks do not overlap enough to pay for the
+// smaller launches (C5 at batch 16: 4.04 k in two chunks of 8, 4.14-4.20 k in one chunk): the batch then takes the
+// one-stream cut.  (profiles/r02_chunk_sweeps.txt)
+struct ChunkPlan {
+    size_t chunk;
+    bool dual;
+};
+inline ChunkPlan plan_chunks(const Ctx &base, const Ctx &mulc, size_t batch, size_t chunk_opt, size_t streams_opt) {
+    auto nchunks = [&](size_t c) { return (batch + c - 1) / c; };
+    if (chunk_opt) {
+        const size_t c = std::min(batch, chunk_opt);
+        return ChunkPlan{c, streams_opt >= 2 && nchunks(c) >= 2};
+    }
     const size_t per_ct = (7 * mulc.L + 7 * base.L) * mulc.n * sizeof(u64);
-    // two streams: 768 MiB per chunk (128 pairs at C2) measured best, see DESIGN.md section 6
-    const size_t budget = streams_opt >= 2 ? (size_t)768 << 20 : (size_t)3 << 30;
-    const size_t cap = std::max<size_t>(1, std::min<size_t>(budget / per_ct, 4096));
-    const size_t nchunks = (batch + cap - 1) / cap;
-    return (batch + nchunks - 1) / nchunks;
+    auto equal_chunks = [&](size_t budget, size_t min_pairs) {
+        const size_t cap = std::max<size_t>(min_pairs, std::min<size_t>(budget / per_ct, 4096));
+        const size_t nc = (batch + cap - 1) / cap;
+        return (batch + nc - 1) / nc;
+    };
+    if (streams_opt >= 2) {
+        const size_t c = equal_chunks((size_t)384 << 20, 8);
+        if (nchunks(c) >= 4) return ChunkPlan{c, true};
+    }
+    const size_t c = equal_chunks((size_t)3 << 30, 1);
+    return ChunkPlan{c, streams_opt >= 2 && nchunks(c) >= 2};
 }
 
 // Ciphertext::switch_down (F/bfv/ciphertext.rs:148-161): ct [b][nparts][L][N] Ntt -> [b][nparts][L-1][N] Ntt
@@ -1294,8 +1314,9 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     const u64 PL = (u64)L * N, PK = (u64)K * N;
     const size_t parts = m.out_parts();
     if (!batch) return;
-    const size_t streams_opt = m.streams.load(std::memory_order_relaxed);
-    const size_t chunk = default_chunk(b, e, batch, m.chunk.load(std::memory_order_relaxed), streams_opt);
+    const ChunkPlan plan = plan_chunks(b, e, batch, m.chunk.load(std::memory_order_relaxed),
+                                       m.streams.load(std::memory_order_relaxed));
+    const size_t chunk = plan.chunk;
     // the extenders copy the shared prefix rows verbatim; when both share all L rows the tensor
     // kernel reads those rows from the inputs directly and the copy is skipped
     const bool skip_copy = m.ext_lhs->ncommon == L && m.ext_rhs->ncommon == L && !debug_flag("FHE_NO_SKIP_COPY");
@@ -1306,8 +1327,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
               ten(chunk * 3 * PK * sizeof(u64), st), d(chunk * 3 * PL * sizeof(u64), st), pre(pre_bytes, st) {}
     };
     const size_t pre_bytes = m.mod_switch ? chunk * parts * PL * sizeof(u64) : 8;
-    const size_t nchunks = (batch + chunk - 1) / chunk;
-    const bool dual = streams_opt >= 2 && nchunks >= 2;
+    const bool dual = plan.dual;
     hipStream_t lanes[2] = {s0, s0};
     AuxStream *aux = nullptr;
     struct Join {  // the internal stream always rejoins the caller's, also on an error path

@@ -293,7 +293,8 @@ fhe_status fhe_mul_basis(const fhe_mul *m, size_t *count, uint64_t *moduli);
  * keep the values they started with.  (The reference's Multiplicator has no such state; these only choose how
  * the same values are computed.)
  *   chunk   ciphertext pairs per pipeline pass; 0 (default) = equal chunks under a workspace budget
- *           (3 GiB with one stream: 512 pairs at N = 8192, 4 moduli; 768 MiB with two: 128 pairs)
+ *           (3 GiB with one stream: 512 pairs at N = 8192, 4 moduli; 384 MiB but at least 8 pairs with two: 64
+ *           pairs -- used when the batch gives four or more such chunks, else the one-stream cut)
  *   streams 2 (default) = the chunks of a batch alternate between the caller's stream and an internal one,
  *           forked from and joined back into the caller's stream with events: stream-ordered for the caller
  *           exactly as with 1, capturable into a hipGraph, bit-identical results, +4.5 % at C2;

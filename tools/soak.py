@@ -40,5 +40,29 @@ def main():
     sys.exit(1 if bad else 0)
 
 
+def c3(reps):
+    """The same for config C3's shape: relinearise + rotation at N = 16384, 8 moduli (radix-4 key-switch passes, the
+    Ntt-form digit shortcut), 256 ciphertexts per call."""
+    n, L = 16384, 8
+    ctx = fhe.Context(fhe.generate_moduli([60] * L, n), n)
+    kk = ctx.synth_uniform(9, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, n)
+    ksk = fhe.KeySwitchingKey(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous())
+    rk, gk = fhe.RelinearizationKey(ksk), fhe.GaloisKey(ksk, 3)
+    ct3 = ctx.synth_uniform(9, 0, 0, 3, 256)
+    ct2 = ct3[:, :2].contiguous()
+    ref_r, ref_g = rk.relinearizes(ct3), gk.relinearize(ct2)
+    torch.cuda.synchronize()
+    bad, t0 = 0, time.time()
+    for _ in range(reps):
+        r, g = rk.relinearizes(ct3), gk.relinearize(ct2)
+        if not (torch.equal(r, ref_r) and torch.equal(g, ref_g)):
+            bad += 1
+    torch.cuda.synchronize()
+    print(json.dumps(dict(config="C3 shape", repetitions=reps, ops=reps * 512, mismatches=bad, seconds=round(time.time() - t0, 1))))
+    sys.exit(1 if bad else 0)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "c3":
+        c3(int(sys.argv[1]))
     main()

@@ -17,4 +17,4 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
   find $OUT/pass$i -name '*kernel_trace.csv' -delete
 done
 python $ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
-tail -5 $OUT/pass*.log | grep -i "error\|invalid" | head
+grep -il "error\|invalid" $OUT/pass*.log | head

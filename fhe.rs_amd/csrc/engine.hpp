@@ -920,8 +920,9 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     // key moduli below 2^60: the transform runs without most conditional subtractions (fwd_butterfly_narrow)
     bool narrow = !debug_flag("FHE_NO_NARROW");
     for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
-    // N = 16384: radix-4 passes (no spills) unless FHE_KS14_RADIX8=1 (ks_fused_kernel's GM)
-    static const bool radix8_14 = std::getenv("FHE_KS14_RADIX8") != nullptr && std::atoi(std::getenv("FHE_KS14_RADIX8")) != 0;
+    // N = 16384 (ks_fused_kernel's GM): FHE_KS14_PLAN = 8 radix-8 passes (24 VGPRs spilled), 4 radix-4 passes,
+    // unset / anything else: radix-8 while the twiddles are scalar, radix-4 after (GM_MIXED)
+    static const int plan14 = std::getenv("FHE_KS14_PLAN") ? std::atoi(std::getenv("FHE_KS14_PLAN")) : 0;
 #define FHE_KS_LAUNCH(NW, GMV)                                                                                        \
     allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV>), lds);                                                          \
     FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV>), dim3((unsigned)(npolys * kc.L)),              \
@@ -929,11 +930,19 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
                k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,               \
                k_.digit_arg(), xhat, xhat_stride)
     if constexpr (LOGN == 14) {   // (radix-4 passes at N = 8192 measured slower: 0.559 vs 0.532 ms per launch)
-        if (!radix8_14) {
+        if (plan14 == 4) {
             if (narrow) {
                 FHE_KS_LAUNCH(true, 2);
             } else {
                 FHE_KS_LAUNCH(false, 2);
+            }
+            return;
+        }
+        if (plan14 != 8) {
+            if (narrow) {
+                FHE_KS_LAUNCH(true, k::GM_MIXED);
+            } else {
+                FHE_KS_LAUNCH(false, k::GM_MIXED);
             }
             return;
         }

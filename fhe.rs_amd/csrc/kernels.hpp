@@ -297,17 +297,39 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
 // LATE = false: the wider passes come first (they run on scalar twiddles); LATE = true: last, so that the trailing
 // passes share one radix and their exchanges are wave-local (the key switch at N = 8192: 2+2+3+3+3, two workgroup
 // barriers per digit transform instead of four).
+// GM_MIXED: radix-8 passes as long as a pass's twiddles are wave-uniform (stage offset + 3 <= LOGM - 6: they come
+// through scalar registers and cost no VGPRs), radix-4 passes after that (3 per-lane twiddles instead of 7: 16
+// VGPRs less than a per-lane radix-8 pass) -- the key switch at N = 16384, whose two accumulator sets leave ~64 VGPRs.
+constexpr int GM_MIXED = 32;
+constexpr int mixed_plan_g(int logm, int pass) {   // stages of pass `pass` (0 beyond the last pass)
+    int s0 = 0;
+    for (int q = 0;; q++) {
+        if (s0 >= logm) return 0;
+        int g = (s0 + 3 <= logm - 6) ? 3 : 2;
+        if (g > logm - s0) g = logm - s0;
+        if (q == pass) return g;
+        s0 += g;
+    }
+}
+constexpr int mixed_plan_np(int logm) {
+    int n = 0;
+    while (mixed_plan_g(logm, n) > 0) n++;
+    return n;
+}
+constexpr int fwd_np(int logm, int gm) { return gm == GM_MIXED ? mixed_plan_np(logm) : plan_np(logm, gm); }
 template <int LOGM, int GM, int PASS, bool LATE = false>
 constexpr int fwd_plan_g() {
+    if (GM == GM_MIXED) return mixed_plan_g(LOGM, PASS);
     return plan_base(LOGM, GM) +
            ((LATE ? PASS >= plan_np(LOGM, GM) - plan_rem(LOGM, GM) : PASS < plan_rem(LOGM, GM)) ? 1 : 0);
 }
 constexpr int fwd_plan_g_c(int logm, int gm, int pass, bool late) {
+    if (gm == GM_MIXED) return mixed_plan_g(logm, pass);
     return plan_base(logm, gm) + ((late ? pass >= plan_np(logm, gm) - plan_rem(logm, gm) : pass < plan_rem(logm, gm)) ? 1 : 0);
 }
 // is the exchange between forward passes `pass` and `pass + 1` wave-local?
 constexpr bool fwd_wl_after(int logm, int gm, bool late, int pass) {
-    if (pass < 0 || pass + 1 >= plan_np(logm, gm)) return false;
+    if (pass < 0 || pass + 1 >= fwd_np(logm, gm)) return false;
     int s0 = 0;
     for (int q = 0; q < pass; q++) s0 += fwd_plan_g_c(logm, gm, q, late);
     const int g = fwd_plan_g_c(logm, gm, pass, late), gn = fwd_plan_g_c(logm, gm, pass + 1, late);
@@ -327,7 +349,7 @@ __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restric
     else
         fwd_pass<G, LOGM, S0, T, TWPF, NARROW, NoSrc, NT, WLX>(lds, tw, kbase, pm, tid, tw_regs, NoSrc{}, tile_words);
     FHE_TS(8 + 2 * PASS);
-    if constexpr (PASS + 1 < plan_np(LOGM, GM)) {
+    if constexpr (PASS + 1 < fwd_np(LOGM, GM)) {
         constexpr int GN = fwd_plan_g<LOGM, GM, PASS + 1, LATE>();
         FwdTw<GN, LOGM, S0 + G, T> next;
         if constexpr (TWPF) fwd_tw_load(next, tw, kbase, tid);   // in flight across the barrier
@@ -989,8 +1011,10 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     constexpr int CH = tile_chunks_c(LOGN, T);
     constexpr int NE = CH > 0 ? 2 * CH : 1;  // coefficients owned by a thread
     // GM: radix (log2) of the LDS passes.  8 everywhere but N = 16384, whose 1024 threads hold both accumulator sets in
-    // registers (64 VGPRs): beside a radix-8 pass that spills 24 VGPRs (100 B of scratch per lane, 5 GB of extra HBM
-    // traffic per 512-polynomial launch, PMC); radix-4 passes fit (124 VGPRs) at the price of two more LDS exchanges.
+    // registers (64 VGPRs): beside a per-lane-twiddle radix-8 pass that spills 24 VGPRs (100 B of scratch per lane,
+    // 5 GB of extra HBM traffic per 512-polynomial launch, PMC).  GM_MIXED keeps radix 8 for the passes whose
+    // twiddles are scalar and takes radix 4 for the rest (3+3+2+2+2+2 stages, 124 VGPRs, no scratch): C3 relinearise
+    // 99.2 k (radix 8) -> 110.5 k (radix 4 throughout) -> 111.7-112.9 k ops/s.
     const uint32_t tid0 = threadIdx.x;
     // (an XCD-aware order that puts the lk workgroups of one polynomial on one L2, as tensor_intt_kernel
     // does, was measured: no change -- this kernel is nowhere near the HBM limit)

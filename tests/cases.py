@@ -784,12 +784,22 @@ def case_errors(fhe):
     assert fhe.generate_prime(11, 16, 1033) is None
     assert fhe.supports_opt(4611686018326724609) and not fhe.supports_opt(1153)
     assert fhe.is_prime(1153) and not fhe.is_prime(1155)
-    # per-handle multiply options: only 1 or 2 streams; host-only handles refuse device work
+    assert code(lambda: c.random_from_seed(np.zeros((1, 32), dtype=np.uint8))) == -18
+
+
+def case_option_errors(fhe):
+    """Per-handle multiply options accept only 1 or 2 streams; a failing host table callback aborts the
+    parameter set (needs a device or the emulator: parameter sets always carry device tables)."""
+    def code(fn):
+        try:
+            fn()
+        except fhe.FheError as e:
+            return e.code
+        return 0
     opar, par = _params(fhe, 2, 16)
     m = fhe.Multiplicator.default(par, None, 0)
     assert m.options() == dict(chunk=0, streams=2)
     assert code(lambda: m.set_streams(3)) == -1 and code(lambda: m.set_streams(0)) == -1
     assert m.set_streams(1).set_chunk(7).options() == dict(chunk=7, streams=1)
-    assert code(lambda: c.random_from_seed(np.zeros((1, 32), dtype=np.uint8))) == -18
     # a host table callback that fails aborts the parameter set with NttOperatorUnavailable
     assert code(lambda: fhe.BfvParameters(16, opar.plaintext, moduli=opar.moduli, tables_fn=lambda q, n: 1 / 0)) == -5

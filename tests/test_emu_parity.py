@@ -180,6 +180,7 @@ def test_random_from_seed(fhe):
 
 def test_errors(fhe):
     cases.case_errors(fhe)
+    cases.case_option_errors(fhe)
 
 
 @pytest.mark.parametrize("n", [8192, 16384, 32768, 65536])

@@ -161,6 +161,7 @@ def test_random_from_seed(fhe, dev):
 
 def test_errors(fhe):
     cases.case_errors(fhe)
+    cases.case_option_errors(fhe)
 
 
 def test_empty_batch(fhe):

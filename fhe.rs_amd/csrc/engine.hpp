@@ -442,6 +442,23 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
                 }
                 return;
             }
+            static const int cpt8 = std::getenv("FHE_NTT_CPT8") ? std::atoi(std::getenv("FHE_NTT_CPT8")) : 0;
+            if (cpt8 && logn == 13) {   // measured alternative: 8 coefficients per thread, 8 waves per SIMD (kernels.hpp)
+                const size_t lds = k::lds_words(1u << 13) * sizeof(u64);
+#define FHE_NTT8(NW, GMV)                                                                                          \
+    do {                                                                                                           \
+        allow_big_lds((k::ntt_fwd8_kernel<NW, GMV>), lds);                                                         \
+        FHE_LAUNCH("ntt_fwd", (k::ntt_fwd8_kernel<NW, GMV>), dim3(rows_total), dim3(1024), lds, s, in, out, map,   \
+                   c.dmods(), c.dtw(), prologue);                                                                  \
+    } while (0)
+                if (cpt8 == 3) {
+                    if (narrow) FHE_NTT8(true, 3); else FHE_NTT8(false, 3);
+                } else {
+                    if (narrow) FHE_NTT8(true, k::GM_MIXED); else FHE_NTT8(false, k::GM_MIXED);
+                }
+#undef FHE_NTT8
+                return;
+            }
             if (narrow)
                 launch_ntt_lds<false, true>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(),
                                             logn, prologue);

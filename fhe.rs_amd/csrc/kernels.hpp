@@ -279,9 +279,9 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
                 for (uint32_t j = 0; j < half; j++) {
                     const uint32_t a = blk * 2 * half + j;
                     if constexpr (NARROW > 0)
-                        fwd_butterfly_narrow(x[a], x[a + half], wv.x, wv.y, pm, fwd_narrow_corrects(S0 + u, NARROW));
+                        fwd_butterfly_narrow<UNIFORM>(x[a], x[a + half], wv.x, wv.y, pm, fwd_narrow_corrects(S0 + u, NARROW));
                     else
-                        fwd_butterfly(x[a], x[a + half], wv.x, wv.y, pm);
+                        fwd_butterfly<UNIFORM>(x[a], x[a + half], wv.x, wv.y, pm);
                 }
             }
         }
@@ -472,20 +472,20 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
                             __builtin_trap();  // range tracking broken
 #endif
                         if (V0 + G == LOGM && u == G - 1 && fold) {  // both outputs below 2p
-                            x[a] = mul_shoup_lazy_n(y + t, ninv.x, ninv.y, pm.np);
-                            x[b] = mul_shoup_lazy_n(diff, zninv.x, zninv.y, pm.np);
+                            x[a] = mul_shoup_lazy_n<true>(y + t, ninv.x, ninv.y, pm.np);
+                            x[b] = mul_shoup_lazy_n<true>(diff, zninv.x, zninv.y, pm.np);
                         } else {
                             x[a] = y + t;
-                            x[b] = mul_shoup_lazy_n(diff, zv.x, zv.y, pm.np);
+                            x[b] = mul_shoup_lazy_n<UNIFORM>(diff, zv.x, zv.y, pm.np);
                         }
                         bnd[a] = bnd[a] + bnd[b];  // (kept independent of the run-time `fold`)
                         bnd[b] = 2;
                     } else if (V0 + G == LOGM && u == G - 1 && fold) {
                         const u64 t = x[a], y = x[b];
-                        x[a] = mul_shoup_lazy_n(y + t, ninv.x, ninv.y, pm.np);
-                        x[b] = mul_shoup_lazy_n(pm.p2 + t - y, zninv.x, zninv.y, pm.np);
+                        x[a] = mul_shoup_lazy_n<true>(y + t, ninv.x, ninv.y, pm.np);
+                        x[b] = mul_shoup_lazy_n<true>(pm.p2 + t - y, zninv.x, zninv.y, pm.np);
                     } else {
-                        inv_butterfly(x[a], x[b], zv.x, zv.y, pm);
+                        inv_butterfly<UNIFORM>(x[a], x[b], zv.x, zv.y, pm);
                     }
                 }
             }
@@ -650,6 +650,44 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
             lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
         else
             lds_to_tile<CH, M, T>(lds, dst, tid, [](u64 v) { return v; });  // < 2p, global pass finishes
+    }
+}
+
+// ------------------------------- forward NTT, 8 coefficients per thread (occupancy experiment) ----
+// Same transform as ntt_kernel<false, 13>, cut for twice the resident waves: 1024 threads x 8 coefficients, pass plan
+// GM (3: radix 8 throughout, GM_MIXED: radix 8 while the twiddles are scalar, radix 4 after), registers capped at 64
+// so that the two workgroups a CU's LDS holds bring 8 waves per SIMD instead of 4.  FHE_NTT_CPT8 = 3 / 32 selects it
+// for forward launches over 8192-point rows; numbers in DESIGN.md section 6.
+template <bool NARROW, int GM>
+__global__ void __launch_bounds__(1024, 8)
+    ntt_fwd8_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map, const DevMod *__restrict__ mods,
+                    const u64x2 *__restrict__ tw, uint32_t prologue) {
+    FHE_DYN_SMEM(u64, lds);
+    constexpr int LOGM = 13, T = 1024, M = 1 << LOGM;
+    constexpr int CH = tile_chunks_c(LOGM, T);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t poly = to_sgpr(blockIdx.x / map.rows);
+    const uint32_t r = map.row_begin + (blockIdx.x - poly * map.rows);
+    const uint32_t mi = (uint32_t)(map.mod_offset + (int32_t)r);
+    const DevMod md = mods[mi];
+    const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
+    const u64 *src = in + (u64)poly * map.src_poly_stride +
+                     (u64)(map.src_row_fixed >= 0 ? (uint32_t)map.src_row_fixed : r) * M;
+    u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * M;
+    const u64x2 *twr = tw + (u64)mi * M;
+    const bool red = prologue == PRO_REDUCE;
+    ntt_fwd_lds<LOGM, T, GM, false, true, (NARROW ? 1 : 0)>(lds, twr, 1, pm, tid, [&](uint32_t i, uint32_t) {
+        const u64 v = src[i];
+        return red ? reduce_u64(v, md) : v;
+    });
+    if constexpr (NARROW) {
+        const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
+        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) {
+            return csub_n(csub_n(csub_n(csub_n(v, p8, np8), p4, np4), p2, pm.np2), p, pm.np);
+        });
+    } else {
+        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(csub_n(v, p2, pm.np2), p, pm.np); });
     }
 }
 
@@ -858,12 +896,14 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         b1 = b0 + pk;
     }
     auto prod = [&](u64 x00, u64 x01, u64 x10, u64 x11) -> u64 {
-        if (slot == 0) return mul_mod(x00, x10, md);
-        if (slot == 2) return mul_mod(x01, x11, md);
+        // (results stay below 2p: the inverse transform's first pass takes that range)
+        if (slot == 0) return mul_mod_lazy(x00, x10, md);
+        if (slot == 2) return mul_mod_lazy(x01, x11, md);
         // c1 = c00*c11 + c01*c10: one Barrett reduction of the 128-bit sum (< 2p^2 < 2^(2k+1): the
-        // quotient estimate is then short by at most 3, which the two conditional subtractions absorb)
-        const u128_t sum = (u128_t)x00 * x11 + (u128_t)x01 * x10;
-        return barrett_reduce_wide((u64)(sum >> 64), (u64)sum, md);
+        // quotient estimate is then short by at most 3: below 4p before the conditional subtraction)
+        u64 hi, lo;
+        mac2_wide62(x00, x11, x01, x10, hi, lo);
+        return barrett_reduce_wide_lazy(hi, lo, md);
     };
     if constexpr (CH > 0) {
         if (slot != 1) {
@@ -879,8 +919,8 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
 #pragma unroll
             for (int c = 0; c < CH; c++) {
                 const uint32_t i = 2 * (c * T + tid);
-                lds[padi(i)] = mul_mod(va[c].x, vb[c].x, md);
-                lds[padi(i + 1)] = mul_mod(va[c].y, vb[c].y, md);
+                lds[padi(i)] = mul_mod_lazy(va[c].x, vb[c].x, md);
+                lds[padi(i + 1)] = mul_mod_lazy(va[c].y, vb[c].y, md);
             }
         } else {
         constexpr int HALF = CH > 1 ? CH / 2 : 1;  // loads of at most HALF chunks x 4 operands in flight

@@ -31,8 +31,68 @@ struct DevMod {  // layout == hostmath.hpp ModConsts
     u64 np, np2;  // 2^64 - p, 2^64 - 2p (loaded, so the compiler cannot fold x + np back into x - p)
 };
 
+// FHE_SENS: timing-sensitivity builds only (WRONG results; tools/ab_sens.sh): bit 0 the approximate quotient from two
+// partial products, bit 1 every high product from two, bit 2 the lazy Shoup low products from one.
+#ifndef FHE_SENS
+#define FHE_SENS 0
+#endif
+// The high product through v_mad_u64_u32's carry-out (FHE_MAD_CARRY, default on; the device compiler has no way to
+// ask for it): the two cross products are summed by the multiply-add itself, their carry leaves in an SGPR pair and
+// joins the upper half of the sum as the 64-bit addend of the last multiply -- one v_mul_hi, three multiply-adds, a
+// move and a select instead of the four multiplies plus ~six moves / 64-bit adds of the generic expansion (gfx950
+// needs even-aligned register pairs, so every 32-bit piece that enters a 64-bit addend costs the compiler a move).
+// SU: `b` is wave-uniform and stays in scalar registers (one constant-bus operand per instruction).
+// Every asm statement is a single instruction, so the scheduler still interleaves neighbouring butterflies; the
+// s_nop covers the two wait states gfx950 wants between a VALU write of an SGPR and a VALU read of it.
+#ifndef FHE_MAD_CARRY
+#define FHE_MAD_CARRY 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && FHE_MAD_CARRY && !(FHE_SENS & 2)
+#define FHE_HAVE_MAD_CARRY 1
+template <bool SU>
+__device__ __forceinline__ u64 mad64_carry(uint32_t a, uint32_t b, u64 add, u64 &carry) {
+    u64 r;
+    if constexpr (SU)
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "s"(b), "v"(add));
+    else
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b), "v"(add));
+    return r;
+}
+__device__ __forceinline__ uint32_t carry_bit(u64 carry) {
+    uint32_t r;
+    asm("s_nop 1\n\tv_cndmask_b32 %0, 0, 1, %1" : "=v"(r) : "s"(carry));
+    return r;
+}
+// floor(a * b / 2^64)
+template <bool SU = false>
+__device__ __forceinline__ u64 mulhi64_c(u64 a, u64 b) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const u64 m = (u64)a0 * b1 + (u64)__umulhi(a0, b0);   // < 2^64
+    u64 c;
+    const u64 n = mad64_carry<SU>(a1, b0, m, c);
+    return (u64)a1 * b1 + ((u64)(uint32_t)(n >> 32) | ((u64)carry_bit(c) << 32));
+}
+// the same without the a0 * b0 partial product: the true value or one less
+template <bool SU = false>
+__device__ __forceinline__ u64 mulhi64_approx_c(u64 a, u64 b) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const u64 m = (u64)a0 * b1;
+    u64 c;
+    const u64 n = mad64_carry<SU>(a1, b0, m, c);
+    return (u64)a1 * b1 + ((u64)(uint32_t)(n >> 32) | ((u64)carry_bit(c) << 32));
+}
+// (Issuing the two 32-bit cross products of the Shoup low word behind the carry-producing multiply in the same asm
+// statement, as its wait states, measured 1.2 % slower than the s_nop: the statement pins three instructions.)
+#else
+#define FHE_HAVE_MAD_CARRY 0
+#endif
+
 FHE_HD u64 mulhi64(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if FHE_SENS & 2
+    return (u64)(uint32_t)(a >> 32) * (uint32_t)(b >> 32) + (((u64)(uint32_t)a * (uint32_t)(b >> 32)) >> 32);
+#elif defined(__HIP_DEVICE_COMPILE__) && FHE_MAD_CARRY
+    return mulhi64_c<false>(a, b);
+#elif defined(__HIP_DEVICE_COMPILE__)
     return __umul64hi(a, b);
 #else
     return (u64)(((u128_t)a * b) >> 64);
@@ -65,9 +125,57 @@ FHE_HD u64 barrett_reduce_wide(u64 hi, u64 lo, const DevMod &m) {
     r = csub_n(r, m.p2, m.np2);
     return csub_n(r, m.p, m.np);
 }
+// Full product of two residues, both below 2^62 (the largest modulus size): four 32 x 32 multiply-adds with the
+// cross products summed by the multiply-add itself -- a0*b1 + a1*b0 + 2^32 cannot leave 64 bits when a1, b1 < 2^30.
+FHE_HD void mul_wide62(u64 a, u64 b, u64 &hi, u64 &lo) {
+#if defined(FHE_HOST_EMULATION)
+    if ((a | b) >> 62) __builtin_trap();
+#endif
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const u64 l = (u64)a0 * b0;
+    u64 m = (u64)a0 * b1 + (l >> 32);
+    m += (u64)a1 * b0;
+    hi = (u64)a1 * b1 + (m >> 32);
+    lo = (u64)(uint32_t)l | (m << 32);
+}
+// a*b + c*d for four such residues (below 2^125): eight multiply-adds, one carry (the two low products)
+FHE_HD void mac2_wide62(u64 a, u64 b, u64 c, u64 d, u64 &hi, u64 &lo) {
+#if FHE_HAVE_MAD_CARRY
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint32_t c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32), d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
+    u64 cl;
+    const u64 l = mad64_carry<false>(c0, d0, (u64)a0 * b0, cl);
+    u64 m = (u64)a0 * b1 + ((u64)(uint32_t)(l >> 32) | ((u64)carry_bit(cl) << 32));
+    m += (u64)a1 * b0;   // four cross products below 2^62 each and 2^33: no carry out
+    m += (u64)c0 * d1;
+    m += (u64)c1 * d0;
+    hi = (u64)a1 * b1 + (m >> 32);
+    hi += (u64)c1 * d1;
+    lo = (u64)(uint32_t)l | (m << 32);
+#else
+#if defined(FHE_HOST_EMULATION)
+    if ((a | b | c | d) >> 62) __builtin_trap();
+#endif
+    const u128_t sum = (u128_t)a * b + (u128_t)c * d;
+    hi = (u64)(sum >> 64), lo = (u64)sum;
+#endif
+}
+// lazy: below 2p (what the inverse transform's first pass takes)
+FHE_HD u64 barrett_reduce_wide_lazy(u64 hi, u64 lo, const DevMod &m) {
+    const uint32_t s = m.k - 1;
+    u64 xs = (s == 0) ? lo : ((lo >> s) | (hi << (64 - s)));
+    u64 q = mulhi64(xs, m.mu);
+    return csub_n(lo + q * m.np, m.p2, m.np2);
+}
 FHE_HD u64 mul_mod(u64 a, u64 b, const DevMod &m) {  // a, b < p
-    u64 lo = a * b, hi = mulhi64(a, b);
+    u64 lo, hi;
+    mul_wide62(a, b, hi, lo);
     return barrett_reduce_wide(hi, lo, m);
+}
+FHE_HD u64 mul_mod_lazy(u64 a, u64 b, const DevMod &m) {  // a, b < p -> below 2p
+    u64 lo, hi;
+    mul_wide62(a, b, hi, lo);
+    return barrett_reduce_wide_lazy(hi, lo, m);
 }
 
 // Reduction of an arbitrary 64-bit value to [0, p): q = floor(a * floor(2^64/p) / 2^64).
@@ -105,13 +213,32 @@ struct PM {
 };
 FHE_HD PM make_pm(const DevMod &m) { return PM{m.p, m.p2, m.np, m.np2}; }
 // mul_shoup_lazy with a*b - q*p written as a*b + q*(2^64 - p)  (mod 2^64)
-FHE_HD u64 mul_shoup_lazy_n(u64 a, u64 b, u64 bs, u64 np) { return a * b + mulhi64(a, bs) * np; }
+// SU (here and in the butterflies): the twiddle pair is wave-uniform (scalar registers); see mad64_carry
+template <bool SU = false>
+FHE_HD u64 mulhi64_t(u64 a, u64 b) {
+#if FHE_HAVE_MAD_CARRY
+    return mulhi64_c<SU>(a, b);
+#else
+    return mulhi64(a, b);
+#endif
+}
+#if FHE_SENS & 4
+FHE_HD u64 sens_lo(u64 a, u64 b) { return (u64)(uint32_t)a * (uint32_t)b; }
+template <bool SU = false>
+FHE_HD u64 mul_shoup_lazy_n(u64 a, u64 b, u64 bs, u64 np) { return sens_lo(a, b) + sens_lo(mulhi64(a, bs), np); }
+#else
+template <bool SU = false>
+FHE_HD u64 mul_shoup_lazy_n(u64 a, u64 b, u64 bs, u64 np) {
+    return a * b + mulhi64_t<SU>(a, bs) * np;
+}
+#endif
 FHE_HD u64 add_mod_n(u64 a, u64 b, const PM &m) { return csub_n(a + b, m.p, m.np); }
 
 // Harvey lazy butterflies, M/ntt/native.rs:256-269 / 288-300.
+template <bool SU = false>
 FHE_HD void fwd_butterfly(u64 &x, u64 &y, u64 w, u64 ws, const PM &m) {
     x = csub_n(x, m.p2, m.np2);
-    u64 t = mul_shoup_lazy_n(y, w, ws, m.np);
+    u64 t = mul_shoup_lazy_n<SU>(y, w, ws, m.np);
     y = x + m.p2 - t;
     x = x + t;
 }
@@ -135,12 +262,20 @@ constexpr int fwd_narrow_bound(int stage, int b0 = 1) {  // b before `stage`, b0
 }
 constexpr bool fwd_narrow_corrects(int stage, int b0 = 1) { return fwd_narrow_bound(stage, b0) > 16 - FWD_NARROW_STEP; }
 // floor(a * s / 2^64) or one less: the partial product a0 * s0 is left out (it contributes at most a carry of 1)
+template <bool SU = false>
 FHE_HD u64 mulhi64_approx(u64 a, u64 s) {
+#if FHE_HAVE_MAD_CARRY && !(FHE_SENS & 1)
+    return mulhi64_approx_c<SU>(a, s);
+#endif
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+#if FHE_SENS & 1
+    return (u64)a1 * s1 + (((u64)a0 * s1) >> 32);
+#endif
     const u64 m = (u64)a0 * s1;
     const u64 m2 = (u64)a1 * s0 + (uint32_t)m;
     return (u64)a1 * s1 + (m >> 32) + (m2 >> 32);
 }
+template <bool SU = false>
 FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, bool correct) {
     if (correct) {  // x < 16p -> < 4p
         const u64 p4 = m.p2 << 1, p8 = m.p2 << 2, np4 = m.np2 << 1, np8 = m.np2 << 2;
@@ -148,10 +283,14 @@ FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, boo
         x = csub_n(x, p4, np4);
     }
 #if FHE_APPROX_SHOUP
-    const u64 t = y * w + mulhi64_approx(y, ws) * m.np;   // below 3p
+#if FHE_SENS & 4
+    const u64 t = sens_lo(y, w) + sens_lo(mulhi64_approx<SU>(y, ws), m.np);
+#else
+    const u64 t = y * w + mulhi64_approx<SU>(y, ws) * m.np;   // below 3p
+#endif
     const u64 pk = m.p2 + m.p;
 #else
-    const u64 t = mul_shoup_lazy_n(y, w, ws, m.np);
+    const u64 t = mul_shoup_lazy_n<SU>(y, w, ws, m.np);
     const u64 pk = m.p2;
 #endif
 #if defined(FHE_HOST_EMULATION)
@@ -160,10 +299,11 @@ FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, boo
     y = x + pk - t;
     x = x + t;
 }
+template <bool SU = false>
 FHE_HD void inv_butterfly(u64 &x, u64 &y, u64 z, u64 zs, const PM &m) {
     u64 t = x;
     x = csub_n(y + t, m.p2, m.np2);
-    y = mul_shoup_lazy_n(m.p2 + t - y, z, zs, m.np);
+    y = mul_shoup_lazy_n<SU>(m.p2 + t - y, z, zs, m.np);
 }
 
 FHE_HD u64 splitmix64(u64 x) {

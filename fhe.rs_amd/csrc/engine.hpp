@@ -422,6 +422,9 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     if (npolys == 0 || map.rows == 0) return;
     const uint32_t logn = (uint32_t)c.logn;
     const unsigned rows_total = (unsigned)(npolys * map.rows);
+    // timing experiment only (WRONG results): every polynomial of the launch reads and writes the first one's rows, so
+    // the kernel runs out of L2 -- what is left is its arithmetic / LDS time (tools/ab_nomem.sh)
+    if (debug_flag("FHE_DEBUG_NTT_NOMEM")) map.src_poly_stride = map.dst_poly_stride = 0;
     if (logn <= 14) {
         if (!inverse) {
             // every modulus of the launch below 2^60: the transform without per-stage conditional subtractions
@@ -1408,6 +1411,8 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         if (m.rk) {
             // c0, c1 go back to Ntt; c2 stays in PowerBasis for the key switch (the reference
             // transforms c2 forward and, at mul.rs:212, back again; iNTT(NTT(x)) = x exactly).
+            // (Transforming c2 as well and handing it to the key switch as `xhat` was measured at C2: the key
+            // switch gains 1.0 ms per 10 steps, the larger forward launch costs 1.6: profiles/r02_mul_xhat_ab.txt.)
             launch_ntt(b, false, d.u(), d.u(), full_map(b, L), nb * 2, k::PRO_NONE, s);
             // RELINEARIZE (mul.rs:211-227): (c0, c1) += key_switch(c2), written to the output layout
             key_switch_add(*m.rk, d.u() + 2 * nb * PL, PL, d.u(), d.u() + nb * PL, PL, dst, dst + PL, 2 * PL, nb, s);

@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../fhe.rs_amd/csrc/zq_dev.hpp"
@@ -194,6 +195,10 @@ __global__ void bench(u64 *out, u64 seed, u64 p, u64 w, u64 ws) {
                 x[i] = csub_n(y[i] + t, pm.p2, pm.np2);
                 y[i] = shoup_allmad(pm.p2 + t - y[i], w, ws, pm.np);
             }
+            if (KIND == 40) fwd_butterfly_narrow<false>(x[i], y[i], w, ws, pm, false);   // round-2 arithmetic (carry-out high products)
+            if (KIND == 41) fwd_butterfly<true>(x[i], y[i], w, ws, pm);                  // ... scalar twiddle operands
+            if (KIND == 42) inv_butterfly<true>(x[i], y[i], w, ws, pm);
+            if (KIND == 43) fwd_butterfly_narrow<true>(x[i], y[i], w, ws, pm, false);
             if (KIND == 28) x[i] = x[i] * w + mulhi64_z(x[i], ws, zero) * pm.np;
             if (KIND == 29) {
                 const u64 t = y[i] * w + mulhi64_z(y[i], ws, zero) * pm.np;
@@ -254,6 +259,17 @@ double run(const char *name, double ops_per_iter) {
 }
 
 int main() {
+    if (getenv("UB_R02B")) {   // the butterflies as the kernels run them since the carry-out high products
+        run<4>("mulhi64 (carry-out form)", 1);
+        run<5>("mul_shoup_lazy", 1);
+        run<6>("fwd_butterfly (wide)", 1);
+        run<41>("fwd_butterfly (wide), scalar twiddle", 1);
+        run<7>("inv_butterfly", 1);
+        run<42>("inv_butterfly, scalar twiddle", 1);
+        run<40>("fwd_butterfly_narrow (approximate quotient)", 1);
+        run<43>("fwd_butterfly_narrow, scalar twiddle", 1);
+        return 0;
+    }
     run<0>("v_mul_lo_u32", 1);
     run<1>("v_mul_hi_u32", 1);
     run<2>("v_mad_u64_u32", 1);

@@ -88,6 +88,50 @@ def case_poly_ops(fhe, dev, n=32):
     assert np.array_equal(x.back(c.mul_shoup(x.to(lazy), x.to(arr(b)), x.to(sh))), arr(a.mul(bs)))
 
 
+def case_product_extremes(fhe, dev, n=64):
+    """Residue products at the word boundaries (zq/mod.rs:208-260 `mul` / `mul_shoup`, ops.rs:208-245): the device forms
+    its high products through the multiply-add's carry-out and full products from four 32 x 32 multiply-adds with
+    no carry handling in the middle column (zq_dev.hpp mulhi64_c / mul_wide62) -- operands made of all-ones and
+    all-zeros 32-bit words, 0, 1, p-1 and the lazy range up to 4p - 1 are where a dropped carry would show.
+    Expected values from Python integers."""
+    x = Xfer(dev)
+    small = 1153 if n <= 64 else fhe.generate_prime(18, 2 * n, 1 << 18)
+    moduli = [small] + [fhe.generate_prime(b, 2 * n, 1 << b) for b in (33, 45, 60, 62)] + [4611686018326724609]
+    moduli = list(dict.fromkeys(moduli))
+    c = fhe.Context(moduli, n)
+    M32 = (1 << 32) - 1
+
+    def specials(p, top):   # values below `top`
+        cand = [0, 1, 2, p - 1, p - 2, p >> 1, M32, 1 << 32, (1 << 32) + 1, M32 << 32, (M32 << 32) | M32,
+                p - M32, p - (1 << 32), (p >> 32) << 32, ((p >> 32) << 32) | M32, top - 1, top - M32, top >> 1]
+        return sorted({v % top for v in cand if v >= 0})
+
+    rng = random.Random(77)
+    A, B, L = [], [], []
+    for p in moduli:
+        sa, sl = specials(p, p), specials(p, min(4 * p, 1 << 64))
+        a = [sa[i % len(sa)] for i in range(n)]
+        b = [sa[(i // 3 + 5 * i) % len(sa)] for i in range(n)]
+        lz = [sl[(7 * i + i // 5) % len(sl)] for i in range(n)]
+        for i in range(n - 8, n):
+            a[i], b[i], lz[i] = rng.randrange(p), rng.randrange(p), rng.randrange(min(4 * p, 1 << 64))
+        A.append(a), B.append(b), L.append(lz)
+    An, Bn, Ln = (np.array(v, dtype=np.uint64) for v in (A, B, L))
+    want = np.array([[(a * b) % p for a, b in zip(ra, rb)] for ra, rb, p in zip(A, B, moduli)], dtype=np.uint64)
+    assert np.array_equal(x.back(c.mul(x.to(An[None]), x.to(Bn[None])))[0], want)
+    sh = c.shoup(Bn)
+    assert sh.tolist() == [[(b << 64) // p for b in rb] for rb, p in zip(B, moduli)]
+    want_l = np.array([[(a * b) % p for a, b in zip(ra, rb)] for ra, rb, p in zip(L, B, moduli)], dtype=np.uint64)
+    assert np.array_equal(x.back(c.mul_shoup(x.to(Ln), x.to(Bn), x.to(sh))), want_l)
+    # the same extremes through the transforms (every butterfly multiplies by a twiddle): forward then inverse is the
+    # identity, and the forward values match the oracle's
+    o = OCtx(moduli, n)
+    pw = Poly(o, POWER_BASIS, [list(r) for r in A])
+    f = x.back(c.ntt_forward(x.to(An[None].copy())))[0]
+    assert np.array_equal(f, arr(pw.into_ntt()))
+    assert np.array_equal(x.back(c.ntt_backward(x.to(f[None].copy())))[0], An)
+
+
 def case_substitute(fhe, dev, n=16):
     """rq/mod.rs:947-1036."""
     x = Xfer(dev)

@@ -30,6 +30,10 @@ def test_poly_ops(fhe):
     cases.case_poly_ops(fhe, False)
 
 
+def test_product_extremes(fhe):
+    cases.case_product_extremes(fhe, False)
+
+
 def test_substitute(fhe):
     cases.case_substitute(fhe, False)
 

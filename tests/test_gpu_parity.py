@@ -49,6 +49,11 @@ def test_poly_ops(fhe, dev):
     cases.case_poly_ops(fhe, dev)
 
 
+@pytest.mark.parametrize("n", [64, 8192])
+def test_product_extremes(fhe, n):
+    cases.case_product_extremes(fhe, True, n)
+
+
 @pytest.mark.parametrize("dev", [False, True])
 def test_substitute(fhe, dev):
     cases.case_substitute(fhe, dev)

@@ -127,6 +127,36 @@ __device__ __forceinline__ u64 mulhi64_approx(u64 a, u64 s) {   // a0*s0 dropped
     const u64 m2 = (u64)a1 * s0 + (uint32_t)m;
     return (u64)a1 * s1 + (m >> 32) + (m2 >> 32);
 }
+// y * w mod p for p = 2^62 - c, c < 2^28 -- what the reference's generate_prime(62, ...) hands out for the extended
+// basis (zq/primes.rs:27-48 walks down from 2^62 in steps of 2N) -- any y < 2^64, w < 2^62; result below 2p (lazy).
+// 2^62 = c (mod p), so the 126-bit product folds twice: x = xh 2^62 + xl -> xh c + xl (< 2^92) -> sh c + sl.
+// Seven multiply-adds, no quotient and no Shoup companion of w against the Harvey butterfly's ten / eleven multiplies.
+// Measured (profiles/r02_ubench_butterflies_carry.jsonl): 2.71 T/s as a bare modular product against 2.51 T/s for the
+// Shoup product, but 1.75 / 1.68 T/s inside the forward / inverse butterfly against 1.79 / 1.72 T/s -- the fourteen
+// shifts, masks and moves around the folds cost what the three multiplies save.  Not built into the kernels.
+__device__ __forceinline__ u64 solinas62_lazy(u64 y, u64 w, uint32_t c) {
+#if defined(FHE_HOST_EMULATION)
+    if ((w >> 62) || (c >> 28)) __builtin_trap();
+#endif
+#if FHE_HAVE_MAD_CARRY
+    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const u64 l = (u64)y0 * w0;
+    const u64 m = (u64)y0 * w1 + (l >> 32);          // < 2^62 + 2^32
+    u64 cm;
+    const u64 n = mad64_carry<false>(y1, w0, m, cm);  // may carry: y1 * w0 < 2^64
+    const u64 hi = (u64)y1 * w1 + ((u64)(uint32_t)(n >> 32) | ((u64)carry_bit(cm) << 32));   // < 2^62
+    const u64 lo = (u64)(uint32_t)l | (n << 32);
+#else
+    const u128_t x = (u128_t)y * w;
+    const u64 hi = (u64)(x >> 64), lo = (u64)x;
+#endif
+    const u64 xh = (hi << 2) | (lo >> 62), xl = lo & ((1ull << 62) - 1);
+    const u64 a = (u64)(uint32_t)xh * c + xl;              // < 2^60 + 2^62
+    const u64 b = (u64)(uint32_t)(xh >> 32) * c + (a >> 32);   // xh c + xl = b 2^32 + (a mod 2^32), b < 2^60 + 2^31
+    const u64 sl = (u64)(uint32_t)a | ((b & 0x3FFFFFFFull) << 32);
+    return (u64)(uint32_t)(b >> 30) * c + sl;              // (b >> 30) < 2^31: the product is below 2^59
+}
+
 constexpr int ILP = 8;
 constexpr int ITERS = 4096;
 
@@ -199,6 +229,18 @@ __global__ void bench(u64 *out, u64 seed, u64 p, u64 w, u64 ws) {
             if (KIND == 41) fwd_butterfly<true>(x[i], y[i], w, ws, pm);                  // ... scalar twiddle operands
             if (KIND == 42) inv_butterfly<true>(x[i], y[i], w, ws, pm);
             if (KIND == 43) fwd_butterfly_narrow<true>(x[i], y[i], w, ws, pm, false);
+            if (KIND == 50) x[i] = solinas62_lazy(x[i], w, (uint32_t)ws | 1);   // 2^62 - c primes: seven multiply-adds
+            if (KIND == 51) {   // wide forward butterfly on it
+                x[i] = csub_n(x[i], pm.p2, pm.np2);
+                const u64 t = solinas62_lazy(y[i], w, (uint32_t)ws | 1);
+                y[i] = x[i] + pm.p2 - t;
+                x[i] = x[i] + t;
+            }
+            if (KIND == 52) {   // Gentleman-Sande butterfly on it
+                const u64 t = x[i];
+                x[i] = csub_n(y[i] + t, pm.p2, pm.np2);
+                y[i] = solinas62_lazy(pm.p2 + t - y[i], w, (uint32_t)ws | 1);
+            }
             if (KIND == 28) x[i] = x[i] * w + mulhi64_z(x[i], ws, zero) * pm.np;
             if (KIND == 29) {
                 const u64 t = y[i] * w + mulhi64_z(y[i], ws, zero) * pm.np;
@@ -268,6 +310,9 @@ int main() {
         run<42>("inv_butterfly, scalar twiddle", 1);
         run<40>("fwd_butterfly_narrow (approximate quotient)", 1);
         run<43>("fwd_butterfly_narrow, scalar twiddle", 1);
+        run<50>("solinas62_lazy (p = 2^62 - c)", 1);
+        run<51>("fwd_butterfly (wide) on solinas62_lazy", 1);
+        run<52>("inv_butterfly on solinas62_lazy", 1);
         return 0;
     }
     run<0>("v_mul_lo_u32", 1);

@@ -653,6 +653,11 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     }
 }
 
+// (Persistent workgroups -- the rows of a launch dealt round-robin to two or four resident workgroups per CU, the next
+// row's coefficients prefetched into registers across the epilogue -- were built and measured for the forward
+// transform: 17.2-17.9 M against 24.8 M row-NTT/s (60-bit rows), 15.6-17.8 M against 19.8-20.8 M (62-bit): the 32
+// prefetch registers on top of a radix-16 pass spill (36-124 B of scratch per lane) and the hardware dispatcher
+// already overlaps one workgroup's loads with the other's arithmetic.  profiles/r02_ntt_persist_ab.txt.)
 // ------------------------------- forward NTT, 8 coefficients per thread (occupancy experiment) ----
 // Same transform as ntt_kernel<false, 13>, cut for twice the resident waves: 1024 threads x 8 coefficients, pass plan
 // GM (3: radix 8 throughout, GM_MIXED: radix 8 while the twiddles are scalar, radix 4 after), registers capped at 64

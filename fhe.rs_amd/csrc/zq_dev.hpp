@@ -31,7 +31,8 @@ struct DevMod {  // layout == hostmath.hpp ModConsts
     u64 np, np2;  // 2^64 - p, 2^64 - 2p (loaded, so the compiler cannot fold x + np back into x - p)
 };
 
-// FHE_SENS: timing-sensitivity builds only (WRONG results; tools/ab_sens.sh): bit 0 the approximate quotient from two
+// FHE_SENS: timing-sensitivity builds only (WRONG results; tools/ab_sens.sh; bits 3 / 4: the pseudo-Mersenne fold and
+// q * c - (q << b) for 2^b - c primes, both slower in the kernels): bit 0 the approximate quotient from two
 // partial products, bit 1 every high product from two, bit 2 the lazy Shoup low products from one.
 #ifndef FHE_SENS
 #define FHE_SENS 0
@@ -216,6 +217,23 @@ struct PM {
 FHE_HD PM make_pm(const DevMod &m) { return PM{m.p, m.p2, m.np, m.np2}; }
 // mul_shoup_lazy with a*b - q*p written as a*b + q*(2^64 - p)  (mod 2^64)
 // SU (here and in the butterflies): the twiddle pair is wave-uniform (scalar registers); see mad64_carry
+#if (FHE_SENS & 8) && defined(__HIP_DEVICE_COMPILE__)
+// timing only: the pseudo-Mersenne fold (tools/ubench_int.cpp solinas62_lazy) in place of every lazy Shoup product
+__device__ __forceinline__ u64 sens_solinas(u64 y, u64 w, uint32_t c) {
+    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const u64 l = (u64)y0 * w0;
+    const u64 m = (u64)y0 * w1 + (l >> 32);
+    u64 cm;
+    const u64 n = mad64_carry<false>(y1, w0, m, cm);
+    const u64 hi = (u64)y1 * w1 + ((u64)(uint32_t)(n >> 32) | ((u64)carry_bit(cm) << 32));
+    const u64 lo = (u64)(uint32_t)l | (n << 32);
+    const u64 xh = (hi << 2) | (lo >> 62), xl = lo & ((1ull << 62) - 1);
+    const u64 a = (u64)(uint32_t)xh * c + xl;
+    const u64 b = (u64)(uint32_t)(xh >> 32) * c + (a >> 32);
+    const u64 sl = (u64)(uint32_t)a | ((b & 0x3FFFFFFFull) << 32);
+    return (u64)(uint32_t)(b >> 30) * c + sl;
+}
+#endif
 template <bool SU = false>
 FHE_HD u64 mulhi64_t(u64 a, u64 b) {
 #if FHE_HAVE_MAD_CARRY
@@ -231,7 +249,14 @@ FHE_HD u64 mul_shoup_lazy_n(u64 a, u64 b, u64 bs, u64 np) { return sens_lo(a, b)
 #else
 template <bool SU = false>
 FHE_HD u64 mul_shoup_lazy_n(u64 a, u64 b, u64 bs, u64 np) {
+#if (FHE_SENS & 8) && defined(__HIP_DEVICE_COMPILE__)
+    return sens_solinas(a, b, (uint32_t)np);
+#elif (FHE_SENS & 16) && defined(__HIP_DEVICE_COMPILE__)
+    const u64 q = mulhi64_t<SU>(a, bs);   // timing only: q * (2^64 - 2^b + c) as q * c - (q << b)
+    return a * b + q * (u64)(uint32_t)np - ((u64)((uint32_t)q << 28) << 32);
+#else
     return a * b + mulhi64_t<SU>(a, bs) * np;
+#endif
 }
 #endif
 FHE_HD u64 add_mod_n(u64 a, u64 b, const PM &m) { return csub_n(a + b, m.p, m.np); }
@@ -288,7 +313,14 @@ FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, boo
 #if FHE_SENS & 4
     const u64 t = sens_lo(y, w) + sens_lo(mulhi64_approx<SU>(y, ws), m.np);
 #else
+#if (FHE_SENS & 8) && defined(__HIP_DEVICE_COMPILE__)
+    const u64 t = sens_solinas(y, w, (uint32_t)m.np);
+#elif (FHE_SENS & 16) && defined(__HIP_DEVICE_COMPILE__)
+    const u64 qq = mulhi64_approx<SU>(y, ws);
+    const u64 t = y * w + qq * (u64)(uint32_t)m.np - ((u64)((uint32_t)qq << 28) << 32);
+#else
     const u64 t = y * w + mulhi64_approx<SU>(y, ws) * m.np;   // below 3p
+#endif
 #endif
     const u64 pk = m.p2 + m.p;
 #else

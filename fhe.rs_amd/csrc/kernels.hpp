@@ -417,7 +417,33 @@ __device__ __forceinline__ void inv_tw_load(InvTw<G, LOGM, V0, T> &tw_regs, cons
 // multiplication and is below 2p again -- and `bnd[]` tracks every register's bound (in units of p)
 // through the fully unrolled stages, so the conditional subtractions shrink to the few needed to keep
 // sums below 16p and to hand the next pass values below 2p (7 instead of 12 per radix-8 group).
-template <int G, int LOGM, int V0, int T, bool NARROW = false, bool WLX = false>
+// FHE_APPROX_SHOUP (zq_dev.hpp): the narrow passes also take the three-partial-product quotient -- the product is
+// then below 3p instead of 2p, `bnd[]` holds any integer up to 16, conditional subtractions pick the multiple of p
+// (8p, 4p, 2p, p) that leaves the smallest bound, and values travel between passes below BIN / BOUT = 4 p (first
+// pass in: 2p; last pass out: 2p, through the exact quotient of the folded last stage): one v_mul_hi_u32 less per
+// butterfly for one more conditional subtraction per radix-8 group (8 instead of 7; 20 instead of 16 per radix-16).
+constexpr int INV_NARROW_MID = FHE_APPROX_SHOUP ? 4 : 2;
+constexpr int inv_best_c(int bd) {   // the power of two c <= 8, c < bd, that minimises max(c, bd - c)
+    int best = 1, bv = bd - 1;
+    for (int c = 2; c <= 8; c *= 2)
+        if (c < bd) {
+            const int v = c > bd - c ? c : bd - c;
+            if (v <= bv) best = c, bv = v;
+        }
+    return best;
+}
+// k * p for a compile-time k <= 16 out of the (uniform) p and 2p by shifts and adds: scalar instructions, where a
+// 64-bit multiply by k would go through the vector multiplier
+__device__ __forceinline__ u64 small_multiple(const PM &pm, int k) {
+    u64 r = 0;
+    if (k & 1) r += pm.p;
+    if (k & 2) r += pm.p2;
+    if (k & 4) r += pm.p2 << 1;
+    if (k & 8) r += pm.p2 << 2;
+    if (k & 16) r += pm.p2 << 3;
+    return r;
+}
+template <int G, int LOGM, int V0, int T, bool NARROW = false, bool WLX = false, int BIN = 2, int BOUT = 2>
 __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
                                          const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv,
                                          const InvTw<G, LOGM, V0, T> &tw_regs) {
@@ -440,14 +466,23 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
         u64 x[R];
 #pragma unroll
         for (uint32_t e = 0; e < R; e++) x[e] = g[padi(e << V0)];
-        int bnd[R];  // NARROW: x[e] < bnd[e] * p (compile-time after unrolling); powers of two
+        int bnd[R];  // NARROW: x[e] < bnd[e] * p (compile-time after unrolling)
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++) bnd[e] = 2;
-        // x < bnd*p -> x < (bnd/2)*p
-        auto halve = [&](u64 &v, int &bd) {
-            const int sh = bd == 16 ? 2 : bd == 8 ? 1 : 0;   // (bd/2) * p = p2 << sh for bd = 16, 8, 4
-            v = csub_n(v, pm.p2 << sh, pm.np2 << sh);
-            bd /= 2;
+        for (uint32_t e = 0; e < R; e++) bnd[e] = BIN;
+        // x < bd*p -> x < max(c, bd - c)*p by one conditional subtraction of c*p, c in {8, 4, 2, 1}
+        // (straight-line code, no loops: everything folds once the stage loops are unrolled)
+        auto reduce = [&](u64 &v, int &bd) {
+            const int c = inv_best_c(bd);
+            const int sh = c == 8 ? 2 : c == 4 ? 1 : 0;
+            v = c == 1 ? csub_n(v, pm.p, pm.np) : csub_n(v, pm.p2 << sh, pm.np2 << sh);
+            bd = c > bd - c ? c : bd - c;
+        };
+        auto fit16 = [&](u64 &va, int &ba, u64 &vb, int &bb) {   // keep va + vb and va + bb*p below 16p
+#pragma unroll
+            for (int it = 0; it < 4; it++)
+                if (ba + bb > 16) {
+                    if (ba >= bb) reduce(va, ba); else reduce(vb, bb);
+                }
         };
 #pragma unroll
         for (int u = 0; u < G; u++) {
@@ -460,26 +495,26 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
                 for (uint32_t j = 0; j < (1u << u); j++) {
                     const uint32_t a = blk * (2u << u) + j, b = a + (1u << u);
                     if constexpr (NARROW) {
-                        // keep x[a] + x[b] and x[a] + bnd[b]*p below 16p
-                        // (straight-line ifs, not loops: they fold once the stage loops are unrolled)
-                        if (bnd[a] + bnd[b] > 16) halve(x[a], bnd[a]);
-                        if (bnd[a] + bnd[b] > 16) halve(x[b], bnd[b]);
+                        fit16(x[a], bnd[a], x[b], bnd[b]);
                         const u64 t = x[a], y = x[b];
-                        const int shb = bnd[b] == 16 ? 3 : bnd[b] == 8 ? 2 : bnd[b] == 4 ? 1 : 0;  // bnd[b]*p = p2 << shb
-                        const u64 diff = (pm.p2 << shb) + t - y;
+                        const u64 diff = small_multiple(pm, bnd[b]) + t - y;   // (a compile-time multiple of the uniform p)
 #if defined(FHE_HOST_EMULATION)
-                        if (y >= (pm.p2 << shb) || t >= (pm.p >> 0) * (u64)bnd[a] || bnd[a] + bnd[b] > 16)
+                        if (y >= small_multiple(pm, bnd[b]) || (bnd[a] < 16 && t >= small_multiple(pm, bnd[a])) || bnd[a] + bnd[b] > 16)
                             __builtin_trap();  // range tracking broken
 #endif
-                        if (V0 + G == LOGM && u == G - 1 && fold) {  // both outputs below 2p
+                        if (V0 + G == LOGM && u == G - 1 && fold) {  // exact quotients: both outputs below 2p
                             x[a] = mul_shoup_lazy_n<true>(y + t, ninv.x, ninv.y, pm.np);
                             x[b] = mul_shoup_lazy_n<true>(diff, zninv.x, zninv.y, pm.np);
                         } else {
                             x[a] = y + t;
+#if FHE_APPROX_SHOUP
+                            x[b] = diff * zv.x + mulhi64_approx<UNIFORM>(diff, zv.y) * pm.np;   // below 3p
+#else
                             x[b] = mul_shoup_lazy_n<UNIFORM>(diff, zv.x, zv.y, pm.np);
+#endif
                         }
                         bnd[a] = bnd[a] + bnd[b];  // (kept independent of the run-time `fold`)
-                        bnd[b] = 2;
+                        bnd[b] = FHE_APPROX_SHOUP ? 3 : 2;
                     } else if (V0 + G == LOGM && u == G - 1 && fold) {
                         const u64 t = x[a], y = x[b];
                         x[a] = mul_shoup_lazy_n<true>(y + t, ninv.x, ninv.y, pm.np);
@@ -490,13 +525,13 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
                 }
             }
         }
-        if constexpr (NARROW) {  // the next pass (and the epilogue) expect values below 2p
+        if constexpr (NARROW) {  // the next pass (or the epilogue / the global pass) expects values below BOUT * p
             if (!(V0 + G == LOGM && fold)) {
 #pragma unroll
                 for (uint32_t e = 0; e < R; e++) {
-                    if (bnd[e] > 8) halve(x[e], bnd[e]);
-                    if (bnd[e] > 4) halve(x[e], bnd[e]);
-                    if (bnd[e] > 2) halve(x[e], bnd[e]);
+#pragma unroll
+                    for (int it = 0; it < 4; it++)
+                        if (bnd[e] > BOUT) reduce(x[e], bnd[e]);
                 }
             }
         }
@@ -531,7 +566,9 @@ __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ 
     constexpr int G = inv_plan_g<LOGM, PASS>();
     constexpr bool WLX = inv_wl_after(LOGM, PASS) || inv_wl_after(LOGM, PASS - 1);
     static_assert(!WLX || T % 64 == 0, "wave-local exchanges need whole 64-lane waves");
-    inv_pass<G, LOGM, V0, T, NARROW, WLX>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, tw_regs);
+    constexpr bool LAST = PASS + 1 == plan_np(LOGM, GMAX);
+    inv_pass<G, LOGM, V0, T, NARROW, WLX, (PASS == 0 ? 2 : INV_NARROW_MID), (LAST ? 2 : INV_NARROW_MID)>(
+        lds, itw, logn, sub, pm, tid, fold, ninv, zninv, tw_regs);
     if constexpr (PASS + 1 < plan_np(LOGM, GMAX)) {
         InvTw<inv_plan_g<LOGM, PASS + 1>(), LOGM, V0 + G, T> next;
         inv_tw_load(next, itw, logn, sub, tid);   // in flight across the barrier

@@ -119,6 +119,13 @@ __device__ __forceinline__ uint32_t to_sgpr(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
 #error "wave_sync() / wave_local_exchange() assume 64-lane wavefronts (gfx950)"
 #endif
+// FHE_BARRIER: the workgroup barrier of the NTT / tensor / key-switch kernels.  A timing-sensitivity build
+// (-DFHE_SENS=32, WRONG results: LDS races) turns every one of them into the wave-local fence to price the barriers.
+#if (FHE_SENS & 32) && defined(__HIP_DEVICE_COMPILE__)
+#define FHE_BARRIER() wave_sync()
+#else
+#define FHE_BARRIER() __syncthreads()
+#endif
 __device__ __forceinline__ void wave_sync() {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FHE_NO_WAVE_SYNC)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -192,7 +199,7 @@ struct NoSrc {};
 // their L2 latency overlaps the barrier instead of following it.
 template <int G, int LOGM, int S0, int T>
 struct FwdTw {
-    static constexpr bool UNIFORM = (LOGM - S0 - G) >= 6;
+    static constexpr bool UNIFORM = (LOGM - S0 - G) >= 6 || (FHE_SENS & 64);   // (bit 6: timing only, every pass on scalar twiddles)
     static constexpr int NG = (1 << (LOGM - G)) > T ? (1 << (LOGM - G)) / T : 1;  // groups per thread
     u64x2 w[UNIFORM ? 1 : NG][UNIFORM ? 1 : (1 << G) - 1];
 };
@@ -231,7 +238,7 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
     constexpr uint32_t R = 1u << G;
     constexpr uint32_t lo_bits = LOGM - S0 - G;
     constexpr uint32_t ngroups = 1u << (LOGM - G);
-    constexpr bool UNIFORM = lo_bits >= 6;
+    constexpr bool UNIFORM = lo_bits >= 6 || (FHE_SENS & 64);
 #pragma unroll
     for (uint32_t g0 = 0; g0 < ngroups; g0 += T) {
         const uint32_t grp = g0 + tid;
@@ -358,12 +365,12 @@ __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restric
         if constexpr (wave_local_exchange(LOGM - S0 - G, G, LOGM - S0 - G - GN, GN))
             wave_sync();
         else
-            __syncthreads();
+            FHE_BARRIER();
         FHE_TS(9 + 2 * PASS);
         ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, PASS + 1, S0 + G, LATE, NT>(lds, tw, kbase, pm, tid, next, NoSrc{},
                                                                                       tile_words);
     } else {
-        if constexpr (FSYNC) __syncthreads();
+        if constexpr (FSYNC) FHE_BARRIER();
     }
 }
 template <int LOGM, int T, int GM = GMAX, bool TWPF = true, bool FSYNC = true, int NARROW = 0, class Src = NoSrc,
@@ -385,7 +392,7 @@ __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ 
 // Per-lane twiddles of the non-UNIFORM (early) inverse passes, fetched ahead like FwdTw.
 template <int G, int LOGM, int V0, int T>
 struct InvTw {
-    static constexpr bool UNIFORM = V0 >= 6;
+    static constexpr bool UNIFORM = V0 >= 6 || (FHE_SENS & 64);
     static constexpr int NG = (1 << (LOGM - G)) > T ? (1 << (LOGM - G)) / T : 1;
     u64x2 z[UNIFORM ? 1 : NG][UNIFORM ? 1 : (1 << G) - 1];
 };
@@ -449,7 +456,7 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
                                          const InvTw<G, LOGM, V0, T> &tw_regs) {
     constexpr uint32_t R = 1u << G;
     constexpr uint32_t ngroups = 1u << (LOGM - G);
-    constexpr bool UNIFORM = V0 >= 6;
+    constexpr bool UNIFORM = V0 >= 6 || (FHE_SENS & 64);
     const uint32_t n = 1u << logn;
 #pragma unroll
     for (uint32_t g0 = 0; g0 < ngroups; g0 += T) {
@@ -577,10 +584,10 @@ __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ 
         if constexpr (wave_local_exchange(V0, G, V0 + G, inv_plan_g<LOGM, PASS + 1>()))
             wave_sync();
         else
-            __syncthreads();
+            FHE_BARRIER();
         ntt_inv_lds<LOGM, T, PASS + 1, V0 + G, NARROW>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, next);
     } else {
-        __syncthreads();
+        FHE_BARRIER();
     }
 }
 
@@ -681,7 +688,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
             tile_to_lds<CH, M, T>(lds, src, tid, [&](u64 v) { return reduce_u64(v, md); });
         else
             tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
-        __syncthreads();
+        FHE_BARRIER();
         ntt_inv_lds<LOGM, T, 0, 0, NARROW>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1], tw0);
         if (whole)
             lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
@@ -868,7 +875,7 @@ __global__ void __launch_bounds__(512, 4)
     fwd_tw_load(tw3, twr, 1, tid);
     wave_sync();
     fwd_pass<4, LOGM, 9, T, true, NB, NoSrc, 1, true>(lds, twr, 1, pm, tid, tw3);
-    __syncthreads();
+    FHE_BARRIER();
     if constexpr (NARROW) {  // < 16p -> canonical
         const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
         lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) {
@@ -992,7 +999,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     const u64x2 *twr = itw + ((u64)r << logn);
     InvTwFirst<LOGM, T> tw0;
     inv_tw_load(tw0, twr, logn, sub, tid);   // in flight across the barrier (the loader needs the registers)
-    __syncthreads();
+    FHE_BARRIER();
     u64 *dst = out + ((u64)slot * nb + b) * pk + roff;
     // (a block-uniform branch between the narrow and the general inverse passes inside one kernel was measured:
     // 128 VGPRs, spills and twice the code -- 2 % slower; hence one launch per row group)
@@ -1201,7 +1208,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
             tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return lift((v >> sh) & mask_i); });
         }
         FHE_TS(1);
-        __syncthreads();
+        FHE_BARRIER();
         FHE_TS(2);
         if constexpr (PREFETCH) {
             if (ii + 1 < nloop) {
@@ -1227,7 +1234,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                     kq[4 * c] = a0[ci], kq[4 * c + 1] = a0s[ci], kq[4 * c + 2] = a1[ci], kq[4 * c + 3] = a1s[ci];
                 }
                 FHE_TS(3);
-                __syncthreads();
+                FHE_BARRIER();
                 FHE_TS(4);
             }
 #pragma unroll
@@ -1264,7 +1271,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
         // (wave-contiguous chunk ownership, which makes this barrier and the one before the MAC wave-local as
         // well, was measured: nothing beyond what the late pass plan already gives)
         FHE_TS(5);
-        __syncthreads();
+        FHE_BARRIER();
         FHE_TS(6);
     }
     const uint32_t tid = opaque(tid0);  // keeps the epilogue's address arithmetic below the digit loop
@@ -1394,7 +1401,7 @@ __global__ void __launch_bounds__(ks_pair_threads_c(LOGN, CPT), CPT == 8 ? 4 : 2
     auto round = [&](auto ntc) {
         constexpr int NT = decltype(ntc)::value;
         const uint32_t tid = opaque(tid0);
-        __syncthreads();   // the round's tiles are complete
+        FHE_BARRIER();   // the round's tiles are complete
         if constexpr (NARROW) {
             if (since + NT > 8) {   // (block-uniform) fold the accumulators back below 2p
                 const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
@@ -1417,7 +1424,7 @@ __global__ void __launch_bounds__(ks_pair_threads_c(LOGN, CPT), CPT == 8 ? 4 : 2
             kq[0] = reinterpret_cast<const u64x2 *>(k0 + koff0)[ci], kq[1] = reinterpret_cast<const u64x2 *>(k0s + koff0)[ci];
             kq[2] = reinterpret_cast<const u64x2 *>(k1 + koff0)[ci], kq[3] = reinterpret_cast<const u64x2 *>(k1s + koff0)[ci];
         }
-        __syncthreads();
+        FHE_BARRIER();
         // MAC of tile d; STAGE: the digit `nxt` takes the tile in the coming round and its lifted row is written
         // into every chunk right after the chunk has been consumed
         auto mac_tile = [&](int d, auto stc, uint32_t nxt) {
@@ -1595,7 +1602,7 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
             lds[padi(2 * ci)] = v[0].x;
             lds[padi(2 * ci + 1)] = v[0].y;
         }
-        __syncthreads();
+        FHE_BARRIER();
         // (NARROW: the folded loader stages leave values below 4p)
         ntt_fwd_lds<LOGM, T, KS_GMAX, false, true, (NARROW ? 4 : 0), NoSrc, KS_LATE>(lds, twr, NS + sub, pm, tid);
         const u64 koff = ((u64)i * lk + j) * N + (u64)sub * M;
@@ -1614,7 +1621,7 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
             acc1_lds[ci] = a;
             if (c & 1) sched_fence();
         }
-        __syncthreads();
+        FHE_BARRIER();
     }
     const uint32_t tid = opaque(tid0);
     const u64 ooff = (u64)b * out_poly_stride + (u64)j * N + (u64)sub * M;

@@ -31,7 +31,8 @@ struct DevMod {  // layout == hostmath.hpp ModConsts
     u64 np, np2;  // 2^64 - p, 2^64 - 2p (loaded, so the compiler cannot fold x + np back into x - p)
 };
 
-// FHE_SENS: timing-sensitivity builds only (WRONG results; tools/ab_sens.sh; bits 3 / 4: the pseudo-Mersenne fold and
+// FHE_SENS: timing-sensitivity builds only (WRONG results; tools/ab_sens.sh; bits 5 / 6 in kernels.hpp: no workgroup
+// barriers, scalar twiddles everywhere; bits 3 / 4: the pseudo-Mersenne fold and
 // q * c - (q << b) for 2^b - c primes, both slower in the kernels): bit 0 the approximate quotient from two
 // partial products, bit 1 every high product from two, bit 2 the lazy Shoup low products from one.
 #ifndef FHE_SENS

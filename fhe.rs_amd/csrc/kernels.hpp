@@ -954,6 +954,14 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         mac2_wide62(x00, x11, x01, x10, hi, lo);
         return barrett_reduce_wide_lazy(hi, lo, md);
     };
+    // the first inverse pass's per-lane twiddles (56 VGPRs at N = 8192) are requested half-way through the products,
+    // when half of the operand registers are free again: their L2 latency then hides behind the remaining
+    // products and the barrier instead of following it (FHE_TENSOR_TW_EARLY=0: after the products, as before)
+#ifndef FHE_TENSOR_TW_EARLY
+#define FHE_TENSOR_TW_EARLY 1
+#endif
+    const u64x2 *twr = itw + ((u64)r << logn);
+    InvTwFirst<LOGM, T> tw0;
     if constexpr (CH > 0) {
         if (slot != 1) {
             // c0 = c00*c10 / c2 = c01*c11: two operand rows, all CH chunks of both in flight at once
@@ -967,6 +975,10 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
             }
 #pragma unroll
             for (int c = 0; c < CH; c++) {
+                if (FHE_TENSOR_TW_EARLY && CH > 1 && c == CH / 2) {
+                    sched_fence();
+                    inv_tw_load(tw0, twr, logn, sub, tid);
+                }
                 const uint32_t i = 2 * (c * T + tid);
                 lds[padi(i)] = mul_mod_lazy(va[c].x, vb[c].x, md);
                 lds[padi(i + 1)] = mul_mod_lazy(va[c].y, vb[c].y, md);
@@ -986,6 +998,10 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
             }
 #pragma unroll
             for (int c = 0; c < HALF; c++) {
+                if (FHE_TENSOR_TW_EARLY && CH > 1 && h + HALF >= CH && c == HALF / 2) {   // (last batch, half done)
+                    sched_fence();
+                    inv_tw_load(tw0, twr, logn, sub, tid);
+                }
                 const uint32_t i = 2 * ((h + c) * T + tid);
                 lds[padi(i)] = prod(v00[c].x, v01[c].x, v10[c].x, v11[c].x);
                 lds[padi(i + 1)] = prod(v00[c].y, v01[c].y, v10[c].y, v11[c].y);
@@ -996,9 +1012,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     } else {
         for (uint32_t i = tid; i < M; i += T) lds[padi(i)] = prod(a0[i], a1[i], b0[i], b1[i]);
     }
-    const u64x2 *twr = itw + ((u64)r << logn);
-    InvTwFirst<LOGM, T> tw0;
-    inv_tw_load(tw0, twr, logn, sub, tid);   // in flight across the barrier (the loader needs the registers)
+    if (!(FHE_TENSOR_TW_EARLY && CH > 1)) inv_tw_load(tw0, twr, logn, sub, tid);   // in flight across the barrier
     FHE_BARRIER();
     u64 *dst = out + ((u64)slot * nb + b) * pk + roff;
     // (a block-uniform branch between the narrow and the general inverse passes inside one kernel was measured:

@@ -1100,6 +1100,11 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
 // F/bfv/ops/mul.rs:224-225; rotation adds substitute(c0) to c0 only); canonical outputs.
 // ks_threads_c(LOGN) threads; thread t owns the 16-byte chunks {c*T + t}, c < CH (or the single
 // coefficient t when the row is smaller than one chunk per thread).
+// (FHE_KS_TWPF=true: the transforms' per-lane twiddles requested one pass ahead at N = 8192 -- 112 VGPRs, no scratch,
+// and no change in same-box A/B, profiles/r02_ks_twpf_ab.txt)
+#ifndef FHE_KS_TWPF
+#define FHE_KS_TWPF false
+#endif
 template <int LOGN, bool NARROW = false, int GM = KS_GMAX>
 __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
@@ -1239,7 +1244,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
             // transform, so their L2 latency is spent waiting for the other waves, not after them
             constexpr bool KPF = PREFETCH && CH >= 2;
             // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
-            ntt_fwd_lds<LOGN, T, GM, false, !KPF, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
+            ntt_fwd_lds<LOGN, T, GM, FHE_KS_TWPF && LOGN == 13, !KPF, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
             u64x2 kq[KPF ? 8 : 1];
             if constexpr (KPF) {
 #pragma unroll

@@ -75,8 +75,22 @@ enum { PRO_NONE = 0, PRO_REDUCE = 1 };
 // LDS padding: one extra u64 every 16 keeps the 16-element-strided accesses of the last
 // radix pass (lane stride 128 B) on distinct banks (ds_read_b64: 64 banks x 4 B, conflicts
 // are per 32-lane half; 17*l mod 32 is a bijection).
+// Round 2: in a model of 32 bank pairs per 32-lane half this layout is two-way conflicted in EVERY access pattern of
+// the passes (a unit-stride half spans 34 words) -- the SQ counters agree: half of all LDS cycles are conflict cycles --
+// while i + 3 * (i >> 5) (FHE_LDS_PAD=3; tools/lds_pad_search.py enumerates the candidates) is conflict-free in seven
+// of the nine patterns and keeps pad(base + off) = pad(base) + pad(off).  Built, bit-exact, and measured in a
+// drift-cancelling ABBA run: every kernel within +-1 % (profiles/r02_lds_pad_ab.txt).  LDS time is not on these
+// kernels' critical path; the round-1 layout (2 KiB smaller per tile) stays.
+#ifndef FHE_LDS_PAD
+#define FHE_LDS_PAD 1
+#endif
+#if FHE_LDS_PAD == 3
+FHE_HD uint32_t padi(uint32_t i) { return i + 3 * (i >> 5); }
+FHE_HD uint32_t lds_words(uint32_t n) { return n + 3 * (n >> 5) + 2; }
+#else
 FHE_HD uint32_t padi(uint32_t i) { return i + (i >> 4); }
 FHE_HD uint32_t lds_words(uint32_t n) { return n + (n >> 4) + 2; }
+#endif
 
 constexpr int GMAX = 4;  // radix-16: up to four butterfly stages per LDS round trip
 
@@ -1374,7 +1388,7 @@ __global__ void __launch_bounds__(ks_pair_threads_c(LOGN, CPT), CPT == 8 ? 4 : 2
     constexpr int N = 1 << LOGN;
     constexpr int CH = tile_chunks_c(LOGN, T);
     static_assert(CH > 0, "ks_pair_kernel needs at least one 16-byte chunk per thread");
-    constexpr uint32_t TW = N + (N >> 4) + 2;   // u64 words per tile (= lds_words(N))
+    constexpr uint32_t TW = FHE_LDS_PAD == 3 ? N + 3 * (N >> 5) + 2 : N + (N >> 4) + 2;   // u64 words per tile (= lds_words(N))
     const uint32_t tid0 = threadIdx.x;
     const uint32_t b = to_sgpr(blockIdx.x / lk), j = blockIdx.x - b * lk;
     const DevMod md = mods[j];

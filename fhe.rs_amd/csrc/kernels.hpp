@@ -98,6 +98,9 @@ constexpr int GMAX = 4;  // radix-16: up to four butterfly stages per LDS round 
 // scalar and the twiddle loads become s_load (no VGPRs, no per-lane address math).
 // Compiler scheduling fence: keeps a batch of loads (and the registers they pin) from being
 // hoisted across it.  No instruction is emitted.
+// (s_setprio 3 from a workgroup's start until its operand loads are issued -- so that a freshly dispatched workgroup
+// gets its loads out ahead of its CU neighbour's arithmetic -- was measured: forward NTT unchanged, inverse NTT 11 %
+// and tensor+iNTT 5 % slower, profiles/r02_setprio_ab.txt.)
 __device__ __forceinline__ void sched_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);

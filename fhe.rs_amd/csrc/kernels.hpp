@@ -1262,10 +1262,16 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
             constexpr bool KPF = PREFETCH && CH >= 2;
             // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
             ntt_fwd_lds<LOGN, T, GM, FHE_KS_TWPF && LOGN == 13, !KPF, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
-            u64x2 kq[KPF ? 8 : 1];
+            // (all four chunks prefetched -- 118 VGPRs, no scratch: no change; three: 2 % slower.  ABBA runs in
+            // profiles/r02_ks_kpf_ab.txt: the key words' latency is not what the MAC waits for)
+#ifndef FHE_KS_KPF_CHUNKS
+#define FHE_KS_KPF_CHUNKS 2
+#endif
+            constexpr int KPFN = KPF ? (FHE_KS_KPF_CHUNKS < CH ? FHE_KS_KPF_CHUNKS : CH) : 0;   // chunks whose key words are prefetched
+            u64x2 kq[KPF ? 4 * KPFN : 1];
             if constexpr (KPF) {
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
+                for (int c = 0; c < KPFN; c++) {
                     const uint32_t ci = c * T + tid;
                     kq[4 * c] = a0[ci], kq[4 * c + 1] = a0s[ci], kq[4 * c + 2] = a1[ci], kq[4 * c + 3] = a1s[ci];
                 }
@@ -1277,7 +1283,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
             for (int c = 0; c < CH; c++) {
                 const uint32_t ci = c * T + tid;
                 u64x2 q0, q0s, q1, q1s;
-                if (KPF && c < 2) {
+                if (KPF && c < KPFN) {
                     q0 = kq[KPF ? 4 * c : 0], q0s = kq[KPF ? 4 * c + 1 : 0], q1 = kq[KPF ? 4 * c + 2 : 0], q1s = kq[KPF ? 4 * c + 3 : 0];
                 } else {
                     q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];

@@ -902,6 +902,9 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
                             const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s,
                             const u64 *xhat, u64 xhat_stride) {
     const Ctx &kc = *k_.ksk_ctx;
+    // timing experiment only (WRONG results): every polynomial of the launch reads the first one's rows and writes
+    // the first one's outputs, so the kernel's digit rows / addends / outputs stay in L2 (tools/ab_env.sh)
+    if (debug_flag("FHE_DEBUG_KS_NOMEM")) p_stride = out_stride = a_stride = xhat_stride = 0;
 #ifdef FHE_KS_EXPERIMENTS
     if constexpr (k::ks_pair_ok_c(LOGN)) {
         const uint32_t lm = k_.lift_mode();   // 1 / 2: RNS digits below 2 / 4 q_j (what the pair kernel lifts)

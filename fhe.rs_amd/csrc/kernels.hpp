@@ -1316,6 +1316,10 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
         FHE_BARRIER();
         FHE_TS(6);
     }
+    // (FHE_DEBUG_KS_NOMEM -- every polynomial aliased to the first: rows, addends and outputs out of L2 -- makes this
+    // kernel 11 % faster at C2: what its one workgroup per CU cannot hide.  Requesting the addends during the last
+    // digit, into the row-prefetch registers that are idle then, was built: those 16 registers stay live through the
+    // last MAC and spill (84-164 B of scratch); not kept.)
     const uint32_t tid = opaque(tid0);  // keeps the epilogue's address arithmetic below the digit loop
     const u64 ooff = (u64)b * out_poly_stride + (u64)j * N;
     const u64 aoff = (u64)b * addend_poly_stride + (u64)j * N;

@@ -45,6 +45,25 @@ inline bool debug_sync() {
     return on;
 }
 inline bool debug_flag(const char *name) { return std::getenv(name) != nullptr; }
+// compute units of a device (persistent launches size their grids with it)
+inline int device_cus(int device) {
+#if defined(FHE_HOST_EMULATION)
+    (void)device;
+    return 3;   // (few, so that the emulated suite runs several items through one workgroup)
+#else
+    static std::mutex mu;
+    static std::vector<int> cache;
+    std::lock_guard<std::mutex> g(mu);
+    if (device < 0) return 1;
+    if ((size_t)device >= cache.size()) cache.resize((size_t)device + 1, 0);
+    if (!cache[(size_t)device]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
+        cache[(size_t)device] = n;
+    }
+    return cache[(size_t)device];
+#endif
+}
 
 // ------------------------------------------------------------------------ profiling ----
 // Optional per-kernel timing with HIP events recorded on the launching stream
@@ -946,12 +965,22 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     // N = 16384 (ks_fused_kernel's GM): FHE_KS14_PLAN = 8 radix-8 passes (24 VGPRs spilled), 4 radix-4 passes,
     // unset / anything else: radix-8 while the twiddles are scalar, radix-4 after (GM_MIXED)
     static const int plan14 = std::getenv("FHE_KS14_PLAN") ? std::atoi(std::getenv("FHE_KS14_PLAN")) : 0;
+    // N = 8192: one workgroup owns a CU (132 KiB of LDS), so the items of a launch go to one resident workgroup per
+    // CU, each prefetching its next item's first row across its epilogue (FHE_KS_PERSIST=0: one workgroup per item)
+    static const int ks_persist = std::getenv("FHE_KS_PERSIST") ? std::atoi(std::getenv("FHE_KS_PERSIST")) : 1;
+    unsigned ks_grid = (unsigned)(npolys * kc.L);
+#if defined(FHE_HOST_EMULATION)
+    constexpr bool ks_persist_size = true;   // (every size, so that the emulated suite walks the item loop)
+#else
+    constexpr bool ks_persist_size = LOGN == 13;
+#endif
+    if (ks_persist_size && ks_persist > 0) ks_grid = std::min<unsigned>(ks_grid, (unsigned)(device_cus(kc.device) * ks_persist));
 #define FHE_KS_LAUNCH(NW, GMV)                                                                                        \
     allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV>), lds);                                                          \
-    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV>), dim3((unsigned)(npolys * kc.L)),              \
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV>), dim3(ks_grid),                                \
                dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,       \
                k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,               \
-               k_.digit_arg(), xhat, xhat_stride)
+               k_.digit_arg(), xhat, xhat_stride, (uint32_t)(npolys * kc.L))
     if constexpr (LOGN == 14) {   // (radix-4 passes at N = 8192 measured slower: 0.559 vs 0.532 ms per launch)
         if (plan14 == 4) {
             if (narrow) {

@@ -1129,7 +1129,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                     u64 addend_poly_stride, const u64 *__restrict__ k0, const u64 *__restrict__ k0s,
                     const u64 *__restrict__ k1, const u64 *__restrict__ k1s, const DevMod *__restrict__ mods,
                     const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk, uint32_t digit_arg,
-                    const u64 *__restrict__ xhat, u64 xhat_poly_stride) {
+                    const u64 *__restrict__ xhat, u64 xhat_poly_stride, uint32_t total) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ks_threads_c(LOGN);
     constexpr int N = 1 << LOGN;
@@ -1143,7 +1143,21 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     const uint32_t tid0 = threadIdx.x;
     // (an XCD-aware order that puts the lk workgroups of one polynomial on one L2, as tensor_intt_kernel
     // does, was measured: no change -- this kernel is nowhere near the HBM limit)
-    const uint32_t b = to_sgpr(blockIdx.x / lk), j = blockIdx.x - b * lk;
+    // The (ciphertext, key modulus) items of a launch are dealt round-robin to the gridDim.x workgroups (`total` of
+    // them; the host launches one workgroup per item except at N = 8192, where a workgroup owns its CU: there
+    // gridDim.x is the number of CUs and, while an item's result is on its way out, the next item's first digit row
+    // is already coming in -- neither that load nor a workgroup launch sits between two items).
+    u64x2 pre[ks_acc1_in_lds_c(LOGN) ? CH : 1];
+    bool have_pre = false;   // (block-uniform) `pre` already holds this item's first digit row
+#if defined(FHE_HOST_EMULATION)
+    constexpr bool ITEM_LOOP = true;    // (every size, so that the emulated suite walks the loop)
+#else
+    constexpr bool ITEM_LOOP = LOGN == 13;
+#endif
+    uint32_t item = blockIdx.x;
+    if (item >= total) return;
+    do {
+    const uint32_t b = to_sgpr(item / lk), j = item - b * lk;
     const DevMod md = mods[j];
     const u64 p = md.p, p2 = md.p2;
     const PM pm = make_pm(md);
@@ -1216,9 +1230,8 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     constexpr bool PREFETCH = ks_acc1_in_lds_c(LOGN);   // (needs the VGPRs the LDS accumulators free)
     // (Feeding the first pass from these registers instead of staging the lifted row in LDS was
     // measured: 2.5 % slower -- the extra register shuffling outweighs the saved barrier.)
-    u64x2 pre[PREFETCH ? CH : 1];
     if constexpr (PREFETCH) {
-        if (nloop > 0) {
+        if (nloop > 0 && !have_pre) {
             const u64x2 *first = reinterpret_cast<const u64x2 *>(src0 + (u64)digit_of(0) * dstride);
 #pragma unroll
             for (int c = 0; c < CH; c++) pre[c] = first[c * T + tid0];
@@ -1321,6 +1334,21 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     // digit, into the row-prefetch registers that are idle then, was built: those 16 registers stay live through the
     // last MAC and spill (84-164 B of scratch); not kept.)
     const uint32_t tid = opaque(tid0);  // keeps the epilogue's address arithmetic below the digit loop
+    have_pre = false;
+    if constexpr (PREFETCH && ITEM_LOOP) {
+        const uint32_t nitem = item + gridDim.x;
+        if (nitem < total) {   // the next item's first digit row (the same selection as at the top of the loop)
+            const uint32_t nb = nitem / lk, nj = nitem - nb * lk;
+            const bool nown = xhat != nullptr && digit_shift_bits == 0 && nj < ndigits;
+            if (ndigits - (nown ? 1u : 0u) > 0) {
+                const uint32_t nd = (nown && nj == 0) ? 1u : 0u;
+                const u64x2 *first = reinterpret_cast<const u64x2 *>(pin + (u64)nb * src_poly_stride + (u64)nd * dstride);
+#pragma unroll
+                for (int c = 0; c < CH; c++) pre[c] = first[c * T + tid];
+                have_pre = true;
+            }
+        }
+    }
     const u64 ooff = (u64)b * out_poly_stride + (u64)j * N;
     const u64 aoff = (u64)b * addend_poly_stride + (u64)j * N;
     if constexpr (CH > 0) {
@@ -1356,6 +1384,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
         out0[ooff + tid] = r0;
         out1[ooff + tid] = r1;
     }
+    } while (ITEM_LOOP && (item += gridDim.x) < total);
 }
 
 // ------------------------------------------- fused key switch, two digits per round ----

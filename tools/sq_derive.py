@@ -2,7 +2,9 @@
 """Derived per-kernel metrics from the SQ counter passes of tools/collect_sq.sh (summary via the raw CSVs):
 instructions per wave, valu_pipe_floor (SQ_INSTS_VALU x 2 cycles / (kernel cycles x 1024 SIMDs); kernel cycles =
 SQ_BUSY_CYCLES / 32), wave_wait_inst_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, wave_wait_frac = SQ_WAIT_ANY /
-SQ_WAVE_CYCLES, waves resident per SIMD = SQ_WAVE_CYCLES x 4 / (kernel cycles x 1024)  (SQ_WAVE_CYCLES in quad-cycles).
+SQ_WAVE_CYCLES, waves resident per SIMD = SQ_WAVE_CYCLES x 4 / (kernel cycles x 1024)  (SQ_WAVE_CYCLES in quad-cycles).  Kernels with resident workgroups
+(ks_fused_kernel at N = 8192 since round 2: one workgroup per CU walks 8 items at C2) have fewer, longer waves:
+their instructions per wave are per 8 items, not per item.
 usage: sq_derive.py <dir> > profiles/<round>_sq_derived.json"""
 import collections, csv, glob, json, os, sys
 

@@ -972,7 +972,7 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
 #if defined(FHE_HOST_EMULATION)
     constexpr bool ks_persist_size = true;   // (every size, so that the emulated suite walks the item loop)
 #else
-    constexpr bool ks_persist_size = LOGN == 13;
+    constexpr bool ks_persist_size = LOGN == 13 || (FHE_KS_PERSIST14 && LOGN == 14);
 #endif
     if (ks_persist_size && ks_persist > 0) ks_grid = std::min<unsigned>(ks_grid, (unsigned)(device_cus(kc.device) * ks_persist));
 #define FHE_KS_LAUNCH(NW, GMV)                                                                                        \

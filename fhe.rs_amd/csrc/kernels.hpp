@@ -1122,6 +1122,11 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
 #ifndef FHE_KS_TWPF
 #define FHE_KS_TWPF false
 #endif
+// (FHE_KS_PERSIST14=1: resident workgroups at N = 16384 as well -- no row-prefetch registers there, so nothing to
+// overlap: C3 relinearise 108.1-109.7 k against 111.0-111.3 k ops/s, profiles/r02_ks_persist_ab.txt)
+#ifndef FHE_KS_PERSIST14
+#define FHE_KS_PERSIST14 0
+#endif
 template <int LOGN, bool NARROW = false, int GM = KS_GMAX>
 __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
@@ -1152,7 +1157,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
 #if defined(FHE_HOST_EMULATION)
     constexpr bool ITEM_LOOP = true;    // (every size, so that the emulated suite walks the loop)
 #else
-    constexpr bool ITEM_LOOP = LOGN == 13;
+    constexpr bool ITEM_LOOP = LOGN == 13 || (FHE_KS_PERSIST14 && LOGN == 14);
 #endif
     uint32_t item = blockIdx.x;
     if (item >= total) return;

@@ -22,6 +22,15 @@ def test_ntt(fhe, n):
     cases.case_ntt(fhe, False, n, batch=2 if n < 1024 else 1)
 
 
+@pytest.mark.parametrize("n", [256, 1024])
+def test_ntt_narrow_moduli(fhe, n):
+    """Moduli below 2^60: the bound-tracked forward / inverse passes (radix-16 groups at these sizes), whose
+    range checks trap in this build."""
+    from fhe_oracle.zq import generate_prime
+    mods = [generate_prime(60, 2 * n, 1 << 60), generate_prime(50, 2 * n, 1 << 50), generate_prime(36, 2 * n, 1 << 36)]
+    cases.case_ntt(fhe, False, n, moduli=mods, batch=2, seed=5)
+
+
 def test_ntt_explicit_tables(fhe):
     cases.case_ntt_explicit_tables(fhe, False)
 

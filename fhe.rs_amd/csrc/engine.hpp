@@ -39,12 +39,25 @@ inline void require(bool cond, int code, const char *msg) {
     if (!cond) throw StatusError(code, msg);
 }
 
-// FHE_DEBUG_SYNC=1 synchronises after every kernel launch (debugging aid only).
+// The release library reads NO environment variable: FHE_LAB_FLAG / FHE_LAB_INT are compile-time constants there
+// (the variable names do not even reach the binary).  -DFHE_LAB builds (A/B tooling, never loaded by the package)
+// read FHE_LAB_* switches that choose between exact kernel variants; FHE_LAB_SYNC synchronises after every launch.
+#if defined(FHE_LAB)
+inline bool lab_env_flag(const char *name) { return std::getenv(name) != nullptr; }
+inline int lab_env_int(const char *name, int dflt) {
+    const char *e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+#define FHE_LAB_FLAG(name) ::fhe::lab_env_flag("FHE_LAB_" name)
+#define FHE_LAB_INT(name, dflt) ::fhe::lab_env_int("FHE_LAB_" name, dflt)
+#else
+#define FHE_LAB_FLAG(name) false
+#define FHE_LAB_INT(name, dflt) (dflt)
+#endif
 inline bool debug_sync() {
-    static const bool on = std::getenv("FHE_DEBUG_SYNC") != nullptr;
+    static const bool on = FHE_LAB_FLAG("SYNC");
     return on;
 }
-inline bool debug_flag(const char *name) { return std::getenv(name) != nullptr; }
 // compute units of a device (persistent launches size their grids with it)
 inline int device_cus(int device) {
 #if defined(FHE_HOST_EMULATION)
@@ -415,6 +428,16 @@ inline void allow_big_lds(K kernel, size_t bytes) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
+#if defined(FHE_LAB)
+// rejected kernel variants, selected by FHE_LAB_* environment switches in lab builds only (lab/lab_engine.hpp)
+struct Ksk;
+inline bool lab_try_ntt_fwd(const Ctx &c, unsigned rows_total, bool narrow, const u64 *in, u64 *out, const k::RowMap &map,
+                            uint32_t prologue, hipStream_t s);
+template <int LOGN>
+inline bool lab_try_ks_pair(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride, const u64 *a0,
+                            const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s);
+#endif
+
 template <bool INV, bool NARROW = false>
 inline void launch_ntt_lds(const char *name, uint32_t logm, unsigned grid, hipStream_t s, const u64 *in, u64 *out,
                            const k::RowMap &map, const DevMod *mods, const k::u64x2 *tw, const k::u64x2 *ninv,
@@ -441,46 +464,15 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     if (npolys == 0 || map.rows == 0) return;
     const uint32_t logn = (uint32_t)c.logn;
     const unsigned rows_total = (unsigned)(npolys * map.rows);
-    // timing experiment only (WRONG results): every polynomial of the launch reads and writes the first one's rows, so
-    // the kernel runs out of L2 -- what is left is its arithmetic / LDS time (tools/ab_nomem.sh)
-    if (debug_flag("FHE_DEBUG_NTT_NOMEM")) map.src_poly_stride = map.dst_poly_stride = 0;
     if (logn <= 14) {
         if (!inverse) {
             // every modulus of the launch below 2^60: the transform without per-stage conditional subtractions
-            bool narrow = !debug_flag("FHE_NO_NARROW");
+            bool narrow = !FHE_LAB_FLAG("NO_NARROW");
             for (uint32_t r = 0; r < map.rows; r++)
                 narrow = narrow && (c.root->moduli[(size_t)((int32_t)(map.row_begin + r) + map.mod_offset)] >> 60) == 0;
-            static const bool swap_variant = std::getenv("FHE_NTT_SWAP") != nullptr && std::atoi(std::getenv("FHE_NTT_SWAP")) != 0;
-            if (swap_variant && logn == 13) {   // measured alternative: in-wave stages by lane exchange (kernels.hpp)
-                const size_t lds = k::lds_words(1u << 13) * sizeof(u64);
-                if (narrow) {
-                    allow_big_lds((k::ntt_fwd_swap_kernel<true>), lds);
-                    FHE_LAUNCH("ntt_fwd", (k::ntt_fwd_swap_kernel<true>), dim3(rows_total), dim3(512), lds, s, in, out, map,
-                               c.dmods(), c.dtw(), prologue);
-                } else {
-                    allow_big_lds((k::ntt_fwd_swap_kernel<false>), lds);
-                    FHE_LAUNCH("ntt_fwd", (k::ntt_fwd_swap_kernel<false>), dim3(rows_total), dim3(512), lds, s, in, out, map,
-                               c.dmods(), c.dtw(), prologue);
-                }
-                return;
-            }
-            static const int cpt8 = std::getenv("FHE_NTT_CPT8") ? std::atoi(std::getenv("FHE_NTT_CPT8")) : 0;
-            if (cpt8 && logn == 13) {   // measured alternative: 8 coefficients per thread, 8 waves per SIMD (kernels.hpp)
-                const size_t lds = k::lds_words(1u << 13) * sizeof(u64);
-#define FHE_NTT8(NW, GMV)                                                                                          \
-    do {                                                                                                           \
-        allow_big_lds((k::ntt_fwd8_kernel<NW, GMV>), lds);                                                         \
-        FHE_LAUNCH("ntt_fwd", (k::ntt_fwd8_kernel<NW, GMV>), dim3(rows_total), dim3(1024), lds, s, in, out, map,   \
-                   c.dmods(), c.dtw(), prologue);                                                                  \
-    } while (0)
-                if (cpt8 == 3) {
-                    if (narrow) FHE_NTT8(true, 3); else FHE_NTT8(false, 3);
-                } else {
-                    if (narrow) FHE_NTT8(true, k::GM_MIXED); else FHE_NTT8(false, k::GM_MIXED);
-                }
-#undef FHE_NTT8
-                return;
-            }
+#if defined(FHE_LAB)
+            if (lab_try_ntt_fwd(c, rows_total, narrow, in, out, map, prologue, s)) return;   // lab/lab_engine.hpp
+#endif
             if (narrow)
                 launch_ntt_lds<false, true>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(),
                                             logn, prologue);
@@ -488,7 +480,7 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
                 launch_ntt_lds<false>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(), logn,
                                       prologue);
         } else {
-            bool narrow = !debug_flag("FHE_NO_NARROW");
+            bool narrow = !FHE_LAB_FLAG("NO_NARROW");
             for (uint32_t r = 0; r < map.rows; r++)
                 narrow = narrow && (c.root->moduli[(size_t)((int32_t)(map.row_begin + r) + map.mod_offset)] >> 60) == 0;
             if (narrow)
@@ -574,7 +566,7 @@ inline void launch_tensor_intt_rows(const Ctx &e, const k::TensorSrc &ts, u64 *o
 
 inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s) {
     // maximal runs of rows of the same kind (moduli below 2^60 or not): one launch each
-    const bool allow = !debug_flag("FHE_NO_NARROW");
+    const bool allow = !FHE_LAB_FLAG("NO_NARROW");
     uint32_t r0 = 0;
     while (r0 < e.L) {
         const bool nr = allow && (e.moduli[r0] >> 60) == 0;
@@ -904,70 +896,25 @@ inline void ksk_validate(const Ctx &ct_ctx, const Ctx &ksk_ctx, size_t ndigits, 
     }
 }
 
-#ifdef FHE_KS_EXPERIMENTS
-// Experiment builds only (kernels.hpp, ks_pair_kernel): FHE_KS_VARIANT = 0 (default) ks_fused_kernel, 1 two digits
-// per round, 2 the same with 16 coefficients per thread, 3 one digit per round on the pair kernel's structure.
-inline int ks_variant() {
-    static const int v = [] {
-        const char *e = std::getenv("FHE_KS_VARIANT");
-        return e ? std::atoi(e) : 0;
-    }();
-    return v;
-}
-#endif
-
 template <int LOGN>
 inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
                             const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s,
                             const u64 *xhat, u64 xhat_stride) {
     const Ctx &kc = *k_.ksk_ctx;
-    // timing experiment only (WRONG results): every polynomial of the launch reads the first one's rows and writes
-    // the first one's outputs, so the kernel's digit rows / addends / outputs stay in L2 (tools/ab_env.sh)
-    if (debug_flag("FHE_DEBUG_KS_NOMEM")) p_stride = out_stride = a_stride = xhat_stride = 0;
-#ifdef FHE_KS_EXPERIMENTS
-    if constexpr (k::ks_pair_ok_c(LOGN)) {
-        const uint32_t lm = k_.lift_mode();   // 1 / 2: RNS digits below 2 / 4 q_j (what the pair kernel lifts)
-        if (ks_variant() >= 1 && ks_variant() <= 3 && k_.ndigits >= 2 && (lm == 1 || lm == 2)) {
-            const size_t lds2 = 2 * k::lds_words(1u << LOGN) * sizeof(u64);
-            bool nrw = !debug_flag("FHE_NO_NARROW");
-            for (u64 q : kc.moduli) nrw = nrw && (q >> 60) == 0;
-#define FHE_KS_PAIR_LAUNCH(NW, CPT, ...)                                                                             \
-    allow_big_lds((k::ks_pair_kernel<LOGN, NW, CPT, ##__VA_ARGS__>), lds2);                                          \
-    FHE_LAUNCH("key_switch_fused", (k::ks_pair_kernel<LOGN, NW, CPT, ##__VA_ARGS__>), dim3((unsigned)(npolys * kc.L)), \
-               dim3(k::ks_pair_threads_c(LOGN, CPT)), lds2, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride,    \
-               k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L)
-            if (ks_variant() == 3) {
-                if (nrw) {
-                    FHE_KS_PAIR_LAUNCH(true, 8, 1);
-                } else {
-                    FHE_KS_PAIR_LAUNCH(false, 8, 1);
-                }
-            } else if (ks_variant() == 2 && LOGN >= 11) {
-                if (nrw) {
-                    FHE_KS_PAIR_LAUNCH(true, 16);
-                } else {
-                    FHE_KS_PAIR_LAUNCH(false, 16);
-                }
-            } else if (nrw) {
-                FHE_KS_PAIR_LAUNCH(true, 8);
-            } else {
-                FHE_KS_PAIR_LAUNCH(false, 8);
-            }
-#undef FHE_KS_PAIR_LAUNCH
-            return;
-        }
-    }
+#if defined(FHE_LAB)
+    if (lab_try_ks_pair<LOGN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s)) return;   // lab/lab_engine.hpp
 #endif
     const size_t lds = (k::lds_words(1u << LOGN) + (k::ks_acc1_in_lds_c(LOGN) ? (size_t)1 << LOGN : 0)) * sizeof(u64);
     // key moduli below 2^60: the transform runs without most conditional subtractions (fwd_butterfly_narrow)
-    bool narrow = !debug_flag("FHE_NO_NARROW");
+    bool narrow = !FHE_LAB_FLAG("NO_NARROW");
     for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
-    // N = 16384 (ks_fused_kernel's GM): FHE_KS14_PLAN = 8 radix-8 passes (24 VGPRs spilled), 4 radix-4 passes,
-    // unset / anything else: radix-8 while the twiddles are scalar, radix-4 after (GM_MIXED)
-    static const int plan14 = std::getenv("FHE_KS14_PLAN") ? std::atoi(std::getenv("FHE_KS14_PLAN")) : 0;
+    // N = 16384 (ks_fused_kernel's GM): radix-8 while the twiddles are scalar, radix-4 after (GM_MIXED).  Lab builds:
+    // FHE_LAB_KS14_PLAN = 8 radix-8 passes throughout (24 VGPRs spilled), 4 radix-4 passes throughout.
+    static const int plan14 = FHE_LAB_INT("KS14_PLAN", 0);
     // N = 8192: one workgroup owns a CU (132 KiB of LDS), so the items of a launch go to one resident workgroup per
-    // CU, each prefetching its next item's first row across its epilogue (FHE_KS_PERSIST=0: one workgroup per item)
-    static const int ks_persist = std::getenv("FHE_KS_PERSIST") ? std::atoi(std::getenv("FHE_KS_PERSIST")) : 1;
+    // CU, each prefetching its next item's first row across its epilogue (lab builds, FHE_LAB_KS_PERSIST=0: one
+    // workgroup per item)
+    static const int ks_persist = FHE_LAB_INT("KS_PERSIST", 1);
     unsigned ks_grid = (unsigned)(npolys * kc.L);
 #if defined(FHE_HOST_EMULATION)
     constexpr bool ks_persist_size = true;   // (every size, so that the emulated suite walks the item loop)
@@ -1016,13 +963,13 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
 inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
                              const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s,
                              const u64 *xhat = nullptr, u64 xhat_stride = 0) {
-    if (debug_flag("FHE_NO_KS_XHAT")) xhat = nullptr;
+    if (FHE_LAB_FLAG("NO_KS_XHAT")) xhat = nullptr;
     const Ctx &kc = *k_.ksk_ctx;
     kc.need_device();
     if (!npolys) return;
     // N = 16384: whole-row kernel (1024 threads x 16 coefficients, 24 VGPRs spilled) or two 8192-point sub-blocks
     // with the first stage folded into the loader (FHE_KS_SPLIT14=1)
-    static const bool split14 = std::getenv("FHE_KS_SPLIT14") != nullptr && std::atoi(std::getenv("FHE_KS_SPLIT14")) != 0;
+    static const bool split14 = FHE_LAB_INT("KS_SPLIT14", 0) != 0;
     if (kc.logn <= 13 || (kc.logn == 14 && !split14)) {  // (N = 8192 as 2 x 4096 measured +-1 %)
 #define FHE_KS_CASE(LN) \
     case LN: launch_ks_fused<LN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride); break;
@@ -1037,7 +984,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     // Rows larger than LDS (N >= 32768): one workgroup per 8192-point sub-block, the first
     // logn - 13 stages folded into its loader (ks_fused_split_kernel).
     const size_t lds = (k::lds_words(8192) + 8192) * sizeof(u64);
-    bool narrow = !debug_flag("FHE_NO_NARROW");
+    bool narrow = !FHE_LAB_FLAG("NO_NARROW");
     for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
 #define FHE_KS_SPLIT_LAUNCH(G0, NW)                                                                                \
     allow_big_lds((k::ks_fused_split_kernel<G0, 13, NW>), lds);                                                    \
@@ -1380,7 +1327,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     const size_t chunk = plan.chunk;
     // the extenders copy the shared prefix rows verbatim; when both share all L rows the tensor
     // kernel reads those rows from the inputs directly and the copy is skipped
-    const bool skip_copy = m.ext_lhs->ncommon == L && m.ext_rhs->ncommon == L && !debug_flag("FHE_NO_SKIP_COPY");
+    const bool skip_copy = m.ext_lhs->ncommon == L && m.ext_rhs->ncommon == L && !FHE_LAB_FLAG("NO_SKIP_COPY");
     struct ChunkWs {
         WsGuard extL, extR, ten, d, pre;
         ChunkWs(size_t chunk, u64 PK, u64 PL, size_t pre_bytes, hipStream_t st)
@@ -1421,7 +1368,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         // TENSOR (mul.rs:198-201) + the inverse NTT of the down-scaler (M/rq/scaler.rs:69-79):
         // ten [3][nb][K][N] ends up in PowerBasis.  Rows that fit LDS: one fused kernel;
         // larger rows: element-wise tensor kernel, then the two-kernel inverse NTT.
-        const bool fused_tensor = e.logn <= 16 && !debug_flag("FHE_NO_TENSOR_FUSION");
+        const bool fused_tensor = e.logn <= 16 && !FHE_LAB_FLAG("NO_TENSOR_FUSION");
         if (fused_tensor) {
             require(nb <= 32768, E_ARG, "chunk too large for the fused tensor kernel");  // 3*K*nb blocks in a 1-D grid
             k::TensorSrc ts{extL.u(), extR.u(), skip_copy ? l : nullptr, skip_copy ? r : nullptr, (uint32_t)L,
@@ -1462,3 +1409,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
 }
 
 }  // namespace fhe
+
+#if defined(FHE_LAB)
+#include "lab/lab_engine.hpp"
+#endif

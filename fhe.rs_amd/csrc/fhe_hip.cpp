@@ -1408,8 +1408,8 @@ fhe_status fhe_prof_get(size_t index, char *name, size_t name_cap, uint64_t *lau
     });
 }
 
-#if defined(FHE_PHASE_TIMING)
-// Diagnostic builds only (not in the header): reads and clears the phase-timing slots of kernels.hpp.
+#if defined(FHE_LAB) && defined(FHE_PHASE_TIMING)
+// Lab builds only (not in the header): reads and clears the phase-timing slots of kernels.hpp.
 fhe_status fhe_debug_phase_timing(uint64_t *out, size_t n) {
     return guard([&] {
         unsigned long long h[64] = {0}, z[64] = {0};

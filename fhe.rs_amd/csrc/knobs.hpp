@@ -1,0 +1,50 @@
+// knobs.hpp -- the compile-time switches of measured alternatives, all in one place.
+//
+// Every knob below selects between EXACT implementations (same residues, different instruction streams); the values
+// written here are the ones the measurements of rounds 1-2 picked.  The release build
+// (__graft_entry__.build()) pins them: defining any of them on the command line without -DFHE_LAB is a compile error,
+// so a -D typo cannot ship a different kernel.  -DFHE_LAB builds (tools/ab_*.sh; never loaded by the package) may
+// override them, additionally compile the rejected kernels under csrc/lab/ and read FHE_LAB_* environment switches.
+// The release library reads no environment variable at all.
+#pragma once
+
+#if !defined(FHE_LAB)
+#if defined(FHE_SENS) || defined(FHE_MAD_CARRY) || defined(FHE_APPROX_SHOUP) || defined(FHE_KS_LATE) ||             \
+    defined(FHE_KS_TWPF) || defined(FHE_KS_PERSIST14) || defined(FHE_KS_KPF_CHUNKS) || defined(FHE_TENSOR_TW_EARLY) ||  \
+    defined(FHE_KS_EXPERIMENTS) || defined(FHE_PHASE_TIMING) || defined(FHE_LDS_PAD) || defined(FHE_NO_WAVE_SYNC) || \
+    defined(FHE_DIAG_NO_SGPR_ASM) || defined(FHE_KS_HALF13) || defined(FHE_KS_SPLIT_XCD)
+#error "kernel-variant macros are lab-only: add -DFHE_LAB (the release build pins every knob, see knobs.hpp)"
+#endif
+#endif
+#if defined(FHE_SENS)
+#error "FHE_SENS (timing-only builds that computed wrong residues) was removed in round 3; see commit db30352"
+#endif
+
+// High products through v_mad_u64_u32's carry-out (zq_dev.hpp); 0: the compiler's generic expansion.
+#ifndef FHE_MAD_CARRY
+#define FHE_MAD_CARRY 1
+#endif
+// Narrow (< 2^60) butterflies take the Shoup quotient from three partial products (zq_dev.hpp).
+#ifndef FHE_APPROX_SHOUP
+#define FHE_APPROX_SHOUP 1
+#endif
+// Key-switch transforms: the wider radix passes last, so that the trailing exchanges are wave-local (kernels.hpp).
+#ifndef FHE_KS_LATE
+#define FHE_KS_LATE true
+#endif
+// Key switch at N = 8192: per-lane twiddles requested one pass ahead (measured: no change).
+#ifndef FHE_KS_TWPF
+#define FHE_KS_TWPF false
+#endif
+// Resident key-switch workgroups at N = 16384 as well (measured: 2 % slower at C3).
+#ifndef FHE_KS_PERSIST14
+#define FHE_KS_PERSIST14 0
+#endif
+// Chunks of key words requested before the barrier that ends a digit's transform.
+#ifndef FHE_KS_KPF_CHUNKS
+#define FHE_KS_KPF_CHUNKS 2
+#endif
+// Fused tensor + iNTT: first-pass twiddles requested half-way through the products.
+#ifndef FHE_TENSOR_TW_EARLY
+#define FHE_TENSOR_TW_EARLY 1
+#endif

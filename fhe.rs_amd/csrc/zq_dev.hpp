@@ -14,6 +14,8 @@
 #pragma once
 #include <cstdint>
 
+#include "knobs.hpp"
+
 #if defined(__HIPCC__) || defined(__HIP__)
 #define FHE_HD __host__ __device__ __forceinline__
 #else
@@ -31,13 +33,9 @@ struct DevMod {  // layout == hostmath.hpp ModConsts
     u64 np, np2;  // 2^64 - p, 2^64 - 2p (loaded, so the compiler cannot fold x + np back into x - p)
 };
 
-// FHE_SENS: timing-sensitivity builds only (WRONG results; tools/ab_sens.sh; bits 5 / 6 in kernels.hpp: no workgroup
-// barriers, scalar twiddles everywhere; bits 3 / 4: the pseudo-Mersenne fold and
-// q * c - (q << b) for 2^b - c primes, both slower in the kernels): bit 0 the approximate quotient from two
-// partial products, bit 1 every high product from two, bit 2 the lazy Shoup low products from one.
-#ifndef FHE_SENS
-#define FHE_SENS 0
-#endif
+// (Round 2 priced the instruction stream with timing-only builds that computed WRONG residues on purpose -- fewer
+// partial products, no barriers, a pseudo-Mersenne fold; results in DESIGN.md section 6, sources in the history up to
+// commit db30352.  None of that is in this file any more: every path here is exact.)
 // The high product through v_mad_u64_u32's carry-out (FHE_MAD_CARRY, default on; the device compiler has no way to
 // ask for it): the two cross products are summed by the multiply-add itself, their carry leaves in an SGPR pair and
 // joins the upper half of the sum as the 64-bit addend of the last multiply -- one v_mul_hi, three multiply-adds, a
@@ -46,10 +44,7 @@ struct DevMod {  // layout == hostmath.hpp ModConsts
 // SU: `b` is wave-uniform and stays in scalar registers (one constant-bus operand per instruction).
 // Every asm statement is a single instruction, so the scheduler still interleaves neighbouring butterflies; the
 // s_nop covers the two wait states gfx950 wants between a VALU write of an SGPR and a VALU read of it.
-#ifndef FHE_MAD_CARRY
-#define FHE_MAD_CARRY 1
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && FHE_MAD_CARRY && !(FHE_SENS & 2)
+#if defined(__HIP_DEVICE_COMPILE__) && FHE_MAD_CARRY
 #define FHE_HAVE_MAD_CARRY 1
 template <bool SU>
 __device__ __forceinline__ u64 mad64_carry(uint32_t a, uint32_t b, u64 add, u64 &carry) {
@@ -90,9 +85,7 @@ __device__ __forceinline__ u64 mulhi64_approx_c(u64 a, u64 b) {
 #endif
 
 FHE_HD u64 mulhi64(u64 a, u64 b) {
-#if FHE_SENS & 2
-    return (u64)(uint32_t)(a >> 32) * (uint32_t)(b >> 32) + (((u64)(uint32_t)a * (uint32_t)(b >> 32)) >> 32);
-#elif defined(__HIP_DEVICE_COMPILE__) && FHE_MAD_CARRY
+#if defined(__HIP_DEVICE_COMPILE__) && FHE_MAD_CARRY
     return mulhi64_c<false>(a, b);
 #elif defined(__HIP_DEVICE_COMPILE__)
     return __umul64hi(a, b);
@@ -218,23 +211,6 @@ struct PM {
 FHE_HD PM make_pm(const DevMod &m) { return PM{m.p, m.p2, m.np, m.np2}; }
 // mul_shoup_lazy with a*b - q*p written as a*b + q*(2^64 - p)  (mod 2^64)
 // SU (here and in the butterflies): the twiddle pair is wave-uniform (scalar registers); see mad64_carry
-#if (FHE_SENS & 8) && defined(__HIP_DEVICE_COMPILE__)
-// timing only: the pseudo-Mersenne fold (tools/ubench_int.cpp solinas62_lazy) in place of every lazy Shoup product
-__device__ __forceinline__ u64 sens_solinas(u64 y, u64 w, uint32_t c) {
-    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
-    const u64 l = (u64)y0 * w0;
-    const u64 m = (u64)y0 * w1 + (l >> 32);
-    u64 cm;
-    const u64 n = mad64_carry<false>(y1, w0, m, cm);
-    const u64 hi = (u64)y1 * w1 + ((u64)(uint32_t)(n >> 32) | ((u64)carry_bit(cm) << 32));
-    const u64 lo = (u64)(uint32_t)l | (n << 32);
-    const u64 xh = (hi << 2) | (lo >> 62), xl = lo & ((1ull << 62) - 1);
-    const u64 a = (u64)(uint32_t)xh * c + xl;
-    const u64 b = (u64)(uint32_t)(xh >> 32) * c + (a >> 32);
-    const u64 sl = (u64)(uint32_t)a | ((b & 0x3FFFFFFFull) << 32);
-    return (u64)(uint32_t)(b >> 30) * c + sl;
-}
-#endif
 template <bool SU = false>
 FHE_HD u64 mulhi64_t(u64 a, u64 b) {
 #if FHE_HAVE_MAD_CARRY
@@ -243,23 +219,10 @@ FHE_HD u64 mulhi64_t(u64 a, u64 b) {
     return mulhi64(a, b);
 #endif
 }
-#if FHE_SENS & 4
-FHE_HD u64 sens_lo(u64 a, u64 b) { return (u64)(uint32_t)a * (uint32_t)b; }
-template <bool SU = false>
-FHE_HD u64 mul_shoup_lazy_n(u64 a, u64 b, u64 bs, u64 np) { return sens_lo(a, b) + sens_lo(mulhi64(a, bs), np); }
-#else
 template <bool SU = false>
 FHE_HD u64 mul_shoup_lazy_n(u64 a, u64 b, u64 bs, u64 np) {
-#if (FHE_SENS & 8) && defined(__HIP_DEVICE_COMPILE__)
-    return sens_solinas(a, b, (uint32_t)np);
-#elif (FHE_SENS & 16) && defined(__HIP_DEVICE_COMPILE__)
-    const u64 q = mulhi64_t<SU>(a, bs);   // timing only: q * (2^64 - 2^b + c) as q * c - (q << b)
-    return a * b + q * (u64)(uint32_t)np - ((u64)((uint32_t)q << 28) << 32);
-#else
     return a * b + mulhi64_t<SU>(a, bs) * np;
-#endif
 }
-#endif
 FHE_HD u64 add_mod_n(u64 a, u64 b, const PM &m) { return csub_n(a + b, m.p, m.np); }
 
 // Harvey lazy butterflies, M/ntt/native.rs:256-269 / 288-300.
@@ -279,9 +242,6 @@ FHE_HD void fwd_butterfly(u64 &x, u64 &y, u64 w, u64 ws, const PM &m) {
 // from three of its four 32 x 32 partial products (y0 * ws0 only feeds a carry): the estimate is the true quotient
 // or one less, so t = y*w - q'*p is below 3p instead of 2p -- one multiply and its register shuffling less per
 // butterfly -- and every stage grows the bound by 3p: outputs x + t and x + 3p - t are below (b + 3) p.
-#ifndef FHE_APPROX_SHOUP
-#define FHE_APPROX_SHOUP 1
-#endif
 constexpr int FWD_NARROW_STEP = FHE_APPROX_SHOUP ? 3 : 2;
 constexpr int fwd_narrow_bound(int stage, int b0 = 1) {  // b before `stage`, b0 before stage 0
     int b = b0;
@@ -292,16 +252,14 @@ constexpr bool fwd_narrow_corrects(int stage, int b0 = 1) { return fwd_narrow_bo
 // floor(a * s / 2^64) or one less: the partial product a0 * s0 is left out (it contributes at most a carry of 1)
 template <bool SU = false>
 FHE_HD u64 mulhi64_approx(u64 a, u64 s) {
-#if FHE_HAVE_MAD_CARRY && !(FHE_SENS & 1)
+#if FHE_HAVE_MAD_CARRY
     return mulhi64_approx_c<SU>(a, s);
-#endif
+#else
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
-#if FHE_SENS & 1
-    return (u64)a1 * s1 + (((u64)a0 * s1) >> 32);
-#endif
     const u64 m = (u64)a0 * s1;
     const u64 m2 = (u64)a1 * s0 + (uint32_t)m;
     return (u64)a1 * s1 + (m >> 32) + (m2 >> 32);
+#endif
 }
 template <bool SU = false>
 FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, bool correct) {
@@ -311,18 +269,7 @@ FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, boo
         x = csub_n(x, p4, np4);
     }
 #if FHE_APPROX_SHOUP
-#if FHE_SENS & 4
-    const u64 t = sens_lo(y, w) + sens_lo(mulhi64_approx<SU>(y, ws), m.np);
-#else
-#if (FHE_SENS & 8) && defined(__HIP_DEVICE_COMPILE__)
-    const u64 t = sens_solinas(y, w, (uint32_t)m.np);
-#elif (FHE_SENS & 16) && defined(__HIP_DEVICE_COMPILE__)
-    const u64 qq = mulhi64_approx<SU>(y, ws);
-    const u64 t = y * w + qq * (u64)(uint32_t)m.np - ((u64)((uint32_t)qq << 28) << 32);
-#else
     const u64 t = y * w + mulhi64_approx<SU>(y, ws) * m.np;   // below 3p
-#endif
-#endif
     const u64 pk = m.p2 + m.p;
 #else
     const u64 t = mul_shoup_lazy_n<SU>(y, w, ws, m.np);

@@ -9,4 +9,4 @@ fhe = load_engine(kind)
 n = 8192
 mods = [1152921504606830593, 1152921504606748673, 4611686018427322369]
 cases.case_ntt(fhe, kind == 'hip', n, moduli=mods, batch=3, coracle_ctx=coracle.CCtx(OCtx(mods, n)))
-print("swap NTT ok", kind, os.environ.get("FHE_NTT_SWAP"))
+print("swap NTT ok", kind, os.environ.get("FHE_LAB_NTT_SWAP"))

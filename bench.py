@@ -17,6 +17,9 @@ starts its own N ranks when it is not already running under torchrun (WORLD_SIZE
 `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.  When fewer than N
 devices are visible (a 1-GPU box) the ranks share devices and rendezvous over gloo.
 
+`--gpus N` with N > 1 measures BASELINE.json configs[3] (C4: batch 65536 over 8 GPUs = 8192 pairs per GPU) unless
+`--batch` says otherwise; N = 1 measures C2 (1024 pairs).  Each rank pins its host thread to its GPU's NUMA node.
+
 Prints ONE JSON line on rank 0:
   value / ms_per_step   the K timed steps, single-stream mode with the library's per-launch HIP events on
                         (per-kernel durations are exact there; `roofline` comes from this region)
@@ -25,7 +28,12 @@ Prints ONE JSON line on rank 0:
                         overlap, so per-kernel durations are not attributable there: informational)
   ntt                   forward NTT of [batch*2][4][8192] (fhe-math/benches/ntt.rs:12-38): Poly-NTT/s, row-NTT/s
   other_configs         C3 relinearise / rotations (batch 512) and C5 level-0 multiply+relin+mod-switch (batch 16)
-  roofline              dominant kernel, HIP-event timed on the launching stream
+  roofline              dominant kernel, HIP-event timed on the launching stream; `roofline.int_issue`: the second
+                        ceiling SURVEY 8(d) asks for -- register-resident butterfly / multiply rates measured in this
+                        process (fhe_ubench_int) and every NTT-type kernel as a fraction of them
+  host_api              the drop-in host-pointer entry point (fhe_bfv_mul: H2D + compute + D2H per call) at batch 1
+                        and at the bench batch, and the `_dev` path on buffers / a stream owned through the C ABI
+  per_rank              (N > 1) every rank's own ops/s and the max/min skew
   cpu_baseline          (N = 1) the plain-C port of the reference algorithm on this box's host cores
 """
 import argparse
@@ -34,13 +42,15 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_DEGREE = 8192
 MODULI_SIZES = [60, 60, 60, 60]
-BATCH_PER_GPU = 1024
+BATCH_PER_GPU = 1024        # C2 (configs[1]): the single-GPU workload the metric is quoted on
+BATCH_PER_GPU_SHARDED = 8192  # C4 (configs[3]): 65536 ciphertext pairs over 8 GPUs
 SEED = 0xF4E50002           # 0xF4E50000 + cfg
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -110,17 +120,148 @@ def spawn_ranks(n):
     return rc
 
 
+def pin_to_gpu_numa_node(torch, dev):
+    """Pins this rank's host threads to the CPUs of its GPU's NUMA node (launch latency and the host-pointer copies
+    otherwise cross the socket interconnect on a two-socket box).  Returns what was done, for the JSON line."""
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            return dict(pci=bdf, numa_node=None, pinned=False)
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return dict(pci=bdf, numa_node=node, pinned=False)
+        os.sched_setaffinity(0, cpus)
+        return dict(pci=bdf, numa_node=node, pinned=True, cpus=len(cpus))
+    except Exception as e:   # no sysfs entry / no permission: run unpinned, say so
+        return dict(numa_node=None, pinned=False, error=str(e)[:80])
+
+
+def read_sclk_mhz():
+    """Current engine clock from sysfs (the level pp_dpm_sclk marks with '*'); None when not exposed."""
+    import glob
+    best = None
+    for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+        try:
+            for line in open(f):
+                if "*" in line:
+                    best = max(best or 0, int(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+        except Exception:
+            pass
+    return best
+
+
+def int_issue_roofline(fhe, dev, prof, n, L, K, batch, steps):
+    """"measure it (microbench v_mad_u64_u32 throughput) and report both ceilings".  Runs the library's
+    register-resident loops (the butterflies the kernels are made of, no memory traffic) for ~0.2 s in this process,
+    samples the engine clock while they run, and prices every NTT-type kernel of the timed region against them:
+    frac_of_ceiling = (time its transform butterflies would take at the register-resident rate) / (its HIP-event
+    time).  Tensor products, key-switch MACs, lifts and reductions are real work NOT counted in the numerator."""
+    import threading
+    clocks, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            v = read_sclk_mhz()
+            if v:
+                clocks.append(v)
+            stop.wait(0.01)
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    rates = {k: fhe.ubench_int(k, 0.03, dev) for k in ("mad_u64_u32", "mul_lo_u32", "mul_hi_u32", "shoup_lazy",
+                                                        "fwd_butterfly", "fwd_butterfly_narrow", "inv_butterfly")}
+    stop.set()
+    th.join()
+    bf_row = (n // 2) * (n.bit_length() - 1)                     # butterflies of one row transform
+    fw, fn_, iv = rates["fwd_butterfly"], rates["fwd_butterfly_narrow"], rates["inv_butterfly"]
+    # rows per ct x ct + relin by kernel and butterfly kind (C2: the L ciphertext primes are 60-bit -> narrow passes,
+    # the K - L extension primes 62-bit -> wide passes; the inverse narrow passes are priced with the wide inverse rate)
+    rows = {
+        "ntt_fwd": [(4 * (K - L), fw), (2 * L, fn_)],
+        "ntt_inv": [(4 * L, iv)],
+        "tensor_intt": [(3 * K, iv)],
+        "key_switch_fused": [(L * L, fn_)],
+    }
+    per_kernel = {}
+    for name, parts in rows.items():
+        if name in prof and prof[name][1] > 0:
+            ideal_s = sum(r * bf_row / rate for r, rate in parts) * batch * steps
+            per_kernel[name] = dict(butterflies_per_s=round(sum(r for r, _ in parts) * bf_row * batch * steps
+                                                            / (prof[name][1] * 1e-3), 0),
+                                    frac_of_ceiling=round(ideal_s / (prof[name][1] * 1e-3), 4))
+    return dict(butterflies_per_s_ceiling=dict(forward_wide=round(fw, 0), forward_narrow_lt_2p60=round(fn_, 0),
+                                               inverse=round(iv, 0)),
+                row_ntt_per_s_ceiling=dict(forward_wide=round(fw / bf_row, 0), forward_narrow_lt_2p60=round(fn_ / bf_row, 0),
+                                           inverse=round(iv / bf_row, 0)),
+                mad_u64_u32_per_s=round(rates["mad_u64_u32"], 0), mul_lo_u32_per_s=round(rates["mul_lo_u32"], 0),
+                mul_hi_u32_per_s=round(rates["mul_hi_u32"], 0), shoup_lazy_per_s=round(rates["shoup_lazy"], 0),
+                sclk_mhz_observed=(round(sum(clocks) / len(clocks)) if clocks else None),
+                sclk_samples=len(clocks), per_kernel=per_kernel,
+                note="fhe_ubench_int, this process, this box; numerators count transform butterflies only")
+
+
+def workload_name(world, batch):
+    if world > 1 and batch == BATCH_PER_GPU_SHARDED:
+        return (f"C4: BFV n=8192, 4x60-bit RNS moduli (K=9), batch={batch * world} ct x ct + relinearize sharded across "
+                f"{world} GPUs ({batch} per GPU; BASELINE configs[3] is this at 8 GPUs = 65536)")
+    tag = "C2" if batch == BATCH_PER_GPU else "C2 shape"
+    return f"{tag}: BFV n=8192, 4x60-bit RNS moduli (K=9), batch={batch} ct x ct + relinearize per GPU"
+
+
+def host_api_numbers(fhe, _lib, torch, mul, ctx, par, rk, batch, n, L, value_hint=None):
+    """What a host that keeps `Poly.coefficients` in its own memory gets from the drop-in entry points.
+    host_pointer: fhe_bfv_mul (pageable host arrays in, host array out: H2D + pipeline + D2H inside every call).
+    abi_device_buffers: fhe_bfv_mul_dev on buffers from fhe_buf_alloc and a stream from fhe_stream_create (no torch
+    allocator or stream involved): the device-resident path a Rust / C host uses."""
+    import numpy as np
+    out = {}
+    m2 = fhe.Multiplicator.default(par, rk, 0)          # product defaults (two streams)
+    for b in (1, batch):
+        lh = ctx.synth_uniform(SEED, 0, 0, 2, b).cpu().numpy().view(np.uint64)
+        rh = ctx.synth_uniform(SEED, 0, 2, 2, b).cpu().numpy().view(np.uint64)
+        m2.multiply(lh, rh)
+        reps = 20 if b == 1 else 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m2.multiply(lh, rh)
+        dt = (time.perf_counter() - t0) / reps
+        moved = b * (2 * 2 + 2) * L * n * 8
+        out[f"host_pointer_batch{b}"] = dict(ops_per_s=round(b / dt, 1), ms_per_call=round(dt * 1e3, 3),
+                                            pcie_GBps=round(moved / dt / 1e9, 2))
+        del lh, rh
+    with fhe.Stream(ctx.device) as st:
+        la, ra = ctx.synth_uniform(SEED, 0, 0, 2, batch), ctx.synth_uniform(SEED, 0, 2, 2, batch)
+        assert isinstance(la, fhe.DeviceArray)
+        m2.multiply(la, ra)
+        st.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o = m2.multiply(la, ra)
+        st.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out["abi_device_buffers"] = dict(ops_per_s=round(batch / dt, 1), ms_per_call=round(dt * 1e3, 3), batch=batch,
+                                         note="fhe_buf_alloc / fhe_stream_create / fhe_bfv_mul_dev, outputs allocated per call")
+        for x in (la, ra, o):
+            x.free()
+    st.destroy()
+    return out
+
+
 def key_for(fhe, ctx, seed):
     L = ctx.nmoduli
     kk = ctx.synth_uniform(seed, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, ctx.degree)
     return fhe.KeySwitchingKey(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous())
 
 
-def other_configs(fhe, torch, reps=3):
-    """Informational (never `value`): the other single-GPU configs of BASELINE.json on this box, same process.
-    C3 (fhe/benches/bfv.rs:167-194): N=16384, 8x60-bit, relinearise 3->2 and the two rotations, batch 512.
-    C5 (bfv.rs:247-255 shape at the top of a deep chain): N=32768, 16x60-bit, multiply + relinearise +
-    modulus switch at level 0, batch 16.  Stage-model bytes per op: SURVEY.md §8(d)."""
+def make_timeit(torch, reps=3):
+    """ms per call of fn(): one untimed call, then `reps` calls between two events on torch's current stream (the
+    stream every `_dev` call of this file is issued on)."""
     def timeit(fn):
         fn()
         torch.cuda.synchronize()
@@ -131,7 +272,71 @@ def other_configs(fhe, torch, reps=3):
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
+    return timeit
 
+
+def reference_bench_ids(fhe, torch, par, rk, batch, timeit):
+    """The rest of the reference's own Criterion IDs on the C2 parameter set (informational, same process):
+    crates/fhe/benches/bfv.rs:219-245 `mul` (&c1 * &c2, three parts, no relinearisation), `square` (&c1 * &c1),
+    `mul_then_relinearize` (the two calls in sequence; `mul_and_relin` -- Multiplicator::multiply -- is `value`);
+    crates/fhe-math/benches/rns.rs:32-53 `scaler` / `scaler_as_converter` (3 -> 4 moduli of the reference's lists, per
+    coefficient column = one RnsScaler::scale call); benches/rq.rs:214-260 `mul_shoup_assign` and the two
+    `change_representation` IDs (= Poly-NTT/s backward; forward is the line's `ntt`)."""
+    out = {}
+    n, ctx = par.degree, par.context_at_level(0)
+    L, K = ctx.nmoduli, par.mul_context_at_level(0).nmoduli
+    R = 8 * n
+    a, b = ctx.synth_uniform(SEED, 0, 0, 2, batch), ctx.synth_uniform(SEED, 0, 2, 2, batch)
+    plain = fhe.Multiplicator.default(par, None, 0)
+
+    def entry(ms, rows, units=batch, unit_name="ops_per_s"):
+        gbs = units * rows * R / ms / 1e6 if rows else None
+        d = {unit_name: round(units / ms * 1e3, 1), "ms": round(ms, 3)}
+        if rows:
+            d.update(stage_model_bytes_per_op=rows * R, stage_model_GBps=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+        return d
+    out["bfv/mul"] = entry(timeit(lambda: plain.multiply(a, b)), 22 * K + 9 * L)          # SURVEY 8(d) "&ct*&ct no relin"
+    out["bfv/square"] = entry(timeit(lambda: plain.tensor(a, a)), 22 * K + 9 * L)
+    c3 = plain.multiply(a, b)
+    out["bfv/relinearize"] = entry(timeit(lambda: rk.relinearizes(c3)), 2 * L + L * L + 4 * L)
+    out["bfv/mul_then_relinearize"] = entry(timeit(lambda: rk.relinearizes(plain.multiply(a, b))),
+                                            22 * K + 9 * L + 2 * L + L * L + 4 * L)
+    del c3, plain
+    # fhe-math/benches/rns.rs: the reference's 3 -> 4 modulus lists, PowerBasis columns of [batch*2] polynomials
+    q3 = [4611686018326724609, 4611686018309947393, 4611686018282684417]
+    p4 = [4611686018257518593, 4611686018232352769, 4611686018171535361, 4611686018106523649]
+    cq, cp = fhe.Context(q3, n), fhe.Context(p4, n)
+    x = cq.synth_uniform(SEED, 0, 0, 1, batch * 2)
+    cols = batch * 2 * n
+    for name, num, den in (("rns/scaler/3->4", 1, 46116860181065), ("rns/scaler_as_converter/3->4", 1, 1)):
+        sc = fhe.Scaler(cq, cp, num, den)
+        ms = timeit(lambda: sc.scale(x, ntt=False))
+        out[name] = dict(columns_per_s=round(cols / ms * 1e3, 0), ms=round(ms, 3),
+                         GBps=round(cols * 7 * 8 / ms / 1e6, 1), frac=round(cols * 7 * 8 / ms / 1e6 / HBM_PEAK_GBS, 4))
+    del x, cq, cp
+    # fhe-math/benches/rq.rs
+    polys = a.view(batch * 2, L, n)
+    q8 = ctx.synth_uniform(SEED, 0, 2, 2, 4).view(8, L, n)              # eight distinct NttShoup operands, cycled
+    reps8 = (batch * 2 + 7) // 8
+    qs = q8.repeat(reps8, 1, 1)[: batch * 2].contiguous()
+    qshoup = torch.from_numpy(ctx.shoup(q8.cpu().numpy().view("uint64")).view("int64")).cuda().repeat(reps8, 1, 1)[: batch * 2].contiguous()
+    ms = timeit(lambda: ctx.mul_shoup(polys, qs, qshoup))
+    out["rq/mul_shoup_assign"] = dict(polys_per_s=round(batch * 2 / ms * 1e3, 1), ms=round(ms, 3),
+                                      GBps=round(batch * 2 * 4 * L * R / ms / 1e6, 1),
+                                      frac=round(batch * 2 * 4 * L * R / ms / 1e6 / HBM_PEAK_GBS, 4))
+    ms = timeit(lambda: ctx.ntt_backward(polys))
+    out["rq/change_representation/Ntt_to_PowerBasis"] = dict(
+        poly_ntt_per_s=round(batch * 2 / ms * 1e3, 1), row_ntt_per_s=round(batch * 2 * L / ms * 1e3, 1), ms=round(ms, 3),
+        frac=round(batch * 2 * 2 * L * R / ms / 1e6 / HBM_PEAK_GBS, 4))
+    return out
+
+
+def other_configs(fhe, torch, reps=3):
+    """Informational (never `value`): the other single-GPU configs of BASELINE.json on this box, same process.
+    C3 (fhe/benches/bfv.rs:167-194): N=16384, 8x60-bit, relinearise 3->2 and the two rotations, batch 512.
+    C5 (bfv.rs:247-255 shape at the top of a deep chain): N=32768, 16x60-bit, multiply + relinearise +
+    modulus switch at level 0, batch 16 and 64.  Stage-model bytes per op: SURVEY.md §8(d)."""
+    timeit = make_timeit(torch, reps)
     out = {}
     n, L, batch = 16384, 8, 512
     ctx = fhe.Context(fhe.generate_moduli([60] * L, n), n)
@@ -149,7 +354,7 @@ def other_configs(fhe, torch, reps=3):
                          ms=round(ms, 3), stage_model_bytes_per_op=rows * R, stage_model_GBps=round(gbs, 1),
                          frac=round(gbs / HBM_PEAK_GBS, 4))
     del ct3, ct2, rk, gk3, gkr, ksk, ctx
-    n, L, batch = 32768, 16, 16
+    n, L = 32768, 16
     t = fhe.generate_prime(20, 2 * n, 1 << 20)
     q = fhe.generate_moduli([60] * L, n)
     K = L + (60 * L + 60 + 61) // 62
@@ -164,13 +369,15 @@ def other_configs(fhe, torch, reps=3):
         Q *= m
     extender, down = fhe.Scaler(ctx, mctx, 1, 1), fhe.Scaler(mctx, ctx, t, Q)
     mul = fhe.Multiplicator(extender, extender, down, fhe.RelinearizationKey(key_for(fhe, ctx, 0xF4E50005)), True)
-    a, b = ctx.synth_uniform(0xF4E50005, 0, 0, 2, batch), ctx.synth_uniform(0xF4E50005, 0, 2, 2, batch)
-    ms = timeit(lambda: mul.multiply(a, b))
     rows = 22 * K + 7 * L + L * L + 4 * L + 12 * L - 6
-    gbs = batch * rows * 8 * n / ms / 1e6
-    out["C5_level0_mul_relin_modswitch"] = dict(
-        workload=f"n=32768, 16x60-bit (K={K}), batch {batch}", ops_per_s=round(batch / ms * 1e3, 1), ms=round(ms, 3),
-        stage_model_bytes_per_op=rows * 8 * n, stage_model_GBps=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+    for batch in (16, 64):
+        a, b = ctx.synth_uniform(0xF4E50005, 0, 0, 2, batch), ctx.synth_uniform(0xF4E50005, 0, 2, 2, batch)
+        ms = timeit(lambda: mul.multiply(a, b))
+        gbs = batch * rows * 8 * n / ms / 1e6
+        out["C5_level0_mul_relin_modswitch" + ("" if batch == 16 else f"_batch{batch}")] = dict(
+            workload=f"n=32768, 16x60-bit (K={K}), batch {batch}", ops_per_s=round(batch / ms * 1e3, 1), ms=round(ms, 3),
+            stage_model_bytes_per_op=rows * 8 * n, stage_model_GBps=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+        del a, b
     return out
 
 
@@ -179,7 +386,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="ciphertext pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="ciphertext pairs per GPU per step (default: 1024 = C2 with one GPU, 8192 = C4's shard with more)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip event_free / default_mode / ntt / other_configs")
@@ -192,6 +400,9 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    nranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
+    if not args.batch:
+        args.batch = BATCH_PER_GPU if nranks == 1 else BATCH_PER_GPU_SHARDED
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,7 +435,8 @@ def main():
             dist.destroy_process_group()
         assert total == world * (world - 1) // 2
         if rank == 0:
-            print(json.dumps(dict(spawn_check="ok", n_gpus=world, dist_backend=backend, devices_visible=ndev)))
+            print(json.dumps(dict(spawn_check="ok", n_gpus=world, dist_backend=backend, devices_visible=ndev,
+                                  workload=workload_name(world, args.batch), batch_per_gpu=args.batch)))
         return
 
     import fhe_rs_amd as fhe
@@ -233,6 +445,11 @@ def main():
     assert ndev > 0, "bench.py needs a GPU (the product path has no CPU fallback)"
     dev = local_rank % ndev
     torch.cuda.set_device(dev)
+    if world > 1:
+        assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus)
+        if ndev >= world:
+            assert dist.get_backend() == "nccl", "one device per rank: the ranks must rendezvous over RCCL"
+    pin = pin_to_gpu_numa_node(torch, dev)
 
     # ---- setup (untimed): parameters, device tables, synthetic key + inputs in HBM ----------
     n, batch = N_DEGREE, args.batch
@@ -272,6 +489,21 @@ def main():
     elapsed = timed(step, args.steps)
     fhe.prof_enable(False)
     prof = fhe.prof_report()
+    # every rank's own elapsed time for the same K steps (its barrier-to-barrier time is the slowest rank's)
+    per_rank = None
+    if dist is not None:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        on_gpu = dist.get_backend() == "nccl"
+        tt = torch.tensor([mine], dtype=torch.float64, device=f"cuda:{dev}" if on_gpu else "cpu")
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        rates = [batch * args.steps / float(x.item()) for x in allt]
+        per_rank = dict(ops_per_s=[round(r, 1) for r in rates], max_over_min=round(max(rates) / min(rates), 4),
+                        note="each rank's own un-barriered K steps right after the timed region")
 
     extras = {}
     if not args.no_extras:
@@ -311,6 +543,10 @@ def main():
                              ms_per_launch=round(e3 / args.steps * 1e3, 4))
         # (the transform is a bijection on canonical residues: restore the inputs for the parity spot check)
         lhs = ctx.synth_uniform(SEED, ct0, 0, 2, batch)
+
+        # (4) the drop-in host-pointer entry point and the `_dev` path on ABI-owned buffers (rank 0, one GPU)
+        if world == 1:
+            extras["host_api"] = host_api_numbers(fhe, _lib, torch, mul, ctx, par, rk, batch, n, L, value_hint=None)
 
     if rank != 0:
         if dist is not None:
@@ -362,18 +598,23 @@ def main():
                                   achieved=round(stage_model_rows(L, K, L) * R * value / world / 1e9, 1),
                                   frac=round(stage_model_rows(L, K, L) * R * value / world / 1e9 / HBM_PEAK_GBS, 4)),
                     kernels=per_kernel)
+    if not args.no_extras:
+        roofline["int_issue"] = int_issue_roofline(fhe, dev, prof, n, L, K, batch, args.steps)
 
     result = {
         "metric": "BFV ct x ct + relinearize ops/s (n=8192, 4x60-bit moduli)",
         "value": round(value, 1), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"C2: BFV n=8192, 4x60-bit RNS moduli (K=9), batch={batch} ct x ct + relinearize per GPU",
+        "config": {"workload": workload_name(world, batch),
                    "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"batch-sharded x{world}",
-                   "streams_in_timed_region": args.streams, "dist_backend": backend, "devices_visible": ndev},
+                   "streams_in_timed_region": args.streams, "dist_backend": backend,
+                   "dist_world_size": world if dist is not None else 1, "devices_visible": ndev, "host_pinning": pin},
         "roofline": roofline,
     }
     result.update(extras)
+    if per_rank is not None:
+        result["per_rank"] = per_rank
 
     if world == 1 and not args.no_cpu:
         cb, cm, (clhs, crhs, last, count, npairs) = cpu_baseline(n, MODULI_SIZES, t, SEED, args.cpu_seconds)
@@ -389,10 +630,15 @@ def main():
         result["parity_spot_check"] = f"ciphertext {i} bit-identical to the oracle"
 
     if world == 1 and not args.no_extras:
-        del lhs, rhs, out, mul, rk
+        del lhs, rhs, out, mul
+        fhe.workspace_trim()
+        torch.cuda.empty_cache()
+        ids = reference_bench_ids(fhe, torch, par, rk, batch, make_timeit(torch))
+        del rk
         fhe.workspace_trim()
         torch.cuda.empty_cache()
         result["other_configs"] = other_configs(fhe, torch)
+        result["other_configs"].update(ids)
 
     if dist is not None:
         dist.destroy_process_group()

@@ -7,4 +7,4 @@ The directory is literally called `fhe.rs_amd`, which Python cannot import by st
 from . import _lib  # noqa: F401
 from .api import *  # noqa: F401,F403
 from .api import (Context, Scaler, Switcher, KeySwitchingKey, RelinearizationKey, GaloisKey, EvaluationKey, RGSWCiphertext,
-                  BfvParameters, Multiplicator, FheError)  # noqa: F401
+                  BfvParameters, Multiplicator, FheError, Stream, DeviceArray)  # noqa: F401

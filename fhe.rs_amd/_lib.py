@@ -30,6 +30,26 @@ SIGNATURES = {
     "fhe_last_error": (C.c_char_p, []),
     "fhe_version": (C.c_char_p, []),
     "fhe_device_count": (i32, []),
+    "fhe_buf_alloc": (i32, [i32, sz, C.POINTER(vp)]),
+    "fhe_buf_free": (i32, [vp]),
+    "fhe_buf_upload": (i32, [vp, vp, sz, vp]),
+    "fhe_buf_upload_async": (i32, [vp, vp, sz, vp]),
+    "fhe_buf_download": (i32, [vp, vp, sz, vp]),
+    "fhe_buf_download_async": (i32, [vp, vp, sz, vp]),
+    "fhe_buf_copy_async": (i32, [vp, vp, sz, vp]),
+    "fhe_buf_zero_async": (i32, [vp, sz, vp]),
+    "fhe_host_alloc": (i32, [sz, C.POINTER(vp)]),
+    "fhe_host_free": (i32, [vp]),
+    "fhe_stream_create": (i32, [i32, C.POINTER(vp)]),
+    "fhe_stream_sync": (i32, [vp]),
+    "fhe_stream_destroy": (i32, [vp]),
+    "fhe_device_sync": (i32, [i32]),
+    "fhe_device_mem_info": (i32, [i32, szp, szp]),
+    "fhe_poly_switch_down_to": (i32, [vp, vp, u64p, u64p, sz]),
+    "fhe_poly_switch_down_to_dev": (i32, [vp, vp, vp, vp, sz, vp]),
+    "fhe_bfv_switch_to_level": (i32, [vp, sz, sz, u64p, u64p, sz]),
+    "fhe_bfv_switch_to_level_dev": (i32, [vp, sz, sz, vp, vp, sz, vp]),
+    "fhe_ubench_int": (i32, [i32, i32, C.c_double, C.POINTER(C.c_double)]),
     "fhe_ctx_create": (i32, [i32, sz, sz, u64p, u64p, u64p, u64p, u64p, u64p, u64p, C.POINTER(vp)]),
     "fhe_ctx_destroy": (None, [vp]),
     "fhe_ctx_at_level": (i32, [vp, sz, C.POINTER(vp)]),

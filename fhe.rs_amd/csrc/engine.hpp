@@ -228,6 +228,20 @@ public:
         for (auto &b : blocks)
             if (b.ptr == p) b.in_use = false;
     }
+    // A stream is about to be destroyed: its idle blocks can never be handed out again.
+    void drop_stream(hipStream_t s) {
+        std::lock_guard<std::mutex> lk(mu);
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (auto &b : blocks)
+            if (!b.in_use && b.ptr && b.stream == s) {
+                (void)hipSetDevice(b.device);
+                (void)hipFree(b.ptr);
+                b.ptr = nullptr;
+            }
+        (void)hipSetDevice(cur);
+        blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const Block &b) { return !b.ptr; }), blocks.end());
+    }
     // Frees every idle block (all devices); returns the number of bytes released.
     size_t trim() {
         std::lock_guard<std::mutex> lk(mu);
@@ -282,6 +296,9 @@ struct Ctx {
     // host tables (root only)
     std::vector<NttTables> tabs;
     std::vector<ModConsts> mods;
+    // one 64-bit fingerprint per modulus over the four NTT tables and N^-1 (root only): two contexts agree on the
+    // evaluation order of a shared modulus -- and may exchange Ntt-form rows -- exactly when these are equal
+    std::vector<u64> tab_fp;
     // per-context
     std::vector<u64> inv_last, inv_last_shoup;  // M/rq/context.rs:66-73
     std::unique_ptr<Ctx> next;                  // next_context
@@ -295,6 +312,15 @@ struct Ctx {
     const k::u64x2 *dninv() const { return root->d_ninv.p; }
     const k::u64x2 *dpow2() const { return root->d_pow2.p; }
     const NttTables &tab(size_t i) const { return root->tabs[i]; }
+    // Do the first `rows` moduli of this context and of `o` use the same NTT tables?  (Handles built from different
+    // table sources -- the engine's own psi, fhe_ctx_create with host tables, fhe_params_create_with_tables -- can
+    // share moduli and still disagree on the evaluation order; Ntt-form rows then must not cross between them.)
+    bool same_tables(const Ctx &o, size_t rows) const {
+        if (rows > L || rows > o.L) return false;
+        for (size_t i = 0; i < rows; i++)
+            if (moduli[i] != o.moduli[i] || root->tab_fp[i] != o.root->tab_fp[i]) return false;
+        return true;
+    }
     size_t poly_elems() const { return L * n; }
     void need_device() const { require(device >= 0, E_NO_DEVICE, "handle was created host-only (device = -1)"); }
     bool same_ring(const Ctx &o) const { return n == o.n && moduli == o.moduli; }
@@ -365,6 +391,15 @@ inline std::unique_ptr<Ctx> ctx_create(int device, size_t degree, const std::vec
         } else {
             c->tabs.push_back(make_ntt_tables(moduli[i], degree));
         }
+    }
+    for (size_t i = 0; i < c->L; i++) {
+        const NttTables &t = c->tabs[i];
+        u64 h = splitmix64(moduli[i] ^ degree);
+        for (size_t j = 0; j < degree; j++) {
+            h = splitmix64(h ^ t.omegas[j]) + t.omegas_shoup[j];
+            h = splitmix64(h ^ t.zetas_inv[j]) + t.zetas_inv_shoup[j];
+        }
+        c->tab_fp.push_back(splitmix64(h ^ t.size_inv) + t.size_inv_shoup);
     }
     if (device >= 0) {
         int ndev = 0;
@@ -886,6 +921,10 @@ inline void ksk_validate(const Ctx &ct_ctx, const Ctx &ksk_ctx, size_t ndigits, 
     require(ct_ctx.device == ksk_ctx.device, E_PARAMETER_MISMATCH, "contexts live on different devices");
     require(ksk_ctx.niterations_to(ct_ctx) >= 0, E_CONTEXT_NOT_REACHABLE,
             "ciphertext context is not reachable from the key context");
+    // the key switch adds Ntt-form rows of the two contexts (and reads the caller's Ntt-form digit rows as
+    // transforms under the key moduli, `xhat`): both must evaluate the shared moduli in the same order
+    require(ksk_ctx.same_tables(ct_ctx, ct_ctx.L), E_PARAMETER_MISMATCH,
+            "ParameterMismatch: ciphertext and key contexts were built with different NTT tables");
     if (log_base != 0) {
         require(ksk_ctx.L == 1 && ct_ctx.L == 1, E_PARAMETER_MISMATCH,
                 "decomposition keys need single-modulus contexts");
@@ -1007,20 +1046,49 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
 #undef FHE_KS_SPLIT_LAUNCH
 }
 
-// switch_down_to (M/rq/mod.rs:498-507) for Ntt polys living over `from`, `iters` times:
-// in [npolys][from.L][N] Ntt -> out [npolys][from.L-iters][N] Ntt
-inline void switch_down_to_ntt(const Ctx &from, size_t iters, const u64 *in, u64 *out, size_t npolys, hipStream_t s) {
-    const u64 stride = (u64)from.L * from.n;
-    WsGuard a(npolys * stride * sizeof(u64), s), b(npolys * stride * sizeof(u64), s);
-    launch_ntt(from, true, in, a.u(), full_map(from, from.L), npolys, k::PRO_NONE, s);
-    const Ctx *c = &from;
-    u64 *cur = a.u(), *nxt = b.u();
-    for (size_t i = 0; i < iters; i++) {
-        switch_down_polys(*c, cur, (u64)c->L * c->n, nxt, (u64)(c->L - 1) * c->n, npolys, s);
-        std::swap(cur, nxt);
-        c = c->next.get();
+// Poly::<PowerBasis>::switch_down_to (M/rq/mod.rs:498-507): `iters` applications of switch_down.
+// in [npolys][from.L][N] (poly stride in_stride) -> out [npolys][from.L - iters][N] (poly stride out_stride), both
+// PowerBasis.  Intermediate levels live in one scratch block at a constant stride, updated in place (a lane reads its
+// column's rows before it writes them), so `iters` levels cost one scratch block whatever `iters` is.
+inline void switch_down_to_pb(const Ctx &from, size_t iters, const u64 *in, u64 in_stride, u64 *out, u64 out_stride,
+                              size_t npolys, hipStream_t s) {
+    from.need_device();
+    require(from.at_level(iters) != nullptr, E_NO_MORE_CONTEXT, "NoMoreContext");
+    if (!npolys) return;
+    if (iters == 0) {
+        const u64 per = (u64)from.L * from.n, total = per * npolys;
+        FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in, out,
+                   in_stride, out_stride, per, total);
+        return;
     }
-    launch_ntt(*c, false, cur, out, full_map(*c, c->L), npolys, k::PRO_NONE, s);
+    if (iters == 1) {
+        switch_down_polys(from, in, in_stride, out, out_stride, npolys, s);
+        return;
+    }
+    const u64 ts = (u64)(from.L - 1) * from.n;
+    WsGuard tmp(npolys * ts * sizeof(u64), s);
+    const Ctx *c = &from;
+    for (size_t i = 0; i < iters; i++, c = c->next.get()) {
+        const bool first = i == 0, last = i + 1 == iters;
+        switch_down_polys(*c, first ? in : tmp.u(), first ? in_stride : ts, last ? out : tmp.u(), last ? out_stride : ts,
+                          npolys, s);
+    }
+}
+
+// The same for Ntt polys living over `from` (Ciphertext::switch_down / switch_to_level, F/bfv/ciphertext.rs:148-183,
+// one part at a time there): in [npolys][from.L][N] Ntt -> out [npolys][from.L-iters][N] Ntt.  The reference goes
+// PowerBasis -> switch_down -> Ntt once per level; the Ntt -> PowerBasis -> Ntt round trips between levels are the
+// identity on canonical residues, so one inverse transform, `iters` switch_downs and one forward transform give
+// the same values.
+inline void switch_down_to_ntt(const Ctx &from, size_t iters, const u64 *in, u64 *out, size_t npolys, hipStream_t s) {
+    require(from.at_level(iters) != nullptr, E_NO_MORE_CONTEXT, "NoMoreContext");
+    if (!npolys) return;
+    const Ctx &to = *from.at_level(iters);
+    const u64 stride = (u64)from.L * from.n, ostride = (u64)to.L * to.n;
+    WsGuard a(npolys * stride * sizeof(u64), s);
+    launch_ntt(from, true, in, a.u(), full_map(from, from.L), npolys, k::PRO_NONE, s);
+    switch_down_to_pb(from, iters, a.u(), stride, out, ostride, npolys, s);
+    launch_ntt(to, false, out, out, full_map(to, to.L), npolys, k::PRO_NONE, s);
 }
 
 // key switch followed by the level fix-up and "+= (a0, a1)" used by relinearise / rotate:
@@ -1228,22 +1296,65 @@ struct Mul {
     size_t out_parts() const { return rk ? 2 : 3; }
     size_t out_rows() const { return mod_switch ? base->L - 1 : base->L; }
 };
-struct AuxStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-inline AuxStream &aux_for(int device, hipStream_t user) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, AuxStream> reg;
-    std::lock_guard<std::mutex> lk(mu);
-    AuxStream &a = reg[{device, user}];
-    if (!a.s) {
-        FHE_HIP_CHECK(hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking));
-        FHE_HIP_CHECK(hipEventCreateWithFlags(&a.fork, hipEventDisableTiming));
-        FHE_HIP_CHECK(hipEventCreateWithFlags(&a.join, hipEventDisableTiming));
+// The internal second stream of a (device, caller stream) pair.  The fork / join events are taken from a pool PER CALL
+// (an event that two concurrent callers record and wait on would tie their orderings together); concurrent callers on
+// the SAME user stream still share its one internal stream and therefore serialise there, which is all stream order
+// promises them anyway.  fhe_stream_destroy / fhe_workspace_trim drop what belongs to a stream that is gone.
+class AuxStreams {
+public:
+    static AuxStreams &get() {
+        static AuxStreams a;
+        return a;
     }
-    return a;
-}
+    hipStream_t stream_for(int device, hipStream_t user) {
+        std::lock_guard<std::mutex> lk(mu);
+        hipStream_t &a = reg[{device, user}];
+        if (!a) FHE_HIP_CHECK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        return a;
+    }
+    hipEvent_t take_event() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!pool.empty()) {
+                hipEvent_t e = pool.back();
+                pool.pop_back();
+                return e;
+            }
+        }
+        hipEvent_t e;
+        FHE_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return e;
+    }
+    void give_event(hipEvent_t e) {
+        std::lock_guard<std::mutex> lk(mu);
+        pool.push_back(e);
+    }
+    // the internal stream that shadows `user` on `device` (device < 0: on any device; all: every internal stream and the
+    // pooled events as well) is synchronised and destroyed
+    void drop(int device, hipStream_t user, bool all) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto it = reg.begin(); it != reg.end();) {
+            if (all || ((device < 0 || it->first.first == device) && it->first.second == user)) {
+                if (it->second) {
+                    (void)hipStreamSynchronize(it->second);
+                    (void)hipStreamDestroy(it->second);
+                }
+                it = reg.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        if (all) {
+            for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+            pool.clear();
+        }
+    }
+
+private:
+    std::mutex mu;
+    std::map<std::pair<int, hipStream_t>, hipStream_t> reg;
+    std::vector<hipEvent_t> pool;
+};
 
 // How a batch is cut into chunks, and whether the chunks alternate between two streams.
 // One stream: every launch should cover >> 512 workgroup slots (64-pair chunks are 15 % slower at C2), but beyond
@@ -1337,21 +1448,26 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     const size_t pre_bytes = m.mod_switch ? chunk * parts * PL * sizeof(u64) : 8;
     const bool dual = plan.dual;
     hipStream_t lanes[2] = {s0, s0};
-    AuxStream *aux = nullptr;
     struct Join {  // the internal stream always rejoins the caller's, also on an error path
-        AuxStream *a;
-        hipStream_t to;
+        hipStream_t aux = nullptr, to = nullptr;
+        hipEvent_t fork = nullptr, join = nullptr;
         ~Join() {
-            if (a && hipEventRecord(a->join, a->s) == hipSuccess) (void)hipStreamWaitEvent(to, a->join, 0);
+            if (aux && hipEventRecord(join, aux) == hipSuccess) (void)hipStreamWaitEvent(to, join, 0);
+            // (a wait captures the event's state when it is enqueued: both events may be reused right away)
+            if (fork) AuxStreams::get().give_event(fork);
+            if (join) AuxStreams::get().give_event(join);
         }
-    };
+    } join;
     if (dual) {
-        aux = &aux_for(b.device, s0);
-        lanes[1] = aux->s;
-        FHE_HIP_CHECK(hipEventRecord(aux->fork, s0));
-        FHE_HIP_CHECK(hipStreamWaitEvent(aux->s, aux->fork, 0));
+        AuxStreams &ax = AuxStreams::get();
+        join.to = s0;
+        join.fork = ax.take_event();
+        join.join = ax.take_event();
+        lanes[1] = ax.stream_for(b.device, s0);
+        FHE_HIP_CHECK(hipEventRecord(join.fork, s0));
+        FHE_HIP_CHECK(hipStreamWaitEvent(lanes[1], join.fork, 0));
+        join.aux = lanes[1];
     }
-    Join join{aux, s0};
     ChunkWs ws0(chunk, PK, PL, pre_bytes, lanes[0]);
     std::unique_ptr<ChunkWs> ws1;
     if (dual) ws1 = std::make_unique<ChunkWs>(chunk, PK, PL, pre_bytes, lanes[1]);

@@ -8,6 +8,7 @@
 #include <map>
 
 #include "engine.hpp"
+#include "ubench.hpp"
 
 using namespace fhe;
 
@@ -95,12 +96,15 @@ void set_device(const Ctx &c) {
 }
 
 // Host-pointer convenience: copy in, run `body(device_ptrs...)` on the null stream, copy out.
+// Staging blocks come from the engine's workspace pool (null stream), not from hipMalloc / hipFree per call: a host
+// call is synchronous, so a block released here is idle by the time the next call takes it.
 struct HostIO {
     std::vector<void *> bufs;
-    std::vector<std::pair<void *, size_t>> secrets;  // staging copies cleared before they are freed
+    std::vector<std::pair<void *, size_t>> secrets;  // staging copies cleared before they are released
     ~HostIO() {
         for (auto &s : secrets) (void)hipMemset(s.first, 0, s.second);
-        for (void *p : bufs) (void)hipFree(p);
+        if (!secrets.empty()) (void)hipStreamSynchronize(nullptr);
+        for (void *p : bufs) Workspace::get().release(p);
     }
     u64 *secret(u64 *d, size_t count) {
         secrets.emplace_back(d, std::max<size_t>(count, 1) * sizeof(u64));
@@ -112,8 +116,7 @@ struct HostIO {
         return d;
     }
     u64 *out(size_t count) {
-        void *d = nullptr;
-        FHE_HIP_CHECK(hipMalloc(&d, std::max<size_t>(count, 1) * sizeof(u64)));
+        void *d = Workspace::get().acquire(std::max<size_t>(count, 1) * sizeof(u64), nullptr);
         bufs.push_back(d);
         return (u64 *)d;
     }
@@ -170,6 +173,113 @@ int fhe_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// ------------------------------------------------ device memory and streams ----
+fhe_status fhe_buf_alloc(int device, size_t bytes, void **out) {
+    return guard([&] {
+        need(out, "out");
+        *out = nullptr;
+        int ndev = 0;
+        FHE_HIP_CHECK(hipGetDeviceCount(&ndev));
+        require(device >= 0 && device < ndev, E_NO_DEVICE, "no such HIP device");
+        FHE_HIP_CHECK(hipSetDevice(device));
+        FHE_HIP_CHECK(hipMalloc(out, std::max<size_t>(bytes, 1)));
+    });
+}
+fhe_status fhe_buf_free(void *buf) {
+    return guard([&] {
+        if (buf) FHE_HIP_CHECK(hipFree(buf));
+    });
+}
+static void copy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, void *stream, bool wait) {
+    if (bytes) {
+        need(dst, "dst");
+        need(src, "src");
+        FHE_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, as_stream(stream)));
+    }
+    if (wait) FHE_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+}
+fhe_status fhe_buf_upload_async(void *dst_dev, const void *src_host, size_t bytes, void *stream) {
+    return guard([&] { copy_async(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream, false); });
+}
+fhe_status fhe_buf_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream) {
+    return guard([&] { copy_async(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream, true); });
+}
+fhe_status fhe_buf_download_async(void *dst_host, const void *src_dev, size_t bytes, void *stream) {
+    return guard([&] { copy_async(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, stream, false); });
+}
+fhe_status fhe_buf_download(void *dst_host, const void *src_dev, size_t bytes, void *stream) {
+    return guard([&] { copy_async(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, stream, true); });
+}
+fhe_status fhe_buf_copy_async(void *dst_dev, const void *src_dev, size_t bytes, void *stream) {
+    return guard([&] { copy_async(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, stream, false); });
+}
+fhe_status fhe_buf_zero_async(void *buf, size_t bytes, void *stream) {
+    return guard([&] {
+        if (!bytes) return;
+        need(buf, "buf");
+        FHE_HIP_CHECK(hipMemsetAsync(buf, 0, bytes, as_stream(stream)));
+    });
+}
+fhe_status fhe_host_alloc(size_t bytes, void **out) {
+    return guard([&] {
+        need(out, "out");
+        *out = nullptr;
+        FHE_HIP_CHECK(hipHostMalloc(out, std::max<size_t>(bytes, 1), 0));
+    });
+}
+fhe_status fhe_host_free(void *p) {
+    return guard([&] {
+        if (p) FHE_HIP_CHECK(hipHostFree(p));
+    });
+}
+fhe_status fhe_stream_create(int device, void **out) {
+    return guard([&] {
+        need(out, "out");
+        *out = nullptr;
+        int ndev = 0;
+        FHE_HIP_CHECK(hipGetDeviceCount(&ndev));
+        require(device >= 0 && device < ndev, E_NO_DEVICE, "no such HIP device");
+        FHE_HIP_CHECK(hipSetDevice(device));
+        hipStream_t s = nullptr;
+        FHE_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        *out = (void *)s;
+    });
+}
+fhe_status fhe_stream_sync(void *stream) {
+    return guard([&] { FHE_HIP_CHECK(hipStreamSynchronize(as_stream(stream))); });
+}
+fhe_status fhe_stream_destroy(void *stream) {
+    return guard([&] {
+        if (!stream) return;   // the null stream is not ours to destroy
+        FHE_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+        // what the engine keeps per caller stream: its internal second stream and its idle scratch blocks
+        AuxStreams::get().drop(-1, as_stream(stream), false);
+        Workspace::get().drop_stream(as_stream(stream));
+        FHE_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
+    });
+}
+fhe_status fhe_device_sync(int device) {
+    return guard([&] {
+        int ndev = 0;
+        FHE_HIP_CHECK(hipGetDeviceCount(&ndev));
+        require(device >= 0 && device < ndev, E_NO_DEVICE, "no such HIP device");
+        FHE_HIP_CHECK(hipSetDevice(device));
+        FHE_HIP_CHECK(hipDeviceSynchronize());
+    });
+}
+fhe_status fhe_device_mem_info(int device, size_t *free_bytes, size_t *total_bytes) {
+    return guard([&] {
+        int ndev = 0;
+        FHE_HIP_CHECK(hipGetDeviceCount(&ndev));
+        require(device >= 0 && device < ndev, E_NO_DEVICE, "no such HIP device");
+        FHE_HIP_CHECK(hipSetDevice(device));
+        size_t f = 0, t = 0;
+        FHE_HIP_CHECK(hipMemGetInfo(&f, &t));
+        if (free_bytes) *free_bytes = f;
+        if (total_bytes) *total_bytes = t;
+    });
 }
 
 // ----------------------------------------------------------------------------- ctx ----
@@ -487,6 +597,42 @@ fhe_status fhe_poly_switch_down(const fhe_ctx *ctx, const uint64_t *in, uint64_t
         u64 *di = io.in(in, batch * pe), *dout = io.out(batch * (pe - c.n));
         switch_down_polys(c, di, pe, dout, pe - c.n, batch, nullptr);
         io.back(out, dout, batch * (pe - c.n));
+    });
+}
+
+static size_t iterations_between(const Ctx &from, const Ctx &to) {
+    const long it = from.niterations_to(to);
+    if (it < 0) throw StatusError(FHE_E_CONTEXT_NOT_REACHABLE, "ContextNotReachable");
+    return (size_t)it;
+}
+fhe_status fhe_poly_switch_down_to_dev(const fhe_ctx *from, const fhe_ctx *to, const uint64_t *in, uint64_t *out,
+                                       size_t batch, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(from);
+        need(to, "to");
+        const size_t iters = iterations_between(c, *to->c);
+        if (batch) {
+            need(in, "in");
+            need(out, "out");
+        }
+        switch_down_to_pb(c, iters, in, pe, out, pe - iters * c.n, batch, as_stream(stream));
+    });
+}
+fhe_status fhe_poly_switch_down_to(const fhe_ctx *from, const fhe_ctx *to, const uint64_t *in, uint64_t *out,
+                                   size_t batch) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(from);
+        need(to, "to");
+        const size_t iters = iterations_between(c, *to->c);
+        if (batch) {
+            need(in, "in");
+            need(out, "out");
+        }
+        const size_t po = pe - iters * c.n;
+        HostIO io;
+        u64 *di = io.in(in, batch * pe), *dout = io.out(batch * po);
+        switch_down_to_pb(c, iters, di, pe, dout, po, batch, nullptr);
+        io.back(out, dout, batch * po);
     });
 }
 
@@ -856,6 +1002,42 @@ fhe_status fhe_bfv_switch_down(const fhe_ctx *ctx, size_t nparts, const uint64_t
     });
 }
 
+// Ciphertext::switch_to_level (F/bfv/ciphertext.rs:164-183), `levels` = target_level - level
+static void check_levels(const Ctx &c, size_t levels) {
+    if (!c.at_level(levels))
+        throw StatusError(FHE_E_INVALID_LEVEL, "InvalidLevel: the context chain has " + std::to_string(c.L - 1) +
+                                                   " levels below this one, asked for " + std::to_string(levels));
+}
+fhe_status fhe_bfv_switch_to_level_dev(const fhe_ctx *ctx, size_t levels, size_t nparts, const uint64_t *ct,
+                                       uint64_t *out, size_t batch, void *stream) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        (void)pe;
+        check_levels(c, levels);
+        if (batch && nparts) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        switch_down_to_ntt(c, levels, ct, out, batch * nparts, as_stream(stream));
+    });
+}
+fhe_status fhe_bfv_switch_to_level(const fhe_ctx *ctx, size_t levels, size_t nparts, const uint64_t *ct, uint64_t *out,
+                                   size_t batch) {
+    return guard([&] {
+        FHE_POLY_IO_PROLOGUE(ctx);
+        check_levels(c, levels);
+        if (batch && nparts) {
+            need(ct, "ct");
+            need(out, "out");
+        }
+        const size_t po = pe - levels * c.n;
+        HostIO io;
+        u64 *di = io.in(ct, batch * nparts * pe), *dout = io.out(batch * nparts * po);
+        switch_down_to_ntt(c, levels, di, dout, batch * nparts, nullptr);
+        io.back(out, dout, batch * nparts * po);
+    });
+}
+
 // ------------------------------------------------------ PIR / RGSW / inner sum ----
 fhe_status fhe_bfv_dot_product_scalar_dev(const fhe_ctx *ctx, size_t nparts, size_t count, const uint64_t *cts,
                                           int cts_shared, const uint64_t *pts, int pts_shared, uint64_t *out,
@@ -1110,9 +1292,18 @@ static std::unique_ptr<Mul> make_mul(const Scaler *el, const Scaler *er, const S
     m->mod_switch = mod_switch;
     m->base = el->from;
     m->mulc = el->to;
-    if (rk)  // enable_relinearization (mul.rs:141-151)
+    // the extenders hand their common rows over in Ntt form (M/rq/scaler.rs:61-65): those moduli must be evaluated in
+    // the same order on both sides, i.e. both contexts were built from the same NTT tables
+    require(m->base->same_tables(*m->mulc, std::min(el->ncommon, er->ncommon)) &&
+                el->from->same_tables(*er->from, el->from->L) && el->to->same_tables(*er->to, el->to->L) &&
+                dn->from->same_tables(*el->to, el->to->L) && dn->to->same_tables(*el->from, el->from->L),
+            E_PARAMETER_MISMATCH, "ParameterMismatch: the multiplicator's contexts were built with different NTT tables");
+    if (rk) {  // enable_relinearization (mul.rs:141-151)
         require(rk->ct_ctx->same_ring(*m->base), E_PARAMETER_MISMATCH,
                 "ParameterMismatch: relinearization key level != multiplicator level");
+        require(rk->ct_ctx->same_tables(*m->base, m->base->L), E_PARAMETER_MISMATCH,
+                "ParameterMismatch: relinearization key and multiplicator were built with different NTT tables");
+    }
     if (mod_switch) require(m->base->next != nullptr, E_NO_MORE_CONTEXT, "NoMoreContext");  // mul.rs:155-162
     return m;
 }
@@ -1381,7 +1572,20 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
                    part0, total);
     });
 }
-size_t fhe_workspace_trim(void) { return Workspace::get().trim(); }
+size_t fhe_workspace_trim(void) {
+    AuxStreams::get().drop(-1, nullptr, true);   // internal streams and pooled events go too (recreated on demand)
+    return Workspace::get().trim();
+}
+fhe_status fhe_ubench_int(int device, int which, double min_seconds, double *ops_per_s) {
+    return guard([&] {
+        need(ops_per_s, "ops_per_s");
+        *ops_per_s = 0;
+        int ndev = 0;
+        FHE_HIP_CHECK(hipGetDeviceCount(&ndev));
+        require(device >= 0 && device < ndev, E_NO_DEVICE, "no such HIP device");
+        *ops_per_s = ub::run(device, which, min_seconds);
+    });
+}
 void fhe_prof_enable(int on) { Profiler::get().enabled = on != 0; }
 void fhe_prof_reset(void) {
     try {

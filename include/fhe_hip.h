@@ -10,7 +10,10 @@
  *    exactly `fhe_math::rq::Poly`'s `Array2<u64>` layout (M/rq/mod.rs:126-133, 189-204) with
  *    outer batch dimensions.  Inputs and outputs are canonical residues in [0, q_i).
  *  - Plain entry points take HOST pointers and are synchronous.  `_dev` twins take DEVICE
- *    pointers plus a `hipStream_t` (passed as `void*`) and are stream-ordered.
+ *    pointers plus a `hipStream_t` (passed as `void*`) and are stream-ordered.  Device buffers and
+ *    streams come from the "device memory and streams" block below (or from any other HIP
+ *    allocator in the process: the engine only sees pointers), so a host written in C, Rust, Go ...
+ *    keeps polynomials resident on the GPU between calls without linking HIP itself.
  *  - Handles are opaque, immutable after creation and may be shared by concurrent callers
  *    working on different buffers (matches `Arc<Context>`, M/rq/context.rs:8-19).
  *  - Every function returns 0 (FHE_OK) or a negative `fhe_status`; nothing throws or aborts
@@ -66,6 +69,34 @@ const char *fhe_last_error(void);
 const char *fhe_version(void);
 /* Number of visible HIP devices (0 without a GPU).  Never fails. */
 int fhe_device_count(void);
+
+/* -------------------------------------------------- device memory and streams ---- */
+/* What a non-HIP host needs to use the `_dev` entry points: `rq::Poly`'s `coefficients: Array2<u64>`
+ * (M/rq/mod.rs:126-133) gets a device-resident shadow that lives across calls -- upload once,
+ * chain multiply -> relinearise -> rotate -> switch_down on the device, download lazily (the Rust side of
+ * this is `DevicePoly` / `DeviceCiphertext` in rust/fhe-math-hip).
+ *  - A stream is a plain `hipStream_t` handed out as `void *` (non-blocking with respect to the null
+ *    stream); NULL everywhere means the device's null stream.  Work on one stream runs in order.
+ *  - `*_async` calls only enqueue: with pageable host memory HIP stages the bytes itself, with pinned
+ *    host memory (fhe_host_alloc) the caller must keep the host buffer untouched until the stream
+ *    reaches that point (fhe_stream_sync).  The plain twins additionally wait for the stream.
+ *  - fhe_stream_destroy waits for the stream, then frees what the engine kept for it (its internal
+ *    second stream and idle scratch blocks).  Handles (contexts, keys ...) are not tied to a stream. */
+fhe_status fhe_buf_alloc(int device, size_t bytes, void **out);      /* hipMalloc on `device`           */
+fhe_status fhe_buf_free(void *buf);                                   /* NULL is a no-op                  */
+fhe_status fhe_buf_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+fhe_status fhe_buf_upload_async(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+fhe_status fhe_buf_download(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+fhe_status fhe_buf_download_async(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+fhe_status fhe_buf_copy_async(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+fhe_status fhe_buf_zero_async(void *buf, size_t bytes, void *stream);  /* e.g. wiping a secret-dependent buffer */
+fhe_status fhe_host_alloc(size_t bytes, void **out);                 /* pinned host memory (true async copies) */
+fhe_status fhe_host_free(void *p);
+fhe_status fhe_stream_create(int device, void **stream_out);
+fhe_status fhe_stream_sync(void *stream);
+fhe_status fhe_stream_destroy(void *stream);
+fhe_status fhe_device_sync(int device);
+fhe_status fhe_device_mem_info(int device, size_t *free_bytes, size_t *total_bytes);  /* either may be NULL */
 
 /* ------------------------------------------------------------------ rq::Context ---- */
 /* Context::new (M/rq/context.rs:42-92).  `device` >= 0 uploads tables to that GPU; -1 builds
@@ -126,6 +157,14 @@ fhe_status fhe_poly_substitute_dev(const fhe_ctx *ctx, size_t exponent, const ui
 fhe_status fhe_poly_switch_down(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, size_t batch);
 fhe_status fhe_poly_switch_down_dev(const fhe_ctx *ctx, const uint64_t *in, uint64_t *out, size_t batch,
                                     void *stream);
+
+/* Poly::<PowerBasis>::switch_down_to (M/rq/mod.rs:498-507): niterations_to(to) applications of switch_down in one
+ * call; in [batch][from.L][N] -> out [batch][to.L][N], PowerBasis.  `to` not on `from`'s chain ->
+ * FHE_E_CONTEXT_NOT_REACHABLE; from == to copies. */
+fhe_status fhe_poly_switch_down_to(const fhe_ctx *from, const fhe_ctx *to, const uint64_t *in, uint64_t *out,
+                                   size_t batch);
+fhe_status fhe_poly_switch_down_to_dev(const fhe_ctx *from, const fhe_ctx *to, const uint64_t *in, uint64_t *out,
+                                       size_t batch, void *stream);
 
 /* Rq wire format (`impl From<&Poly> for Rq` / parse_proto, M/rq/convert.rs:17-44, 46-99; Modulus::
  * serialize_vec / deserialize_vec, M/zq/mod.rs:783-793; fhe-util transcode_{to,from}_bytes,
@@ -211,6 +250,16 @@ fhe_status fhe_bfv_galois_dev(const fhe_ksk *gk, size_t exponent, const uint64_t
 fhe_status fhe_bfv_switch_down(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, uint64_t *out, size_t batch);
 fhe_status fhe_bfv_switch_down_dev(const fhe_ctx *ctx, size_t nparts, const uint64_t *ct, uint64_t *out,
                                    size_t batch, void *stream);
+
+/* Ciphertext::switch_to_level (F/bfv/ciphertext.rs:164-183) with levels = target_level - level >= 0:
+ * ct [batch][nparts][L][N] Ntt -> out [batch][nparts][L-levels][N] Ntt.  The reference loops
+ * switch_down (PowerBasis -> divide-and-round -> Ntt per level); here one inverse transform, `levels` divide-and-round
+ * passes and one forward transform give the same values (the Ntt round trips in between are the identity).
+ * levels beyond the chain -> FHE_E_INVALID_LEVEL; levels == 0 copies. */
+fhe_status fhe_bfv_switch_to_level(const fhe_ctx *ctx, size_t levels, size_t nparts, const uint64_t *ct, uint64_t *out,
+                                   size_t batch);
+fhe_status fhe_bfv_switch_to_level_dev(const fhe_ctx *ctx, size_t levels, size_t nparts, const uint64_t *ct,
+                                       uint64_t *out, size_t batch, void *stream);
 
 /* ------------------------------------ PIR / RGSW / inner sum ("next" rows) ---- */
 /* fhe_math::rq::dot_product (M/rq/ops.rs:449-570) and bfv::dot_product_scalar
@@ -369,9 +418,16 @@ fhe_status fhe_generate_moduli(const size_t *sizes, size_t count, size_t degree,
  * out[b][part_local][row][coeff], ct = ct0 + b, part = part0 + part_local. */
 fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0, uint64_t part0, size_t nparts,
                                  uint64_t *out, size_t batch, void *stream);
-/* The engine keeps its scratch buffers (grow-only, reused in stream order per device) between calls;
- * this frees every idle one and returns the number of bytes released. */
+/* The engine keeps its scratch buffers (grow-only, reused in stream order per device), its internal second
+ * streams and a few pooled events between calls; this frees every idle one (call it while no engine call is
+ * running) and returns the number of scratch bytes released. */
 size_t fhe_workspace_trim(void);
+/* Integer-issue ceiling ("report both ceilings"): register-resident loops of the instructions /
+ * butterflies the NTT-type kernels are made of, chip-wide, no memory traffic, run for at least min_seconds
+ * (0 < min_seconds <= 10).  which: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32, 3 lazy Shoup product,
+ * 4 forward butterfly (any modulus < 2^62), 5 forward butterfly for moduli < 2^60, 6 inverse butterfly;
+ * *ops_per_s = lane-operations (multiplies / products / butterflies) per second.  Measurement aid, not on the path. */
+fhe_status fhe_ubench_int(int device, int which, double min_seconds, double *ops_per_s);
 /* Per-kernel HIP-event timing (events recorded on the launching stream). */
 void fhe_prof_enable(int on);
 void fhe_prof_reset(void);

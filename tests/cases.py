@@ -177,6 +177,127 @@ def case_switch_down(fhe, dev, n=16):
     assert np.array_equal(got, want)
 
 
+def case_switch_down_to(fhe, dev, n=16):
+    """Poly::switch_down_to (rq/mod.rs:498-507, tests :1075-1122) and Ciphertext::switch_to_level
+    (bfv/ciphertext.rs:164-183) in ONE call each, against the oracle's level-by-level loops; errors as the reference."""
+    x = Xfer(dev)
+    rng = random.Random(12)
+    o = OCtx(MODULI5, n)
+    c = fhe.Context(MODULI5, n)
+    ps = [rand_poly(o, POWER_BASIS, rng) for _ in range(3)]
+    batch = x.to(np.array([arr(p) for p in ps], dtype=np.uint64))
+    for lvl in range(len(MODULI5)):
+        want = np.array([arr(p.switch_down_to(o.context_at_level(lvl))) for p in ps], dtype=np.uint64)
+        got = x.back(c.switch_down_to(batch, c.at_level(lvl)))
+        assert got.shape == want.shape and np.array_equal(got, want), lvl
+    # from an intermediate level
+    mid_o, mid_c = o.context_at_level(1), c.at_level(1)
+    q = rand_poly(mid_o, POWER_BASIS, rng)
+    assert np.array_equal(x.back(mid_c.switch_down_to(x.to(arr(q)[None]), c.at_level(3)))[0],
+                          arr(q.switch_down_to(o.context_at_level(3))))
+    # a context that is not below `from` on the chain: ContextNotReachable (rq/mod.rs:503-505)
+    for bad_from, bad_to in ((mid_c, c), (c, fhe.Context(Q3, n))):
+        try:
+            bad_from.switch_down_to(x.to(np.zeros((1, bad_from.nmoduli, n), dtype=np.uint64)), bad_to)
+            raise AssertionError("unreachable context accepted")
+        except fhe.FheError as err:
+            assert err.code == -9, err
+    # Ciphertext::switch_to_level on 2 ciphertexts x 3 parts: every reachable number of levels
+    cts = [[rand_poly(o, NTT, rng) for _ in range(3)] for _ in range(2)]
+    src = x.to(np.array([[arr(q) for q in ct] for ct in cts], dtype=np.uint64))
+    for levels in range(len(MODULI5)):
+        want = []
+        for ct in cts:
+            cur = list(ct)
+            for _ in range(levels):   # the reference's loop: PowerBasis -> switch_down -> Ntt per level
+                cur = [q.into_power_basis().switch_down().into_ntt() for q in cur]
+            want.append([arr(q) for q in cur])
+        got = x.back(c.ciphertext_switch_to_level(src, levels))
+        assert np.array_equal(got, np.array(want, dtype=np.uint64)), levels
+    try:
+        c.ciphertext_switch_to_level(src, len(MODULI5))
+        raise AssertionError("level beyond the chain accepted")
+    except fhe.FheError as err:
+        assert err.code == -12, err
+
+
+def case_device_buffers(fhe, n=32):
+    """The C ABI's own device memory and streams (fhe_buf_*, fhe_stream_*): a polynomial batch is uploaded once,
+    goes Ntt -> (.)^2 -> PowerBasis -> switch_down_to -> download without leaving the device, on a stream created
+    through the ABI, and equals the oracle; pinned host memory round-trips; views index without copying."""
+    import ctypes as C
+    from fhe_rs_amd import _lib
+    rng = random.Random(13)
+    o = OCtx(MODULI5, n)
+    c = fhe.Context(MODULI5, n)
+    ps = [rand_poly(o, POWER_BASIS, rng) for _ in range(4)]
+    host = np.array([arr(p) for p in ps], dtype=np.uint64)
+    with fhe.Stream(0) as st:
+        d = fhe.DeviceArray.from_numpy(host)
+        assert d.shape == host.shape and np.array_equal(d.download(), host)
+        assert np.array_equal(d[2].download(), host[2]) and np.array_equal(d[-1][1].download(), host[3][1])
+        f = c.ntt_forward(d)                       # in place, on the ABI stream
+        sq = c.mul(f, fhe.DeviceArray.from_numpy(f.download()))
+        pb = c.ntt_backward(sq)
+        low = c.switch_down_to(pb, c.at_level(2))
+        st.synchronize()
+        want = []
+        for p in ps:
+            f_o = p.into_ntt()
+            want.append(arr(f_o.mul(f_o).into_power_basis().switch_down_to(o.context_at_level(2))))
+        assert np.array_equal(low.download(), np.array(want, dtype=np.uint64))
+        # pinned host memory + the async copies
+        L = _lib.lib()
+        hp = C.c_void_p()
+        _lib.check(L.fhe_host_alloc(host.nbytes, C.byref(hp)))
+        C.memmove(hp, host.ctypes.data, host.nbytes)
+        e = fhe.DeviceArray(host.shape)
+        e2 = fhe.DeviceArray(host.shape)
+        _lib.check(L.fhe_buf_upload_async(C.c_void_p(e.data_ptr()), hp, host.nbytes, st.handle))
+        _lib.check(L.fhe_buf_copy_async(C.c_void_p(e2.data_ptr()), C.c_void_p(e.data_ptr()), host.nbytes, st.handle))
+        _lib.check(L.fhe_buf_zero_async(C.c_void_p(e.data_ptr()), host.nbytes, st.handle))
+        back = np.empty_like(host)
+        _lib.check(L.fhe_buf_download_async(back.ctypes.data_as(C.c_void_p), C.c_void_p(e2.data_ptr()), host.nbytes, st.handle))
+        _lib.check(L.fhe_stream_sync(st.handle))
+        assert np.array_equal(back, host) and not e.download().any()
+        _lib.check(L.fhe_host_free(hp))
+        free_b, total_b = fhe.device_mem_info(0)
+        assert 0 < free_b <= total_b
+        for a in (d, e, e2):
+            a.free()
+    st.destroy()
+    assert L.fhe_buf_alloc(10 ** 6, 8, C.byref(C.c_void_p())) == -18   # no such device
+
+
+def case_table_mismatch(fhe, nmod=3, n=16):
+    """Handles built from different NTT tables must not be combined where Ntt-form rows cross between them
+    (key switch: ct rows read as transforms under the key moduli; multiplicator: common rows of the extenders):
+    same moduli but another primitive root -> ParameterMismatch instead of silently wrong ciphertexts."""
+    opar, par = _params(fhe, nmod, n)
+    ctx = par.context_at_level(0)
+    base = OCtx(opar.moduli, n)
+    other = OCtx(opar.moduli, n, psis=[pow(op.psi, 3, op.p.p) for op in base.ops])
+    ctx2 = fhe.Context(opar.moduli, n, tables=oracle_tables(other))
+    same = fhe.Context(opar.moduli, n, tables=oracle_tables(base))   # the same tables through another door: fine
+    rng = random.Random(5)
+    sk = obfv.SecretKey.random(opar, rng)
+    c0, c0s, c1, c1s = ksk_arrays(obfv.RelinearizationKey(sk, rng).ksk)
+    fhe.KeySwitchingKey(ctx, same, c0, c1, c0s, c1s)
+    for ct_ctx, k_ctx in ((ctx, ctx2), (ctx2, ctx)):
+        try:
+            fhe.KeySwitchingKey(ct_ctx, k_ctx, c0, c1, c0s, c1s)
+            raise AssertionError("key over different NTT tables accepted")
+        except fhe.FheError as e:
+            assert e.code == -11, e
+    # a multiplicator whose relinearisation key lives over other tables than its level
+    rk2 = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx2, ctx2, c0, c1, c0s, c1s))
+    try:
+        fhe.Multiplicator.default(par, rk2, 0)
+        raise AssertionError("multiplicator with a key over different NTT tables accepted")
+    except fhe.FheError as e:
+        assert e.code == -11, e
+
+
 NUMS = [1, 2, 3, 100, 1000, 4611686018326724610]
 DENS = [1, 2, 3, 4, 100, 101, 1000, 1001, 4611686018326724610]
 

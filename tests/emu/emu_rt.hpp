@@ -183,6 +183,13 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
     return hipSuccess;
 }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void *p) { return hipFree(p); }
+inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
+    *free_b = *total_b = (size_t)1 << 34;
+    return hipSuccess;
+}
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;

@@ -70,12 +70,16 @@ def ct_arr(ct):
 
 
 class Xfer:
-    """Moves arrays to the place the engine call should see them: numpy (host-pointer API) or
-    torch CUDA tensors (device-pointer `_dev` API)."""
+    """Moves arrays to the place the engine call should see them: numpy (host-pointer API, dev = False), torch CUDA
+    tensors (device-pointer `_dev` API, dev = True) or `DeviceArray`s allocated through the C ABI itself (dev = "abi":
+    the `_dev` API as a host without PyTorch uses it; the caller makes a `Stream` current)."""
 
     def __init__(self, dev):
         self.dev = dev
-        if dev:
+        if dev == "abi":
+            import fhe_rs_amd
+            self.DeviceArray = fhe_rs_amd.DeviceArray
+        elif dev:
             import torch
             self.torch = torch
 
@@ -83,16 +87,26 @@ class Xfer:
         a = np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
         if not self.dev:
             return a
+        if self.dev == "abi":
+            return self.DeviceArray.from_numpy(a)
         return self.torch.from_numpy(a.view(np.int64)).cuda()
 
     def to_bytes(self, a):
         a = np.ascontiguousarray(np.asarray(a, dtype=np.uint8))
-        return a if not self.dev else self.torch.from_numpy(a.copy()).cuda()
+        if not self.dev:
+            return a
+        if self.dev == "abi":
+            return self.DeviceArray.from_numpy(a)
+        return self.torch.from_numpy(a.copy()).cuda()
 
     def back_bytes(self, x):
-        return np.asarray(x) if not self.dev else x.cpu().numpy()
+        if not self.dev:
+            return np.asarray(x)
+        return x.download() if self.dev == "abi" else x.cpu().numpy()
 
     def back(self, x):
         if not self.dev:
             return np.asarray(x)
+        if self.dev == "abi":
+            return x.download()
         return x.cpu().numpy().view(np.uint64)

@@ -47,6 +47,22 @@ def test_loaded_library_is_the_hip_build(fhe):
     del out
 
 
+def test_release_build_reads_no_environment(fhe):
+    """No wrong-result or kernel-selection switch can reach the shipped library: it does not import getenv and holds
+    none of the FHE_* variable names (those exist only in -DFHE_LAB builds, which the package never loads)."""
+    raw = open(HIP_LIB, "rb").read()
+    for name in (b"FHE_DEBUG", b"FHE_LAB_", b"FHE_NO_", b"FHE_KS_", b"FHE_NTT_", b"FHE_SENS"):
+        assert name not in raw, name
+    nm = subprocess.check_output(["nm", "-D", "--undefined-only", HIP_LIB], text=True)
+    assert "getenv" not in nm
+    # the build recipe itself never defines FHE_LAB, and the product sources keep the lab kernels out of reach
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "FHE_LAB" not in entry
+    kern = open(os.path.join(ROOT, "fhe.rs_amd", "csrc", "kernels.hpp")).read()
+    for rejected in ("ntt_fwd_swap_kernel", "ntt_fwd8_kernel", "ks_pair_kernel", "FHE_SENS"):
+        assert rejected not in kern.split("#if defined(FHE_LAB)")[0], rejected
+
+
 def test_missing_extension_fails_loudly(tmp_path):
     """No silent CPU fallback: importing the package from a copy without the .so raises."""
     import shutil

@@ -1,0 +1,59 @@
+"""A host that is not Python: tests/c_host/c2_golden.c (C99, links only libfhe_hip.so) allocates its device buffers
+and stream through the C ABI, runs BASELINE config C2 at batch 1024 on `fhe_bfv_mul_dev` and compares whole
+ciphertexts with the committed digests of tests/golden/c2_digest.json.  Python here only compiles and launches it."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from helpers import ROOT
+
+SRC = os.path.join(ROOT, "tests", "c_host", "c2_golden.c")
+INC = os.path.join(ROOT, "include")
+LIBDIR = os.path.join(ROOT, "fhe.rs_amd")
+
+
+def build(tmp_path):
+    import __graft_entry__ as g
+    g.build()
+    exe = str(tmp_path / "c2_golden")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", INC, SRC, "-o", exe, "-L", LIBDIR,
+                           "-lfhe_hip", "-Wl,-rpath," + LIBDIR])
+    return exe
+
+
+def test_c_host_compiles_and_links(tmp_path):
+    """CPU: the program builds as strict C99 against the header and the library; without a GPU it stops cleanly."""
+    exe = build(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_c_host_on_emulated_kernels(tmp_path):
+    """CPU: the same program linked against the HOST EMULATION build of the kernel sources (tests/emu, test
+    infrastructure) reproduces the committed C2 digests of ciphertexts 0 and 1 at batch 2 -- the whole
+    buffer / stream / key / multiply path of the ABI, without a GPU."""
+    from helpers import build_emu
+    emu = build_emu()
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "c2_digest.json")))
+    exe = str(tmp_path / "c2_golden_emu")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I", INC, SRC, "-o", exe, emu,
+                           "-Wl,-rpath," + os.path.dirname(emu)])
+    outs = [e for e in g["outputs"] if e["ct"] < 2]
+    args = [exe, str(g["seed"]), str(g["plaintext"]), "2", g["key_sha256"]]
+    args += [f'{e["ct"]}:{e["input_sha256"]}:{e["output_sha256"]}' for e in outs]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_c_host_reproduces_c2_digest(tmp_path):
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "c2_digest.json")))
+    exe = build(tmp_path)
+    args = [exe, str(g["seed"]), str(g["plaintext"]), "1024", g["key_sha256"]]
+    args += [f'{e["ct"]}:{e["input_sha256"]}:{e["output_sha256"]}' for e in g["outputs"]]
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("PYTHON", "TORCH"))}   # nothing Python-side matters
+    r = subprocess.run(args, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("ALL OK") and r.stdout.count(" ok") == 1 + 2 * len(g["outputs"]), r.stdout

@@ -51,6 +51,23 @@ def test_switch_down(fhe):
     cases.case_switch_down(fhe, False)
 
 
+def test_switch_down_to(fhe):
+    cases.case_switch_down_to(fhe, False)
+
+
+def test_switch_down_to_abi_buffers(fhe):
+    with fhe.Stream(0):
+        cases.case_switch_down_to(fhe, "abi")
+
+
+def test_device_buffers_and_streams(fhe):
+    cases.case_device_buffers(fhe)
+
+
+def test_table_mismatch_is_rejected(fhe):
+    cases.case_table_mismatch(fhe)
+
+
 def test_scaler_grid(fhe):
     cases.case_scaler_grid(fhe, False)
 
@@ -219,3 +236,23 @@ def test_key_switch_large_rows(fhe, n):
     for i in range(2):
         w0, w1 = ck.key_switch(p[i])
         assert np.array_equal(np.asarray(g0[i]), w0) and np.array_equal(np.asarray(g1[i]), w1)
+
+
+def test_params_with_short_tables_fail_cleanly(fhe):
+    """A host callback that returns a table shorter than `degree` must fail creation (NttOperatorUnavailable), not
+    hand uninitialised memory to the device as twiddles."""
+    from fhe_oracle.rq import Context as OCtx
+    from helpers import oracle_tables
+    import numpy as np
+
+    def short(modulus, degree):
+        t = oracle_tables(OCtx([modulus], degree))
+        d = {k: np.array(v[0], dtype=np.uint64) for k, v in t.items() if k not in ("size_inv", "size_inv_shoup")}
+        d["zetas_inv"] = d["zetas_inv"][: degree // 2]
+        d["size_inv"], d["size_inv_shoup"] = t["size_inv"][0], t["size_inv_shoup"][0]
+        return d
+    try:
+        fhe.BfvParameters(16, 1153, moduli_sizes=[50, 50], tables_fn=short)
+        raise AssertionError("short host table accepted")
+    except fhe.FheError as e:
+        assert e.code == -5, e

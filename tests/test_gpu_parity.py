@@ -64,6 +64,38 @@ def test_switch_down(fhe, dev):
     cases.case_switch_down(fhe, dev)
 
 
+@pytest.mark.parametrize("dev", [False, True, "abi"])
+def test_switch_down_to(fhe, dev):
+    if dev == "abi":
+        with fhe.Stream(0):
+            cases.case_switch_down_to(fhe, dev)
+    else:
+        cases.case_switch_down_to(fhe, dev)
+
+
+def test_device_buffers_and_streams(fhe):
+    cases.case_device_buffers(fhe)
+
+
+def test_table_mismatch_is_rejected(fhe):
+    cases.case_table_mismatch(fhe)
+
+
+@pytest.mark.parametrize("what", ["multiply", "galois", "key_switch", "wire"])
+def test_abi_owned_buffers(fhe, what):
+    """The `_dev` entry points on buffers and a stream that come from the C ABI itself (no torch allocator)."""
+    with fhe.Stream(0) as st:
+        if what == "multiply":
+            cases.case_multiply(fhe, "abi", nmod=3, n=64, batch=5)
+        elif what == "galois":
+            cases.case_galois(fhe, "abi")
+        elif what == "key_switch":
+            cases.case_key_switch_levels(fhe, "abi")
+        else:
+            cases.case_wire_format(fhe, "abi")
+        st.synchronize()
+
+
 def test_scaler_grid(fhe):
     cases.case_scaler_grid(fhe, True)
 
@@ -406,3 +438,25 @@ def test_multiply_two_streams(fhe):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+def test_release_library_ignores_lab_environment(tmp_path):
+    """Round 2's library read kernel-selection and wrong-result switches from the environment on every launch.  The
+    release build reads none: with every one of those variables set, a fresh process still matches the oracle."""
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    names = ["FHE_DEBUG_NTT_NOMEM", "FHE_DEBUG_KS_NOMEM", "FHE_DEBUG_SYNC", "FHE_NO_NARROW", "FHE_NTT_SWAP", "FHE_NTT_CPT8",
+             "FHE_KS_VARIANT", "FHE_KS14_PLAN", "FHE_KS_PERSIST", "FHE_KS_SPLIT14", "FHE_NO_KS_XHAT", "FHE_NO_SKIP_COPY",
+             "FHE_NO_TENSOR_FUSION"]
+    names += [n.replace("FHE_", "FHE_LAB_") for n in names]
+    env = dict(os.environ, **{n: "1" for n in names})
+    code = ("import sys; sys.path[:0] = [r'%s', r'%s/oracle', r'%s/tests'];"
+            "import fhe_rs_amd as fhe, cases;"
+            "cases.case_multiply(fhe, True, nmod=3, n=64, batch=4);"
+            "cases.case_key_switch_levels(fhe, True);"
+            "cases.case_ntt(fhe, True, 4096, batch=2);"
+            "print('lab-env ok')") % (ROOT, ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "lab-env ok" in r.stdout, r.stdout + r.stderr

@@ -967,6 +967,31 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
                dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,       \
                k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,               \
                k_.digit_arg(), xhat, xhat_stride, (uint32_t)(npolys * kc.L))
+#if defined(FHE_LAB)
+    if constexpr (LOGN == 13) {
+        // FHE_LAB_KS13_T512 = 1: 512 threads x 16 coefficients, both accumulator sets in registers, tile-only LDS (two
+        // workgroups per CU), mixed radix-8 / radix-4 passes; = 2: the same with radix-4 passes throughout
+        static const int t512 = FHE_LAB_INT("KS13_T512", 0);
+        if (t512) {
+            const size_t lds2 = k::lds_words(1u << LOGN) * sizeof(u64);
+            const unsigned grid2 = (unsigned)(npolys * kc.L);
+#define FHE_KS_T512(NW, GMV)                                                                                       \
+    allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 512>), lds2);                                                 \
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV, 512>), dim3(grid2), dim3(512), lds2, s, p,   \
+               p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(),   \
+               kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, grid2)
+            if (t512 == 2) {
+                if (narrow) { FHE_KS_T512(true, 2); } else { FHE_KS_T512(false, 2); }
+            } else if (t512 == 3) {
+                if (narrow) { FHE_KS_T512(true, k::KS_GMAX); } else { FHE_KS_T512(false, k::KS_GMAX); }
+            } else {
+                if (narrow) { FHE_KS_T512(true, k::GM_MIXED); } else { FHE_KS_T512(false, k::GM_MIXED); }
+            }
+#undef FHE_KS_T512
+            return;
+        }
+    }
+#endif
     if constexpr (LOGN == 14) {   // (radix-4 passes at N = 8192 measured slower: 0.559 vs 0.532 ms per launch)
         if (plan14 == 4) {
             if (narrow) {
@@ -1009,7 +1034,10 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     // N = 16384: whole-row kernel (1024 threads x 16 coefficients, 24 VGPRs spilled) or two 8192-point sub-blocks
     // with the first stage folded into the loader (FHE_KS_SPLIT14=1)
     static const bool split14 = FHE_LAB_INT("KS_SPLIT14", 0) != 0;
-    if (kc.logn <= 13 || (kc.logn == 14 && !split14)) {  // (N = 8192 as 2 x 4096 measured +-1 %)
+    // lab builds, FHE_LAB_KS_HALF13=1: N = 8192 as two 4096-point sub-blocks (512 threads, 34 KiB tile + 32 KiB of LDS
+    // accumulators: two workgroups per CU), the first stage folded into the loader
+    static const bool half13 = FHE_LAB_INT("KS_HALF13", 0) != 0;
+    if (kc.logn <= 12 || (kc.logn == 13 && !half13) || (kc.logn == 14 && !split14)) {
 #define FHE_KS_CASE(LN) \
     case LN: launch_ks_fused<LN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride); break;
         switch (kc.logn) {
@@ -1022,14 +1050,28 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     }
     // Rows larger than LDS (N >= 32768): one workgroup per 8192-point sub-block, the first
     // logn - 13 stages folded into its loader (ks_fused_split_kernel).
-    const size_t lds = (k::lds_words(8192) + 8192) * sizeof(u64);
     bool narrow = !FHE_LAB_FLAG("NO_NARROW");
     for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
-#define FHE_KS_SPLIT_LAUNCH(G0, NW)                                                                                \
-    allow_big_lds((k::ks_fused_split_kernel<G0, 13, NW>), lds);                                                    \
-    FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0, 13, NW>), dim3((unsigned)((npolys * kc.L) << G0)), \
-               dim3(1024), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p,  \
-               k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride)
+#define FHE_KS_SPLIT_LAUNCH_M(G0, LM, NW)                                                                          \
+    do {                                                                                                           \
+        const size_t lds_ = (k::lds_words(1u << LM) + ((size_t)1 << LM)) * sizeof(u64);                            \
+        allow_big_lds((k::ks_fused_split_kernel<G0, LM, NW>), lds_);                                               \
+        FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0, LM, NW>),                                     \
+                   dim3((unsigned)((npolys * kc.L) << G0)), dim3((1u << LM) / 8), lds_, s, p, p_stride, o0, o1,    \
+                   out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(),       \
+                   (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride);                       \
+    } while (0)
+#define FHE_KS_SPLIT_LAUNCH(G0, NW) FHE_KS_SPLIT_LAUNCH_M(G0, 13, NW)
+#if defined(FHE_LAB)
+    if (kc.logn == 13) {
+        if (narrow) {
+            FHE_KS_SPLIT_LAUNCH_M(1, 12, true);
+        } else {
+            FHE_KS_SPLIT_LAUNCH_M(1, 12, false);
+        }
+        return;
+    }
+#endif
 #define FHE_KS_SPLIT_CASE(G0)                                                                                      \
     case 13 + G0:                                                                                                  \
         if (narrow) {                                                                                              \
@@ -1044,6 +1086,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     }
 #undef FHE_KS_SPLIT_CASE
 #undef FHE_KS_SPLIT_LAUNCH
+#undef FHE_KS_SPLIT_LAUNCH_M
 }
 
 // Poly::<PowerBasis>::switch_down_to (M/rq/mod.rs:498-507): `iters` applications of switch_down.

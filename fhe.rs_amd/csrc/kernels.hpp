@@ -906,8 +906,13 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
 // and no change in same-box A/B, profiles/r02_ks_twpf_ab.txt)
 // (FHE_KS_PERSIST14=1: resident workgroups at N = 16384 as well -- no row-prefetch registers there, so nothing to
 // overlap: C3 relinearise 108.1-109.7 k against 111.0-111.3 k ops/s, profiles/r02_ks_persist_ab.txt)
-template <int LOGN, bool NARROW = false, int GM = KS_GMAX>
-__global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
+// TT (threads per workgroup, 0 = ks_threads_c(LOGN)): TT = N / 16 at N = 8192 is the two-workgroups-per-CU cut -- 512
+// threads x 16 coefficients, BOTH accumulator sets in registers (64 VGPRs, as at N = 16384), only the 68 KiB row tile
+// in LDS, so that a second workgroup is resident and runs its butterflies while this one sits in a barrier.
+constexpr int ks_threads_tt(int logn, int tt) { return tt ? tt : ks_threads_c(logn); }
+constexpr bool ks_acc1_in_lds_tt(int logn, int tt) { return tt == 0 && ks_acc1_in_lds_c(logn); }
+template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0>
+__global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), 4)
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
                     u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
                     u64 addend_poly_stride, const u64 *__restrict__ k0, const u64 *__restrict__ k0s,
@@ -915,7 +920,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
                     const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk, uint32_t digit_arg,
                     const u64 *__restrict__ xhat, u64 xhat_poly_stride, uint32_t total) {
     FHE_DYN_SMEM(u64, lds);
-    constexpr int T = ks_threads_c(LOGN);
+    constexpr int T = ks_threads_tt(LOGN, TT);
     constexpr int N = 1 << LOGN;
     constexpr int CH = tile_chunks_c(LOGN, T);
     constexpr int NE = CH > 0 ? 2 * CH : 1;  // coefficients owned by a thread
@@ -931,12 +936,12 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     // them; the host launches one workgroup per item except at N = 8192, where a workgroup owns its CU: there
     // gridDim.x is the number of CUs and, while an item's result is on its way out, the next item's first digit row
     // is already coming in -- neither that load nor a workgroup launch sits between two items).
-    u64x2 pre[ks_acc1_in_lds_c(LOGN) ? CH : 1];
+    u64x2 pre[ks_acc1_in_lds_tt(LOGN, TT) ? CH : 1];
     bool have_pre = false;   // (block-uniform) `pre` already holds this item's first digit row
 #if defined(FHE_HOST_EMULATION)
     constexpr bool ITEM_LOOP = true;    // (every size, so that the emulated suite walks the loop)
 #else
-    constexpr bool ITEM_LOOP = LOGN == 13 || (FHE_KS_PERSIST14 && LOGN == 14);
+    constexpr bool ITEM_LOOP = (LOGN == 13 && TT == 0) || (FHE_KS_PERSIST14 && LOGN == 14);
 #endif
     uint32_t item = blockIdx.x;
     if (item >= total) return;
@@ -949,7 +954,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     // N = 8192: 1024 threads cap a thread at 128 VGPRs, which 2 x 16 accumulators plus a radix-8
     // pass do not fit; the c1 accumulators live in LDS behind the row tile instead (each thread
     // only ever touches its own 16-byte chunks, so no extra barrier).
-    constexpr bool ACC1_LDS = ks_acc1_in_lds_c(LOGN);
+    constexpr bool ACC1_LDS = ks_acc1_in_lds_tt(LOGN, TT);
     u64 acc0[NE], acc1[ACC1_LDS ? 1 : NE];
     u64x2 *const acc1_lds = reinterpret_cast<u64x2 *>(lds + lds_words(N));
 #pragma unroll
@@ -1011,7 +1016,7 @@ __global__ void __launch_bounds__(ks_threads_c(LOGN), 4)
     auto digit_of = [&](uint32_t ii) -> uint32_t { return ii + ((own && ii >= j) ? 1u : 0u); };
     // The workgroup is alone on its CU (LDS), so nothing else hides the row load: digit i+1's
     // row is fetched into registers while digit i goes through its passes.
-    constexpr bool PREFETCH = ks_acc1_in_lds_c(LOGN);   // (needs the VGPRs the LDS accumulators free)
+    constexpr bool PREFETCH = ks_acc1_in_lds_tt(LOGN, TT);   // (needs the VGPRs the LDS accumulators free)
     // (Feeding the first pass from these registers instead of staging the lifted row in LDS was
     // measured: 2.5 % slower -- the extra register shuffling outweighs the saved barrier.)
     if constexpr (PREFETCH) {

@@ -449,6 +449,7 @@ def main():
         assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus)
         if ndev >= world:
             assert dist.get_backend() == "nccl", "one device per rank: the ranks must rendezvous over RCCL"
+    all_cpus = os.sched_getaffinity(0)
     pin = pin_to_gpu_numa_node(torch, dev)
 
     # ---- setup (untimed): parameters, device tables, synthetic key + inputs in HBM ----------
@@ -617,6 +618,7 @@ def main():
         result["per_rank"] = per_rank
 
     if world == 1 and not args.no_cpu:
+        os.sched_setaffinity(0, all_cpus)   # the CPU baseline gets every host core, not just the GPU's NUMA node
         cb, cm, (clhs, crhs, last, count, npairs) = cpu_baseline(n, MODULI_SIZES, t, SEED, args.cpu_seconds)
         result["cpu_baseline"] = cb
         result["speedup_vs_cpu_all_cores"] = round(value / cb["value"], 1)

@@ -12,69 +12,78 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("FHE_REFERENCE", "/root/reference")
 OUT = os.path.join(ROOT, "rust", "patches")
 
-# (patch name, file, [(anchor line (exact, stripped), "after" | "before", inserted text)])
+# (patch name, file, [(anchor line(s) (exact, stripped), "after" | "before", inserted text)])
+# A multi-line anchor matches consecutive lines; the text goes after / before its FIRST line.
 EDITS = [
+    # ------------------------------------------------------------------------------------------- fhe-math
     ("01-fhe-math-cargo", "crates/fhe-math/Cargo.toml", [
         ('tfhe-ntt = ["dep:tfhe-ntt"]', "after", 'hip = ["dep:fhe-math-hip"]  # MI355X engine (libfhe_hip.so) behind Poly / Scaler\n'),
         ("tfhe-ntt = { workspace = true, optional = true }", "after",
          'fhe-math-hip = { path = "../../rust/fhe-math-hip", optional = true }\n'),
     ]),
     ("02-ntt-operator-tables", "crates/fhe-math/src/ntt/native.rs", [
-        ("impl NttOperator {", "after", '''    /// The operator's tables, which the `hip` backend uploads as they are (`fhe_ctx_create`): psi stays the host's.
+        ("impl NttOperator {", "after", """    /// The operator's tables, which the `hip` backend uploads as they are (`fhe_ctx_create`): psi stays the host's.
     #[cfg(feature = "hip")]
     pub(crate) fn hip_tables(&self) -> (&[u64], &[u64], &[u64], &[u64], u64, u64) {
         (&self.omegas, &self.omegas_shoup, &self.zetas_inv, &self.zetas_inv_shoup, self.size_inv, self.size_inv_shoup)
     }
 
-'''),
+"""),
     ]),
     ("03-rq-context", "crates/fhe-math/src/rq/context.rs", [
-        ("pub(crate) next_context: Option<Arc<Context>>,", "after", '''    /// Device twin of this context (tables uploaded once; immutable, shared by every Poly over the context).
+        ("pub(crate) next_context: Option<Arc<Context>>,", "after", """    /// Device twin of this context, made on first use (tables uploaded once; immutable, shared by every Poly over
+    /// the context and by every clone made afterwards).  Takes no part in `PartialEq`.
     #[cfg(feature = "hip")]
-    pub(crate) hip: fhe_math_hip::Handle<fhe_math_hip::HipCtx>,
-'''),
-        ("Ok(Self {", "before", '''            #[cfg(feature = "hip")]
-            let hip = {
-                let cat = |f: fn(&NttOperator) -> &[u64]| ops.iter().flat_map(|o| f(o).iter().copied()).collect::<Vec<u64>>();
-                let (om, oms) = (cat(|o| o.hip_tables().0), cat(|o| o.hip_tables().1));
-                let (zi, zis) = (cat(|o| o.hip_tables().2), cat(|o| o.hip_tables().3));
-                let si = ops.iter().map(|o| o.hip_tables().4).collect::<Vec<u64>>();
-                let sis = ops.iter().map(|o| o.hip_tables().5).collect::<Vec<u64>>();
-                let tables = fhe_math_hip::NttTables {
-                    omegas: &om, omegas_shoup: &oms, zetas_inv: &zi, zetas_inv_shoup: &zis, size_inv: &si, size_inv_shoup: &sis,
-                };
-                // device 0; FHE_HIP_DEVICE selects another one (one process per GPU when a batch is sharded)
-                let dev = std::env::var("FHE_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-                fhe_math_hip::Handle::new(
-                    fhe_math_hip::HipCtx::new(dev, degree, moduli, Some(&tables)).map_err(crate::hip_error)?,
-                )
+    pub(crate) hip: fhe_math_hip::LazyHandle<fhe_math_hip::HipCtx>,
+"""),
+        ("impl Context {", "after", """    /// The device twin (`fhe_ctx_create` with the tables this context's `NttOperator`s already hold, so psi -- and
+    /// with it every Ntt-form value -- is the host's).  Each level of a chain has its own twin; equal tables make
+    /// them interchangeable on the device side (the engine compares table fingerprints, not pointers).
+    #[cfg(feature = "hip")]
+    pub fn hip_handle(&self) -> Result<&Arc<fhe_math_hip::HipCtx>> {
+        self.hip.get_or_try_init(|| {
+            let cat = |f: fn(&NttOperator) -> &[u64]| self.ops.iter().flat_map(|o| f(o).iter().copied()).collect::<Vec<u64>>();
+            let (om, oms) = (cat(|o| o.hip_tables().0), cat(|o| o.hip_tables().1));
+            let (zi, zis) = (cat(|o| o.hip_tables().2), cat(|o| o.hip_tables().3));
+            let si = self.ops.iter().map(|o| o.hip_tables().4).collect::<Vec<u64>>();
+            let sis = self.ops.iter().map(|o| o.hip_tables().5).collect::<Vec<u64>>();
+            let tables = fhe_math_hip::NttTables {
+                omegas: &om, omegas_shoup: &oms, zetas_inv: &zi, zetas_inv_shoup: &zis, size_inv: &si, size_inv_shoup: &sis,
             };
-'''),
-        ("next_context,", "after", '''                #[cfg(feature = "hip")]
-                hip,
-'''),
+            fhe_math_hip::HipCtx::new(fhe_math_hip::default_device(), self.degree, &self.moduli, Some(&tables))
+                .map_err(crate::hip_error)
+        })
+    }
+
+"""),
+        ("next_context,", "after", """                #[cfg(feature = "hip")]
+                hip: Default::default(),
+"""),
     ]),
     ("04-rq-poly", "crates/fhe-math/src/rq/mod.rs", [
-        ("fn ntt_forward(&mut self) {", "after", '''        #[cfg(feature = "hip")]
-        if let Some(h) = self.ctx.hip.get() {
+        ("fn ntt_forward(&mut self) {", "after", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
             // [L][N] standard layout: exactly the buffer the C ABI takes
+            let h = self.ctx.hip_handle().expect("fhe_hip: device context");
             h.ntt_forward(self.coefficients.as_slice_mut().unwrap()).expect("fhe_hip: ntt_forward");
             return;
         }
-'''),
-        ("fn ntt_backward(&mut self) {", "after", '''        #[cfg(feature = "hip")]
-        if let Some(h) = self.ctx.hip.get() {
+"""),
+        ("fn ntt_backward(&mut self) {", "after", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
+            let h = self.ctx.hip_handle().expect("fhe_hip: device context");
             h.ntt_backward(self.coefficients.as_slice_mut().unwrap()).expect("fhe_hip: ntt_backward");
             return;
         }
-'''),
+"""),
     ]),
     ("05-rq-ops", "crates/fhe-math/src/rq/ops.rs", [
-        ("impl AddAssign<&Poly<PowerBasis>> for Poly<PowerBasis> {", "before", '''/// `hip` backend of the element-wise assignments below: one call on the `[L][N]` buffers, values identical.
+        ("impl AddAssign<&Poly<PowerBasis>> for Poly<PowerBasis> {", "before", """/// `hip` backend of the element-wise assignments below: one call on the `[L][N]` buffers, values identical.
 #[cfg(feature = "hip")]
 macro_rules! hip_elementwise {
     ($self:ident, $p:ident, $method:ident) => {
-        if let Some(h) = $self.ctx.hip.get() {
+        if fhe_math_hip::enabled() {
+            let h = $self.ctx.hip_handle().expect("fhe_hip: device context");
             h.$method($self.coefficients.as_slice_mut().unwrap(), $p.coefficients.as_slice().unwrap())
                 .expect(concat!("fhe_hip: ", stringify!($method)));
             return;
@@ -82,27 +91,45 @@ macro_rules! hip_elementwise {
     };
 }
 
-'''),
-        ("self.allow_variable_time_computations &= p.allow_variable_time_computations;", "after", '''        #[cfg(feature = "hip")]
+"""),
+        # (the first AddAssign, Poly<PowerBasis>; the macro serves the other element-wise assignments the same way)
+        ('debug_assert_eq!(self.ctx, p.ctx, "Incompatible contexts");\n\n        self.allow_variable_time_computations &= p.allow_variable_time_computations;\n        if self.allow_variable_time_computations {\n            izip!(\n                self.coefficients.outer_iter_mut(),\n                p.coefficients.outer_iter(),\n                self.ctx.q.iter()\n            )\n            .for_each(|(mut v1, v2, qi)| unsafe {\n                qi.add_vec_vt(v1.as_slice_mut().unwrap(), v2.as_slice().unwrap())', "after_third", """        #[cfg(feature = "hip")]
         hip_elementwise!(self, p, add_assign);
-'''),
+"""),
     ]),
     ("06-rq-scaler", "crates/fhe-math/src/rq/scaler.rs", [
-        ("scaler: RnsScaler,", "after", '''    /// Device twin (constants of `scaler` uploaded once).
+        ("scaler: RnsScaler,", "after", """    /// Device twin (constants of `scaler` uploaded on first use).
     #[cfg(feature = "hip")]
-    hip: fhe_math_hip::Handle<fhe_math_hip::HipScaler>,
-'''),
-        ("let mut new_coefficients = Array2::<u64>::zeros((self.to.q.len(), self.to.degree));", "after", '''
+    hip: fhe_math_hip::LazyHandle<fhe_math_hip::HipScaler>,
+"""),
+        ("impl Scaler {", "after", """    /// The device twin (`fhe_scaler_create_from_constants` with every field `RnsScaler::new` computed: nothing is
+    /// re-derived on the device side, so the rounding constants are the host's bit for bit).
+    #[cfg(feature = "hip")]
+    pub fn hip_handle(&self) -> Result<&Arc<fhe_math_hip::HipScaler>> {
+        self.hip.get_or_try_init(|| {
+            let (from, to) = (self.from.hip_handle()?, self.to.hip_handle()?);
+            let k = self.scaler.hip_constants();
+            fhe_math_hip::HipScaler::from_constants(from, to, self.number_common_moduli, k.is_one, &k.view())
+                .map_err(crate::hip_error)
+        })
+    }
+
+"""),
+        ("number_common_moduli,\n            scaler,", "after_second", """            #[cfg(feature = "hip")]
+            hip: Default::default(),
+"""),
+        ("let mut new_coefficients = Array2::<u64>::zeros((self.to.q.len(), self.to.degree));", "after", """
             #[cfg(feature = "hip")]
-            if let Some(h) = self.hip.get() {
+            if fhe_math_hip::enabled() {
                 // copy of the common rows, inverse NTT, per-column RnsScaler::scale and the forward NTT of the
                 // new rows: one device call (fhe_poly_scale), same canonical residues
-                h.scale(
-                    p.coefficients.as_slice().unwrap(),
-                    new_coefficients.as_slice_mut().unwrap(),
-                    R::REPRESENTATION != Representation::PowerBasis,
-                )
-                .map_err(crate::hip_error)?;
+                self.hip_handle()?
+                    .scale(
+                        p.coefficients.as_slice().unwrap(),
+                        new_coefficients.as_slice_mut().unwrap(),
+                        R::REPRESENTATION != Representation::PowerBasis,
+                    )
+                    .map_err(crate::hip_error)?;
                 return Ok(Poly {
                     ctx: self.to.clone(),
                     allow_variable_time_computations: p.allow_variable_time_computations,
@@ -112,10 +139,10 @@ macro_rules! hip_elementwise {
                     _repr: PhantomData,
                 });
             }
-'''),
+"""),
     ]),
     ("10-fhe-math-errors", "crates/fhe-math/src/lib.rs", [
-        ("pub use errors::{Error, PolynomialSerializationError, Result};", "after", '''
+        ("pub use errors::{Error, PolynomialSerializationError, Result};", "after", """
 /// `fhe_status` of the `hip` backend -> the `Error` variant the native path returns in the same situation
 /// (table in include/fhe_hip.h); HIP runtime failures and argument errors have no native counterpart and panic,
 /// as the reference does on programming errors.
@@ -130,49 +157,253 @@ pub(crate) fn hip_error(e: fhe_math_hip::HipError) -> Error {
         _ => panic!("{e}"),
     }
 }
-'''),
+"""),
     ]),
-    ("07-bfv-multiplicator", "crates/fhe/src/bfv/ops/mul.rs", [
-        ("level: usize,\n}", "before_last_line", '''    /// Device twin: extenders, down scaler, relinearisation key (`fhe_mul_create`).
+    ("11-rns-scaler-constants", "crates/fhe-math/src/rns/scaler.rs", [
+        ("impl RnsScaler {", "after", """    /// Every constant `new` computed, flattened the way `fhe_scaler_create_from_constants` takes them
+    /// (`omega*` row-major `[to][from]`, signs as bytes).
     #[cfg(feature = "hip")]
-    hip: fhe_math_hip::Handle<fhe_math_hip::HipMul>,
-'''),
-        ("// Extend", "before", '''        #[cfg(feature = "hip")]
-        if let Some(h) = self.hip.get() {
-            // extend, tensor, scale, relinearise (and switch down) of one ciphertext pair on the device; the batched
-            // form (`multiply_batch`) amortises the PCIe copies and is what the throughput numbers use
-            let flat = |ct: &Ciphertext| ct.iter().flat_map(|p| p.coefficients().iter().copied().collect::<Vec<u64>>()).collect::<Vec<u64>>();
-            let (parts, rows) = h.out_shape().map_err(crate::hip_error)?;
-            let mut out = vec![0u64; parts * rows * self.par.degree()];
-            h.multiply(&flat(lhs), &flat(rhs), &mut out, 1).map_err(crate::hip_error)?;
-            return Ciphertext::from_ntt_coefficients(&self.par, &out, parts, self.level + usize::from(self.mod_switch));
+    pub(crate) fn hip_constants(&self) -> fhe_math_hip::RnsScalerConstantsBuf {
+        fhe_math_hip::RnsScalerConstantsBuf {
+            is_one: self.scaling_factor.is_one,
+            gamma: self.gamma.to_vec(),
+            gamma_shoup: self.gamma_shoup.to_vec(),
+            omega: self.omega.iter().flat_map(|row| row.iter().copied()).collect(),
+            omega_shoup: self.omega_shoup.iter().flat_map(|row| row.iter().copied()).collect(),
+            theta_gamma_lo: self.theta_gamma_lo,
+            theta_gamma_hi: self.theta_gamma_hi,
+            theta_gamma_sign: self.theta_gamma_sign,
+            theta_omega_lo: self.theta_omega_lo.to_vec(),
+            theta_omega_hi: self.theta_omega_hi.to_vec(),
+            theta_omega_sign: self.theta_omega_sign.iter().map(|&s| s as u8).collect(),
+            theta_garner_lo: self.theta_garner_lo.to_vec(),
+            theta_garner_hi: self.theta_garner_hi.to_vec(),
+            theta_garner_shift: self.theta_garner_shift,
         }
+    }
 
-'''),
+"""),
     ]),
-    ("08-bfv-key-switch", "crates/fhe/src/bfv/keys/key_switching_key.rs", [
-        ("let mut c0 = Poly::<Ntt>::zero(&self.ctx_ksk);", "before", '''        #[cfg(feature = "hip")]
-        if let Some(h) = self.hip.get() {
-            // lazy lift + NTT per (digit, key modulus) + Shoup MAC, fused on the device (fhe_key_switch)
-            let n = self.ctx_ksk.moduli().len() * self.par.degree();
-            let (mut o0, mut o1) = (vec![0u64; n], vec![0u64; n]);
-            h.key_switch(p.coefficients().as_slice().unwrap(), &mut o0, &mut o1, 1).map_err(crate::hip_error)?;
-            return Ok((Poly::<Ntt>::from_canonical_ntt(&self.ctx_ksk, o0)?, Poly::<Ntt>::from_canonical_ntt(&self.ctx_ksk, o1)?));
+    # ------------------------------------------------------------------------------------------------ fhe
+    ("12-fhe-cargo", "crates/fhe/Cargo.toml", [
+        ('tfhe-ntt = ["fhe-math/tfhe-ntt"]', "after",
+         'hip = ["dep:fhe-math-hip", "fhe-math/hip"]  # MI355X engine behind Multiplicator / KeySwitchingKey / Ciphertext\n'),
+        ('fhe-util = { version = "=0.1.1", path = "../fhe-util" }', "after",
+         'fhe-math-hip = { path = "../../rust/fhe-math-hip", optional = true }\n'),
+    ]),
+    ("13-fhe-errors", "crates/fhe/src/lib.rs", [
+        ("pub mod proto;", "after", """
+/// `fhe_status` of the `hip` backend -> the `Error` this crate's native path returns in the same situation
+/// (table in include/fhe_hip.h).  HIP runtime failures and argument errors have no native counterpart and panic, as
+/// the reference does on programming errors.
+#[cfg(feature = "hip")]
+pub(crate) fn hip_error(e: fhe_math_hip::HipError) -> Error {
+    use fhe_math_hip::status as st;
+    match e.status {
+        st::CONTEXT_MISMATCH => fhe_math::Error::PolynomialContextMismatch.into(),
+        st::NO_MORE_CONTEXT => fhe_math::Error::NoMoreContext.into(),
+        st::CONTEXT_NOT_REACHABLE => fhe_math::Error::ContextNotReachable.into(),
+        st::PARAMETER_MISMATCH => Error::ParameterMismatch {
+            left: ParameterSource::Ciphertext,
+            right: ParameterSource::Parameters,
+        },
+        st::MUL_POLY_COUNT => CiphertextError::MultiplicationPolynomialCount { left: 0, right: 0, expected: 2 }.into(),
+        _ => panic!("{e}"),
+    }
+}
+"""),
+    ]),
+    ("09-bfv-ciphertext", "crates/fhe/src/bfv/ciphertext.rs", [
+        ("/// Truncate the underlying vector of polynomials.", "before", """    /// The polynomials' coefficients, concatenated `[parts][L][N]`: the layout every ciphertext entry point of
+    /// the `hip` backend takes (a batch is the concatenation of these).
+    #[cfg(feature = "hip")]
+    pub(crate) fn to_flat_coefficients(&self) -> Vec<u64> {
+        self.c.iter().flat_map(|p| p.coefficients().iter().copied().collect::<Vec<u64>>()).collect()
+    }
+
+    /// Rebuilds a ciphertext at `level` from `parts` Ntt-form polynomials laid out `[parts][L][N]` (what the
+    /// `hip` backend returns; canonical residues, so `TryConvertFrom<Vec<u64>>` takes them verbatim).
+    #[cfg(feature = "hip")]
+    pub(crate) fn from_ntt_coefficients(par: &Arc<BfvParameters>, flat: &[u64], parts: usize, level: usize) -> Result<Self> {
+        use fhe_math::rq::traits::TryConvertFrom as PolyTryConvertFrom;
+        let ctx = par.context_at_level(level)?;
+        let per = ctx.moduli().len() * par.degree();
+        if parts < 2 || flat.len() != parts * per {
+            return Err(crate::CiphertextError::TooFewPolynomials { actual: flat.len() / per.max(1), minimum: 2 }.into());
         }
-'''),
-    ]),
-    ("09-bfv-ciphertext-switch-down", "crates/fhe/src/bfv/ciphertext.rs", [
-        ("self.seed = None;\n        for ci in self.c.iter_mut() {", "before_hip_switch_down", '''        #[cfg(feature = "hip")]
-        if let Some(h) = self.c[0].ctx().hip_handle() {
-            // all parts at once: inverse NTT, divide-and-round by the last modulus, forward NTT (fhe_bfv_switch_down)
-            let flat = self.c.iter().flat_map(|p| p.coefficients().iter().copied().collect::<Vec<u64>>()).collect::<Vec<u64>>();
+        let c = flat
+            .chunks_exact(per)
+            .map(|chunk| Poly::<Ntt>::try_convert_from(chunk.to_vec(), ctx, false).map_err(Error::MathError))
+            .collect::<Result<Vec<Poly<Ntt>>>>()?;
+        Ok(Self { par: par.clone(), seed: None, c, level })
+    }
+
+    /// Uploads a batch of ciphertexts (same level, same number of parts) once; the result stays on the GPU across
+    /// `Multiplicator::multiply_dev`, `RelinearizationKey` / rotation calls on `DeviceCiphertexts`, and comes back
+    /// through [`Ciphertext::from_device`].
+    #[cfg(feature = "hip")]
+    pub fn to_device(cts: &[Ciphertext], stream: &fhe_math_hip::Stream) -> Result<fhe_math_hip::DeviceCiphertexts> {
+        let first = cts.first().ok_or(crate::CiphertextError::TooFewPolynomials { actual: 0, minimum: 2 })?;
+        if cts.iter().any(|c| c.level != first.level || c.c.len() != first.c.len() || !Arc::ptr_eq(&c.par, &first.par)) {
+            return Err(Error::ParameterMismatch { left: crate::ParameterSource::Ciphertext, right: crate::ParameterSource::Ciphertext });
+        }
+        let ctx = first.par.context_at_level(first.level)?;
+        let flat = cts.iter().flat_map(|c| c.to_flat_coefficients()).collect::<Vec<u64>>();
+        fhe_math_hip::DeviceCiphertexts::upload(fhe_math_hip::default_device(), &flat, first.c.len(), ctx.moduli().len(),
+            first.par.degree(), first.level, stream)
+            .map_err(crate::hip_error)
+    }
+
+    /// Downloads a device-resident batch (waits for `stream`) into ciphertexts over `par`.
+    #[cfg(feature = "hip")]
+    pub fn from_device(par: &Arc<BfvParameters>, d: &fhe_math_hip::DeviceCiphertexts, stream: &fhe_math_hip::Stream) -> Result<Vec<Ciphertext>> {
+        let flat = d.download(stream).map_err(crate::hip_error)?;
+        flat.chunks_exact(d.words_per_ct()).map(|one| Self::from_ntt_coefficients(par, one, d.parts, d.level)).collect()
+    }
+
+"""),
+        ("self.seed = None;\n        for ci in self.c.iter_mut() {", "after", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
+            // all parts at once: inverse NTT, divide-and-round by the last modulus, forward NTT (fhe_bfv_switch_to_level)
+            let h = self.c[0].ctx().hip_handle()?;
             let rows = self.c[0].ctx().moduli().len() - 1;
             let mut out = vec![0u64; self.c.len() * rows * self.par.degree()];
-            h.ciphertext_switch_down(self.c.len(), &flat, &mut out).map_err(crate::hip_error)?;
+            h.ciphertext_switch_down(self.c.len(), &self.to_flat_coefficients(), &mut out).map_err(crate::hip_error)?;
             *self = Ciphertext::from_ntt_coefficients(&self.par, &out, self.c.len(), self.level + 1)?;
             return Ok(());
         }
-'''),
+"""),
+    ]),
+    ("08-bfv-key-switch", "crates/fhe/src/bfv/keys/key_switching_key.rs", [
+        ("pub(crate) log_base: usize,", "after", """
+    /// Device twin: the key polynomials uploaded on first use (`fhe_ksk_create`).
+    #[cfg(feature = "hip")]
+    pub(crate) hip: fhe_math_hip::LazyHandle<fhe_math_hip::HipKsk>,
+"""),
+        ("impl KeySwitchingKey {", "after", """    /// The device twin of this key: `c0`, `c1` as `[digits][Lk][N]` (their Shoup twins are recomputed by the engine
+    /// as floor(c * 2^64 / q), the definition `Poly::<NttShoup>` uses, zq/mod.rs:195-199).
+    #[cfg(feature = "hip")]
+    pub fn hip_handle(&self) -> Result<&Arc<fhe_math_hip::HipKsk>> {
+        self.hip.get_or_try_init(|| {
+            let flat = |ps: &[Poly<NttShoup>]| ps.iter().flat_map(|p| p.coefficients().iter().copied().collect::<Vec<u64>>()).collect::<Vec<u64>>();
+            let (ct, ksk) = (self.ctx_ciphertext.hip_handle()?, self.ctx_ksk.hip_handle()?);
+            fhe_math_hip::HipKsk::new(ct, ksk, self.c0.len(), &flat(&self.c0), None, &flat(&self.c1), None, self.log_base)
+                .map_err(crate::hip_error)
+        })
+    }
+
+"""),
+        ("log_base,\n            })", "after", """                #[cfg(feature = "hip")]
+                hip: Default::default(),
+"""),
+        ("log_base: 0,", "after", """                #[cfg(feature = "hip")]
+                hip: Default::default(),
+"""),
+        ("log_base: value.log_base as usize,", "after", """            #[cfg(feature = "hip")]
+            hip: Default::default(),
+"""),
+        ("let mut c0 = Poly::<Ntt>::zero(&self.ctx_ksk);\n        let mut c1 = Poly::<Ntt>::zero(&self.ctx_ksk);\n        self.configure_accumulators(p, &mut c0, &mut c1);\n        let p_coefficients = p.coefficients();", "before", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
+            // lazy lift + NTT per (digit, key modulus) + Shoup MAC, fused on the device (fhe_key_switch)
+            let n = self.ctx_ksk.moduli().len() * self.par.degree();
+            let (mut o0, mut o1) = (vec![0u64; n], vec![0u64; n]);
+            self.hip_handle()?
+                .key_switch(p.coefficients().as_slice().unwrap(), &mut o0, &mut o1)
+                .map_err(crate::hip_error)?;
+            let vt = self.permits_variable_time_with(p);
+            return Ok((
+                Poly::<Ntt>::try_convert_from(o0, &self.ctx_ksk, vt)?,
+                Poly::<Ntt>::try_convert_from(o1, &self.ctx_ksk, vt)?,
+            ));
+        }
+"""),
+    ]),
+    ("07-bfv-multiplicator", "crates/fhe/src/bfv/ops/mul.rs", [
+        ("level: usize,\n}", "after", """    /// Device twin: extenders, down scaler, relinearisation key and the mod-switch flag (`fhe_mul_create`), built on
+    /// first use and rebuilt after `enable_relinearization` / `enable_mod_switching`.
+    #[cfg(feature = "hip")]
+    hip: fhe_math_hip::LazyHandle<fhe_math_hip::HipMul>,
+"""),
+        ("impl Multiplicator {", "after", """    #[cfg(feature = "hip")]
+    fn hip_handle(&self) -> Result<&Arc<fhe_math_hip::HipMul>> {
+        self.hip.get_or_try_init(|| {
+            let rk = match self.rk.as_ref() {
+                Some(rk) => Some(rk.ksk.hip_handle()?),
+                None => None,
+            };
+            fhe_math_hip::HipMul::new(self.extender_lhs.hip_handle()?, self.extender_rhs.hip_handle()?,
+                self.down_scaler.hip_handle()?, rk, self.mod_switch)
+                .map_err(crate::hip_error)
+        })
+    }
+
+    #[cfg(feature = "hip")]
+    fn check_operands(&self, lhs: &Ciphertext, rhs: &Ciphertext) -> Result<()> {
+        lhs.validate_for(&self.par)?;
+        rhs.validate_for(&self.par)?;
+        if lhs.level != self.level || rhs.level != self.level {
+            let level = if lhs.level != self.level { lhs.level } else { rhs.level };
+            return Err(Error::InvalidLevel { level, min_level: self.level, max_level: self.level });
+        }
+        if lhs.len() != 2 || rhs.len() != 2 {
+            return Err(crate::CiphertextError::MultiplicationPolynomialCount { left: lhs.len(), right: rhs.len(), expected: 2 }.into());
+        }
+        Ok(())
+    }
+
+    /// `multiply` on many independent pairs in ONE device call (the PCIe copies and the launch chain are paid once
+    /// per batch, not once per pair): what a throughput-bound host uses.  Same values as `multiply` pair by pair.
+    #[cfg(feature = "hip")]
+    pub fn multiply_batch(&self, lhs: &[Ciphertext], rhs: &[Ciphertext]) -> Result<Vec<Ciphertext>> {
+        if lhs.len() != rhs.len() {
+            return Err(crate::CiphertextError::MultiplicationPolynomialCount { left: lhs.len(), right: rhs.len(), expected: 2 }.into());
+        }
+        for (l, r) in lhs.iter().zip(rhs.iter()) {
+            self.check_operands(l, r)?;
+        }
+        let h = self.hip_handle()?;
+        let (parts, rows) = h.out_shape();
+        let flat = |cts: &[Ciphertext]| cts.iter().flat_map(|c| c.to_flat_coefficients()).collect::<Vec<u64>>();
+        let per = parts * rows * self.par.degree();
+        let mut out = vec![0u64; lhs.len() * per];
+        h.multiply(&flat(lhs), &flat(rhs), &mut out).map_err(crate::hip_error)?;
+        let level = self.level + usize::from(self.mod_switch);
+        out.chunks_exact(per).map(|one| Ciphertext::from_ntt_coefficients(&self.par, one, parts, level)).collect()
+    }
+
+    /// `multiply` on device-resident batches (`Ciphertext::to_device`): stream-ordered, nothing crosses PCIe.
+    #[cfg(feature = "hip")]
+    pub fn multiply_dev(&self, lhs: &fhe_math_hip::DeviceCiphertexts, rhs: &fhe_math_hip::DeviceCiphertexts,
+                        stream: &fhe_math_hip::Stream) -> Result<fhe_math_hip::DeviceCiphertexts> {
+        if lhs.level != self.level || rhs.level != self.level {
+            let level = if lhs.level != self.level { lhs.level } else { rhs.level };
+            return Err(Error::InvalidLevel { level, min_level: self.level, max_level: self.level });
+        }
+        self.hip_handle()?.multiply_dev(lhs, rhs, stream).map_err(crate::hip_error)
+    }
+
+"""),
+        ("mod_switch: false,\n            level,", "after_second", """            #[cfg(feature = "hip")]
+            hip: Default::default(),
+"""),
+        ("self.rk = Some(rk.clone());", "after", """        #[cfg(feature = "hip")]
+        self.hip.reset();
+"""),
+        ("self.mod_switch = true;", "after", """            #[cfg(feature = "hip")]
+            self.hip.reset();
+"""),
+        ("// Extend", "before", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
+            // extend, tensor, scale, relinearise (and switch down) of one ciphertext pair on the device; the batched
+            // form (`multiply_batch`) amortises the PCIe copies and `multiply_dev` removes them
+            let h = self.hip_handle()?;
+            let (parts, rows) = h.out_shape();
+            let mut out = vec![0u64; parts * rows * self.par.degree()];
+            h.multiply(&lhs.to_flat_coefficients(), &rhs.to_flat_coefficients(), &mut out).map_err(crate::hip_error)?;
+            return Ciphertext::from_ntt_coefficients(&self.par, &out, parts, self.level + usize::from(self.mod_switch));
+        }
+
+"""),
     ]),
 ]
 
@@ -187,13 +418,18 @@ def apply(text, edits, path):
             idx = [i for i in idx if [l.strip() for l in lines[i + 1:i + 1 + len(rest)]] == rest]
         if not idx:
             raise SystemExit(f"{path}: anchor not found: {first!r}")
+        if len(idx) > 1 and "\n" not in anchor:
+            raise SystemExit(f"{path}: anchor is ambiguous ({len(idx)} matches): {first!r}")
         i = idx[0]
         new = ins.rstrip("\n").split("\n")
         if where == "after":
             lines[i + 1:i + 1] = new
-        elif where in ("before", "before_last_line", "before_hip_switch_down"):
-            at = i + 1 if where == "before_hip_switch_down" else i
-            lines[at:at] = new
+        elif where == "after_second":   # after the second line of a multi-line anchor
+            lines[i + 2:i + 2] = new
+        elif where == "after_third":
+            lines[i + 3:i + 3] = new
+        elif where == "before":
+            lines[i:i] = new
         else:
             raise SystemExit(where)
     return "\n".join(lines)

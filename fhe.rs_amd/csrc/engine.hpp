@@ -1501,15 +1501,30 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
             if (join) AuxStreams::get().give_event(join);
         }
     } join;
-    if (dual) {
+    // A batch that is ONE chunk has nothing to alternate: there the two operand extensions (independent chains of
+    // five launches each: inverse NTT, scaler, forward NTT of the new rows) run side by side, lhs on the caller's
+    // stream and rhs on the internal one, and meet again in front of the tensor kernel -- the tail of one chain's
+    // launch is filled by the other's (C5 at batch 16: launches of 4.25 waves; profiles/r03_split_ext_ab.txt).
+    const bool split_ext = !dual && m.streams.load(std::memory_order_relaxed) >= 2 && batch <= chunk &&
+                           FHE_LAB_INT("MUL_SPLIT_EXT", 1) != 0;
+    hipEvent_t ext_done = nullptr;
+    struct EventBack {
+        hipEvent_t &e;
+        ~EventBack() {
+            if (e) AuxStreams::get().give_event(e);
+        }
+    } ext_done_back{ext_done};
+    if (dual || split_ext) {
         AuxStreams &ax = AuxStreams::get();
         join.to = s0;
         join.fork = ax.take_event();
         join.join = ax.take_event();
-        lanes[1] = ax.stream_for(b.device, s0);
+        hipStream_t aux = ax.stream_for(b.device, s0);
+        if (dual) lanes[1] = aux;
+        if (split_ext) ext_done = ax.take_event();
         FHE_HIP_CHECK(hipEventRecord(join.fork, s0));
-        FHE_HIP_CHECK(hipStreamWaitEvent(lanes[1], join.fork, 0));
-        join.aux = lanes[1];
+        FHE_HIP_CHECK(hipStreamWaitEvent(aux, join.fork, 0));
+        join.aux = aux;
     }
     ChunkWs ws0(chunk, PK, PL, pre_bytes, lanes[0]);
     std::unique_ptr<ChunkWs> ws1;
@@ -1523,7 +1538,13 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         const u64 *l = lhs + b0 * 2 * PL, *r = rhs + b0 * 2 * PL;
         // EXTEND (mul.rs:192-195): both parts of every lhs (rhs) ciphertext in one go
         scale_polys(*m.ext_lhs, l, extL.u(), nb * 2, true, s, !skip_copy);
-        scale_polys(*m.ext_rhs, r, extR.u(), nb * 2, true, s, !skip_copy);
+        if (split_ext) {   // (one chunk: the fork above put the internal stream behind the caller's earlier work)
+            scale_polys(*m.ext_rhs, r, extR.u(), nb * 2, true, join.aux, !skip_copy);
+            FHE_HIP_CHECK(hipEventRecord(ext_done, join.aux));
+            FHE_HIP_CHECK(hipStreamWaitEvent(s, ext_done, 0));
+        } else {
+            scale_polys(*m.ext_rhs, r, extR.u(), nb * 2, true, s, !skip_copy);
+        }
         // TENSOR (mul.rs:198-201) + the inverse NTT of the down-scaler (M/rq/scaler.rs:69-79):
         // ten [3][nb][K][N] ends up in PowerBasis.  Rows that fit LDS: one fused kernel;
         // larger rows: element-wise tensor kernel, then the two-kernel inverse NTT.

@@ -265,6 +265,17 @@ def test_config_c5_chain_n32768(fhe):
     fhe.workspace_trim()
 
 
+@pytest.mark.parametrize("batch", [16, 64])
+def test_config_c5_bench_batches_n32768(fhe, batch):
+    """C5 at the batches bench.py times (16: one chunk; 64: the two-stream cut of plan_chunks, 8 chunks of 8):
+    level-0 multiply + relinearise + modulus switch, sampled ciphertexts (first, last, both sides of chunk
+    boundaries) against the C oracle."""
+    import full_size
+    sample = sorted({0, 1, 7, 8, batch // 2 - 1, batch // 2, batch - 2, batch - 1})
+    full_size.check_mul(fhe, n=32768, sizes=[60] * 16, batch=batch, relin=True, cfg=5, sample=sample, mod_switch=True)
+    fhe.workspace_trim()
+
+
 def test_bench_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` starts its own two ranks; on a one-GPU box they share the device and
     rendezvous over gloo (RCCL needs one device per rank).  The line must say n_gpus = 2."""

@@ -156,7 +156,27 @@ def read_sclk_mhz():
     return best
 
 
-def int_issue_roofline(fhe, dev, prof, n, L, K, batch, steps):
+def sclk_under_load(work, max_seconds=6.0):
+    """Engine clock while `work()` keeps the GPU busy: `rocm-smi --showclocks` (which reads the SMU's current gfxclk,
+    not the DPM level table) runs once as a subprocess while `work` is called in a loop.  None if rocm-smi is missing."""
+    import re
+    import shutil
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        p = subprocess.Popen([exe, "--showclocks"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        t0 = time.perf_counter()
+        while p.poll() is None and time.perf_counter() - t0 < max_seconds:
+            work()
+        out = p.communicate(timeout=10)[0]
+        vals = [int(v) for v in re.findall(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", out)]
+        return max(vals) if vals else None
+    except Exception:
+        return None
+
+
+def int_issue_roofline(fhe, dev, prof, n, L, K, batch, steps, pipeline_step=None, sync=None):
     """"measure it (microbench v_mad_u64_u32 throughput) and report both ceilings".  Runs the library's
     register-resident loops (the butterflies the kernels are made of, no memory traffic) for ~0.2 s in this process,
     samples the engine clock while they run, and prices every NTT-type kernel of the timed region against them:
@@ -177,6 +197,15 @@ def int_issue_roofline(fhe, dev, prof, n, L, K, batch, steps):
                                                         "fwd_butterfly", "fwd_butterfly_narrow", "inv_butterfly")}
     stop.set()
     th.join()
+    # the clock the SMU reports while the integer pipe is saturated, and while the real pipeline runs
+    sclk_ubench = sclk_under_load(lambda: fhe.ubench_int("fwd_butterfly_narrow", 0.05, dev))
+    sclk_pipeline = None
+    if pipeline_step is not None:
+        def work():
+            for _ in range(4):
+                pipeline_step()
+            sync()
+        sclk_pipeline = sclk_under_load(work)
     bf_row = (n // 2) * (n.bit_length() - 1)                     # butterflies of one row transform
     fw, fn_, iv = rates["fwd_butterfly"], rates["fwd_butterfly_narrow"], rates["inv_butterfly"]
     # rows per ct x ct + relin by kernel and butterfly kind (C2: the L ciphertext primes are 60-bit -> narrow passes,
@@ -200,8 +229,11 @@ def int_issue_roofline(fhe, dev, prof, n, L, K, batch, steps):
                                            inverse=round(iv / bf_row, 0)),
                 mad_u64_u32_per_s=round(rates["mad_u64_u32"], 0), mul_lo_u32_per_s=round(rates["mul_lo_u32"], 0),
                 mul_hi_u32_per_s=round(rates["mul_hi_u32"], 0), shoup_lazy_per_s=round(rates["shoup_lazy"], 0),
-                sclk_mhz_observed=(round(sum(clocks) / len(clocks)) if clocks else None),
-                sclk_samples=len(clocks), per_kernel=per_kernel,
+                sclk_mhz_observed=sclk_ubench or (round(sum(clocks) / len(clocks)) if clocks else None),
+                sclk_mhz_during_pipeline=sclk_pipeline,
+                sclk_source=("rocm-smi --showclocks (SMU current gfxclk) sampled once under each load" if sclk_ubench
+                             else "sysfs pp_dpm_sclk level table (the active LEVEL, not the instantaneous clock)"),
+                sclk_dpm_level_mhz=(round(sum(clocks) / len(clocks)) if clocks else None), per_kernel=per_kernel,
                 note="fhe_ubench_int, this process, this box; numerators count transform butterflies only")
 
 
@@ -296,7 +328,10 @@ def reference_bench_ids(fhe, torch, par, rk, batch, timeit):
             d.update(stage_model_bytes_per_op=rows * R, stage_model_GBps=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
         return d
     out["bfv/mul"] = entry(timeit(lambda: plain.multiply(a, b)), 22 * K + 9 * L)          # SURVEY 8(d) "&ct*&ct no relin"
-    out["bfv/square"] = entry(timeit(lambda: plain.tensor(a, a)), 22 * K + 9 * L)
+    # &c1 * &c1: the same buffer as both operands -> the operand is extended once (engine's squaring shortcut);
+    # stage model: extension of 2 polynomials instead of 4
+    out["bfv/square"] = entry(timeit(lambda: plain.multiply(a, a)), 22 * K + 9 * L - (4 * L + 2 * K + 4 * (K - L)))
+    out["bfv/square_general_tensor"] = entry(timeit(lambda: plain.tensor(a, a)), 22 * K + 9 * L)
     c3 = plain.multiply(a, b)
     out["bfv/relinearize"] = entry(timeit(lambda: rk.relinearizes(c3)), 2 * L + L * L + 4 * L)
     out["bfv/mul_then_relinearize"] = entry(timeit(lambda: rk.relinearizes(plain.multiply(a, b))),
@@ -600,7 +635,8 @@ def main():
                                   frac=round(stage_model_rows(L, K, L) * R * value / world / 1e9 / HBM_PEAK_GBS, 4)),
                     kernels=per_kernel)
     if not args.no_extras:
-        roofline["int_issue"] = int_issue_roofline(fhe, dev, prof, n, L, K, batch, args.steps)
+        roofline["int_issue"] = int_issue_roofline(fhe, dev, prof, n, L, K, batch, args.steps, pipeline_step=step,
+                                                   sync=torch.cuda.synchronize)
 
     result = {
         "metric": "BFV ct x ct + relinearize ops/s (n=8192, 4x60-bit moduli)",

@@ -1505,7 +1505,11 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     // five launches each: inverse NTT, scaler, forward NTT of the new rows) run side by side, lhs on the caller's
     // stream and rhs on the internal one, and meet again in front of the tensor kernel -- the tail of one chain's
     // launch is filled by the other's (C5 at batch 16: launches of 4.25 waves; profiles/r03_split_ext_ab.txt).
-    const bool split_ext = !dual && m.streams.load(std::memory_order_relaxed) >= 2 && batch <= chunk &&
+    // Squaring (`&ct * &ct` with both operands the same buffer, the reference's bench ID "square", F/bfv/ops/mod.rs:
+    // 259-358): the rhs extension would recompute the lhs one bit for bit, so it is skipped and the tensor kernel
+    // reads the one extended operand twice (10 launches -> 7 per chunk; same values by construction).
+    const bool square = lhs == rhs && m.ext_lhs == m.ext_rhs;
+    const bool split_ext = !dual && !square && m.streams.load(std::memory_order_relaxed) >= 2 && batch <= chunk &&
                            FHE_LAB_INT("MUL_SPLIT_EXT", 1) != 0;
     hipEvent_t ext_done = nullptr;
     struct EventBack {
@@ -1538,7 +1542,9 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         const u64 *l = lhs + b0 * 2 * PL, *r = rhs + b0 * 2 * PL;
         // EXTEND (mul.rs:192-195): both parts of every lhs (rhs) ciphertext in one go
         scale_polys(*m.ext_lhs, l, extL.u(), nb * 2, true, s, !skip_copy);
-        if (split_ext) {   // (one chunk: the fork above put the internal stream behind the caller's earlier work)
+        if (square) {
+            // (nothing: extR is never read)
+        } else if (split_ext) {   // (one chunk: the fork above put the internal stream behind the caller's earlier work)
             scale_polys(*m.ext_rhs, r, extR.u(), nb * 2, true, join.aux, !skip_copy);
             FHE_HIP_CHECK(hipEventRecord(ext_done, join.aux));
             FHE_HIP_CHECK(hipStreamWaitEvent(s, ext_done, 0));
@@ -1551,14 +1557,14 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         const bool fused_tensor = e.logn <= 16 && !FHE_LAB_FLAG("NO_TENSOR_FUSION");
         if (fused_tensor) {
             require(nb <= 32768, E_ARG, "chunk too large for the fused tensor kernel");  // 3*K*nb blocks in a 1-D grid
-            k::TensorSrc ts{extL.u(), extR.u(), skip_copy ? l : nullptr, skip_copy ? r : nullptr, (uint32_t)L,
-                            (uint32_t)L};
+            k::TensorSrc ts{extL.u(), square ? extL.u() : extR.u(), skip_copy ? l : nullptr, skip_copy ? r : nullptr,
+                            (uint32_t)L, (uint32_t)L};
             launch_tensor_intt(e, ts, ten.u(), nb, s);
         } else {
             for (size_t t0 = 0; t0 < nb; t0 += 32768) {  // grid.y limit
                 const size_t tn = std::min<size_t>(32768, nb - t0);
                 FHE_LAUNCH("tensor", k::tensor_kernel, dim3(blocks_for(PK, EW_THREADS), (unsigned)tn), dim3(EW_THREADS), 0,
-                           s, extL.u() + t0 * 2 * PK, extR.u() + t0 * 2 * PK, skip_copy ? l + t0 * 2 * PL : nullptr,
+                           s, extL.u() + t0 * 2 * PK, (square ? extL.u() : extR.u()) + t0 * 2 * PK, skip_copy ? l + t0 * 2 * PL : nullptr,
                            skip_copy ? r + t0 * 2 * PL : nullptr, ten.u() + t0 * PK, e.dmods(), (uint32_t)K, (uint32_t)L,
                            (uint32_t)L, (uint32_t)e.logn, (u64)nb, 0u);
             }

@@ -1383,8 +1383,8 @@ fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rh
         set_device(*mm.base);
         const size_t ie = 2 * mm.base->L * mm.base->n, oe = mm.out_parts() * mm.out_rows() * mm.base->n;
         HostIO io;
-        u64 *dl = io.in(lhs, batch * ie), *dr = io.in(rhs, batch * ie), *dout = io.out(batch * oe);
-        bfv_mul(mm, dl, dr, dout, batch, nullptr);
+        u64 *dl = io.in(lhs, batch * ie), *dr = lhs == rhs ? dl : io.in(rhs, batch * ie), *dout = io.out(batch * oe);
+        bfv_mul(mm, dl, dr, dout, batch, nullptr);   // (lhs == rhs: one upload, and the squaring shortcut of bfv_mul)
         io.back(out, dout, batch * oe);
     });
 }

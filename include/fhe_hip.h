@@ -352,7 +352,8 @@ fhe_status fhe_mul_set_chunk(fhe_mul *m, size_t chunk);
 fhe_status fhe_mul_set_streams(fhe_mul *m, size_t streams);
 fhe_status fhe_mul_get_options(const fhe_mul *m, size_t *chunk, size_t *streams);
 /* Multiplicator::multiply (F/bfv/ops/mul.rs:165-243), the metric's unit of work:
- * lhs, rhs [batch][2][L][N] Ntt -> out [batch][parts][rows][N] Ntt. */
+ * lhs, rhs [batch][2][L][N] Ntt -> out [batch][parts][rows][N] Ntt.  lhs == rhs (the same buffer: squaring, the
+ * reference's `&c1 * &c1`) extends the operand once; the values are those of the general call. */
 fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out, size_t batch);
 fhe_status fhe_bfv_mul_dev(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out,
                            size_t batch, void *stream);

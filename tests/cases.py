@@ -646,6 +646,34 @@ def case_multiply(fhe, dev, nmod=3, n=16, batch=3, level=0, chunk=0, streams=1):
         assert np.array_equal(got[i], ct_arr(A[i].mul(B[i])))
 
 
+def case_multiply_square(fhe, dev, nmod=3, n=32, batch=5):
+    """`&c1 * &c1` (the reference's bench ID "square", bfv/ops/mod.rs:259-358 squaring branch; benches/bfv.rs:232) on
+    the fused pipeline: the SAME buffer as both operands takes the engine's squaring shortcut (operand extended
+    once) and must equal the general multiplication of two equal ciphertexts and the oracle -- with and without
+    relinearisation, with modulus switching."""
+    x = Xfer(dev)
+    opar, par = _params(fhe, nmod, n)
+    rng = random.Random(77)
+    sk = obfv.SecretKey.random(opar, rng)
+    cts = [sk.encrypt([rng.randrange(opar.plaintext) for _ in range(n)], rng) for _ in range(batch)]
+    a = np.array([ct_arr(c) for c in cts], dtype=np.uint64)
+    ork = obfv.RelinearizationKey(sk, rng)
+    ctx = par.context_at_level(0)
+    rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, *ksk_arrays(ork.ksk)[::2]))
+    for use_rk, ms in ((None, False), (rk, False), (rk, True)):
+        m = fhe.Multiplicator.default(par, use_rk, 0, ms)
+        om = obfv.Multiplicator.default(ork) if use_rk is not None else None
+        da = x.to(a)
+        sq = x.back(m.multiply(da, da))                       # same buffer: the shortcut
+        gen = x.back(m.multiply(x.to(a), x.to(a.copy())))     # two buffers: the general pipeline
+        assert np.array_equal(sq, gen)
+        if om is not None and ms:
+            om.enable_mod_switching()
+        for i, c in enumerate(cts):
+            want = ct_arr(om.multiply(c, c)) if om is not None else ct_arr(c.mul(c))
+            assert np.array_equal(sq[i], want), (use_rk is not None, ms, i)
+
+
 def case_multiply_custom_factors(fhe, dev, n=16):
     """ops/mul.rs:369-418 (`different_mul_strategy`): rhs pre-scaled by P/Q, post-scale t/P."""
     x = Xfer(dev)

@@ -256,3 +256,9 @@ def test_params_with_short_tables_fail_cleanly(fhe):
         raise AssertionError("short host table accepted")
     except fhe.FheError as e:
         assert e.code == -5, e
+
+
+def test_multiply_square_shortcut(fhe):
+    cases.case_multiply_square(fhe, False)
+    with fhe.Stream(0):
+        cases.case_multiply_square(fhe, "abi", batch=3)

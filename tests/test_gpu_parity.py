@@ -132,6 +132,12 @@ def test_multiply(fhe, nmod, n, level, chunk, dev):
     cases.case_multiply(fhe, dev, nmod=nmod, n=n, level=level, chunk=chunk)
 
 
+@pytest.mark.parametrize("dev", [False, True])
+def test_multiply_square_shortcut(fhe, dev):
+    cases.case_multiply_square(fhe, dev)
+    cases.case_multiply_square(fhe, dev, nmod=2, n=1024, batch=3)
+
+
 def test_multiply_custom_factors(fhe):
     cases.case_multiply_custom_factors(fhe, True)
 

@@ -29,6 +29,21 @@ def test_bench_spawns_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = _line(r.stdout)
     assert line["spawn_check"] == "ok" and line["n_gpus"] == 2 and line["dist_backend"] == "gloo"
+    # more than one GPU measures BASELINE configs[3] (C4): 8192 pairs per GPU unless --batch says otherwise
+    assert line["batch_per_gpu"] == 8192 and line["workload"].startswith("C4:") and "8192 per GPU" in line["workload"]
+
+
+def test_bench_single_gpu_is_c2_and_batch_overrides():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--spawn-check"], capture_output=True, text=True,
+                       timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _line(r.stdout)
+    assert line["batch_per_gpu"] == 1024 and line["workload"].startswith("C2:")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--batch", "1024", "--spawn-check"], capture_output=True,
+                       text=True, timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _line(r.stdout)
+    assert line["batch_per_gpu"] == 1024 and not line["workload"].startswith("C4:")
 
 
 def test_bench_under_torchrun():

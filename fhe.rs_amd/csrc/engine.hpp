@@ -752,10 +752,27 @@ inline void scaler_upload(Scaler &s) {
     for (size_t j = 0; j < c.nto; j++)
         std::copy(c.omega.begin() + j * c.nfrom, c.omega.begin() + (j + 1) * c.nfrom, omega_p.begin() + j * nf);
     std::vector<u64> sign64(c.theta_omega_sign.begin(), c.theta_omega_sign.end());
+    // one-accumulator form of w (scale_kernel): subtracted terms enter as (~x) * theta, and the host sums what that
+    // adds too much: (2^64 - 1) * theta_omega_i over the subtracted sources, plus (2^128 - 1) * theta_gamma when the
+    // v * theta_gamma term is subtracted (v = v_hi 2^64 + v_lo, both words complemented); all mod 2^256
+    std::vector<u64> mask64(c.nfrom, 0);
+    BigUint wk(0);
+    for (size_t i = 0; i < c.nfrom; i++)
+        if (c.theta_omega_sign[i]) {
+            mask64[i] = ~0ull;
+            const u64 limbs[2] = {c.theta_omega_lo[i], c.theta_omega_hi[i]};
+            wk = wk + BigUint::from_limbs(limbs, 2) * (BigUint::pow2(64) - BigUint(1));
+        }
+    if (!c.theta_gamma_sign) {
+        const u64 limbs[2] = {c.theta_gamma_lo, c.theta_gamma_hi};
+        wk = wk + BigUint::from_limbs(limbs, 2) * (BigUint::pow2(128) - BigUint(1));
+    }
+    wk = wk % BigUint::pow2(256);
     size_t o_fold = push(fold);
     size_t o_gn = push(gneg), o_om = push(omega_p), o_vt = push(vtab), o_c64 = push(c64), o_c128 = push(c128);
     size_t o_tol = push(padded(c.theta_omega_lo)), o_toh = push(padded(c.theta_omega_hi)), o_tos = push(padded(sign64));
     size_t o_tgl = push(padded(c.theta_garner_lo)), o_tgh = push(padded(c.theta_garner_hi));
+    size_t o_tom = push(padded(mask64));
     s.d_all.upload(all);
     u64 *b = s.d_all.p;
     s.dev.gamma_neg = b + o_gn;
@@ -766,6 +783,8 @@ inline void scaler_upload(Scaler &s) {
     s.dev.theta_omega_lo = b + o_tol;
     s.dev.theta_omega_hi = b + o_toh;
     s.dev.theta_omega_sign = b + o_tos;
+    s.dev.theta_omega_mask = b + o_tom;
+    for (size_t i = 0; i < 4; i++) s.dev.w_const[i] = wk.limb(i);
     s.dev.theta_garner_lo = b + o_tgl;
     s.dev.theta_garner_hi = b + o_tgh;
     s.dev.theta_gamma_lo = c.theta_gamma_lo;

@@ -1323,6 +1323,8 @@ struct ScalerDev {
     const u64 *c128_tab;                                 // [nto][16]  k * 2^128 mod q
     const u64 *theta_omega_lo, *theta_omega_hi;          // [nfrom]
     const u64 *theta_omega_sign;                         // [nfrom] (0/1)
+    const u64 *theta_omega_mask;                         // [nfrom] 0 (term added) or ~0 (term subtracted)
+    u64 w_const[4];                                      // the constant the one-accumulator form of w subtracts (below)
     const u64 *theta_garner_lo, *theta_garner_hi;        // [nfrom]
     u64 theta_gamma_lo, theta_gamma_hi;
     u64 narrow_mask;  // bit j: the output sum for target modulus j provably stays below 2^(2k_j+1) (see scaler_upload)
@@ -1449,31 +1451,29 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
     u64 wlo = 0, whi = 0;
     bool w_sign = false;
     if (!s.is_one) {
-        // t = sum_i +/- r_i * theta_omega_i  -/+  v * theta_gamma  (mod 2^256, scaler.rs:278-301): the
-        // terms added and the terms subtracted are summed separately, one wrapping subtraction at the end
-        Cols5 pos5, neg5;
+        // t = sum_i +/- r_i * theta_omega_i  -/+  v * theta_gamma  (mod 2^256, scaler.rs:278-301).  ONE accumulator:
+        // a subtracted term  -x * theta  is written  (~x) * theta - (2^64 - 1) * theta  (mod 2^256), so every term is
+        // an addition of (x ^ mask) * theta with a wave-uniform mask of 0 or ~0, and the constants
+        // (2^64 - 1) * theta of the subtracted terms are one 256-bit constant the host summed (ScalerDev::w_const).
+        // Round 3: the two-accumulator form (added and subtracted terms summed separately) chose its accumulator by a
+        // uniform branch per term, and every merge of the two paths cost a copy of the ten accumulator registers.
+        Cols5 acc5;
 #pragma unroll
         for (int i = 0; i < NF; i++) {
                 // theta_omega_i = 0 whenever the scaled Garner coefficient is an integer -- e.g. every
                 // source modulus outside the denominator when scaling Q*P -> Q by t/Q (5 of C2's 9)
                 const u64 tlo = s.theta_omega_lo[i], thi = s.theta_omega_hi[i];
                 if ((tlo | thi) == 0) continue;
-                if (s.theta_omega_sign[i])
-                    cols5_mac_64x128(neg5, rests[i], tlo, thi);
-                else
-                    cols5_mac_64x128(pos5, rests[i], tlo, thi);
+                cols5_mac_64x128(acc5, rests[i] ^ s.theta_omega_mask[i], tlo, thi);
             }
-        // v * theta_gamma (128 x 128 -> 256 wrapping): low word of v, then (high word) << 64
-        if (s.theta_gamma_sign)
-            cols5_mac_64x128(pos5, vlo, s.theta_gamma_lo, s.theta_gamma_hi);
-        else
-            cols5_mac_64x128(neg5, vlo, s.theta_gamma_lo, s.theta_gamma_hi);
-        Cols256 pos = cols5_to_cols256(pos5), neg = cols5_to_cols256(neg5);
-        if (s.theta_gamma_sign)
-            cols_mac_64x128_shl64(pos, vhi, s.theta_gamma_lo, s.theta_gamma_hi);
-        else
-            cols_mac_64x128_shl64(neg, vhi, s.theta_gamma_lo, s.theta_gamma_hi);
-        const U256 t = u256_sub(cols_resolve(pos), cols_resolve(neg));
+        // v * theta_gamma (128 x 128 -> 256 wrapping): low word of v, then (high word) << 64; subtracted unless
+        // theta_gamma_sign
+        const u64 gmask = s.theta_gamma_sign ? 0ull : ~0ull;
+        cols5_mac_64x128(acc5, vlo ^ gmask, s.theta_gamma_lo, s.theta_gamma_hi);
+        Cols256 acc = cols5_to_cols256(acc5);
+        cols_mac_64x128_shl64(acc, vhi ^ gmask, s.theta_gamma_lo, s.theta_gamma_hi);
+        const U256 wk{(u128_t)s.w_const[0] | ((u128_t)s.w_const[1] << 64), (u128_t)s.w_const[2] | ((u128_t)s.w_const[3] << 64)};
+        const U256 t = u256_sub(cols_resolve(acc), wk);
         w_sign = u256_ge_2_191(t);
         if (w_sign) {
             u256_shr_lo128(u256_not(t), 126, wlo, whi);

@@ -269,7 +269,13 @@ impl HipCtx {
     /// `Context::new` (rq/context.rs:42-92) on `device` (-1: host-only handle).
     pub fn new(device: i32, degree: usize, moduli: &[u64], tables: Option<&NttTables<'_>>) -> Result<Self> {
         let mut out: *mut ffi::FheCtx = ptr::null_mut();
-        let p = |f: fn(&NttTables<'_>) -> &[u64]| tables.map_or(ptr::null(), |t| f(t).as_ptr());
+        // (all six table pointers, or all NULL: the engine then derives its own primitive roots)
+        let null = ptr::null::<u64>();
+        let (om, oms, zi, zis, si, sis) = match tables {
+            Some(t) => (t.omegas.as_ptr(), t.omegas_shoup.as_ptr(), t.zetas_inv.as_ptr(), t.zetas_inv_shoup.as_ptr(),
+                        t.size_inv.as_ptr(), t.size_inv_shoup.as_ptr()),
+            None => (null, null, null, null, null, null),
+        };
         if let Some(t) = tables {
             let full = moduli.len() * degree;
             expect_len("NttTables.omegas", t.omegas.len(), full)?;
@@ -280,9 +286,7 @@ impl HipCtx {
             expect_len("NttTables.size_inv_shoup", t.size_inv_shoup.len(), moduli.len())?;
         }
         check(unsafe {
-            ffi::fhe_ctx_create(device as c_int, degree, moduli.len(), moduli.as_ptr(), p(|t| t.omegas),
-                p(|t| t.omegas_shoup), p(|t| t.zetas_inv), p(|t| t.zetas_inv_shoup), p(|t| t.size_inv),
-                p(|t| t.size_inv_shoup), &mut out)
+            ffi::fhe_ctx_create(device as c_int, degree, moduli.len(), moduli.as_ptr(), om, oms, zi, zis, si, sis, &mut out)
         })?;
         Ok(Self { view: CtxView { ptr: out, _root: PhantomData } })
     }

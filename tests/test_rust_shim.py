@@ -86,7 +86,7 @@ PATCH_DIR = os.path.join(ROOT, "rust", "patches")
 RUST_STD = {  # methods / functions of std, ndarray and itertools the inserted code calls
     "iter", "map", "collect", "flat_map", "copied", "to_vec", "len", "unwrap", "expect", "clone", "as_slice",
     "as_slice_mut", "chunks_exact", "first", "ok_or", "map_err", "any", "zip", "into", "max", "as_ref", "from", "default",
-    "ptr_eq", "get_or_try_init", "reset", "is_none", "new",
+    "ptr_eq", "get_or_try_init", "reset", "is_none", "new", "with_capacity", "extend_from_slice", "push",
 }
 
 

@@ -42,11 +42,18 @@ EDITS = [
     #[cfg(feature = "hip")]
     pub fn hip_handle(&self) -> Result<&Arc<fhe_math_hip::HipCtx>> {
         self.hip.get_or_try_init(|| {
-            let cat = |f: fn(&NttOperator) -> &[u64]| self.ops.iter().flat_map(|o| f(o).iter().copied()).collect::<Vec<u64>>();
-            let (om, oms) = (cat(|o| o.hip_tables().0), cat(|o| o.hip_tables().1));
-            let (zi, zis) = (cat(|o| o.hip_tables().2), cat(|o| o.hip_tables().3));
-            let si = self.ops.iter().map(|o| o.hip_tables().4).collect::<Vec<u64>>();
-            let sis = self.ops.iter().map(|o| o.hip_tables().5).collect::<Vec<u64>>();
+            let full = self.ops.len() * self.degree;
+            let (mut om, mut oms, mut zi, mut zis) = (Vec::with_capacity(full), Vec::with_capacity(full), Vec::with_capacity(full), Vec::with_capacity(full));
+            let (mut si, mut sis) = (Vec::with_capacity(self.ops.len()), Vec::with_capacity(self.ops.len()));
+            for op in self.ops.iter() {
+                let t = op.hip_tables();
+                om.extend_from_slice(t.0);
+                oms.extend_from_slice(t.1);
+                zi.extend_from_slice(t.2);
+                zis.extend_from_slice(t.3);
+                si.push(t.4);
+                sis.push(t.5);
+            }
             let tables = fhe_math_hip::NttTables {
                 omegas: &om, omegas_shoup: &oms, zetas_inv: &zi, zetas_inv_shoup: &zis, size_inv: &si, size_inv_shoup: &sis,
             };

@@ -62,7 +62,36 @@ def c3(reps):
     sys.exit(1 if bad else 0)
 
 
+def small(reps):
+    """Round 3: one-chunk batches in the handle's default mode -- the lhs / rhs operand extensions run side by side on
+    the caller's and the internal stream (per-call fork / join events from the pool) -- and the squaring shortcut:
+    batch 16 at C2, every result against the single-stream reference."""
+    n = 8192
+    t = fhe.generate_prime(20, 2 * n, 1 << 20)
+    par = fhe.BfvParameters(n, t, moduli_sizes=[60] * 4)
+    ctx = par.context_at_level(0)
+    L = ctx.nmoduli
+    kk = ctx.synth_uniform(7, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, n)
+    ksk = fhe.KeySwitchingKey(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous())
+    mul = fhe.Multiplicator.default(par, fhe.RelinearizationKey(ksk), 0).set_streams(1)
+    a, b = ctx.synth_uniform(7, 0, 0, 2, 16), ctx.synth_uniform(7, 0, 2, 2, 16)
+    ref_m, ref_s = mul.multiply(a, b), mul.multiply(a, a.clone())   # single stream, general pipeline
+    torch.cuda.synchronize()
+    mul.set_streams(2)
+    bad, t0 = 0, time.time()
+    for i in range(reps):
+        m, sq = mul.multiply(a, b), mul.multiply(a, a)
+        if i % 8 == 0 and not (torch.equal(m, ref_m) and torch.equal(sq, ref_s)):
+            bad += 1
+    torch.cuda.synchronize()
+    print(json.dumps(dict(config="C2 batch 16, two streams (split extension) + squaring shortcut", repetitions=reps,
+                          ops=reps * 32, checked=(reps + 7) // 8, mismatches=bad, seconds=round(time.time() - t0, 1))))
+    sys.exit(1 if bad else 0)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "c3":
         c3(int(sys.argv[1]))
+    if len(sys.argv) > 3 and sys.argv[3] == "small":
+        small(int(sys.argv[1]))
     main()

@@ -1,0 +1,429 @@
+// kernels_ks.hpp -- the fused key switch: ks_fused_kernel (rows that fit LDS) and ks_fused_split_kernel (sub-blocks).
+#pragma once
+#include "kernels_passes.hpp"
+
+namespace fhe {
+namespace k {
+
+// ------------------------------------------------------------ fused key switch ----
+// (c0, c1)[b][j] (+)= sum_i NTT_j( [p_i]_{q_j} ) (.) (k0, k1)[i][j]   for one (b, j) per workgroup.
+// The digit rows p[b][i][:] are lifted (reduced mod q_j), transformed in LDS and multiplied
+// into per-thread register accumulators; the key streams from L2/MALL (shared by the batch).
+// A non-null addend0/addend1 is added to the respective output (fused relinearisation add,
+// F/bfv/ops/mul.rs:224-225; rotation adds substitute(c0) to c0 only); canonical outputs.
+// ks_threads_c(LOGN) threads; thread t owns the 16-byte chunks {c*T + t}, c < CH (or the single
+// coefficient t when the row is smaller than one chunk per thread).
+// (FHE_KS_TWPF=true: the transforms' per-lane twiddles requested one pass ahead at N = 8192 -- 112 VGPRs, no scratch,
+// and no change in same-box A/B, profiles/r02_ks_twpf_ab.txt)
+// (FHE_KS_PERSIST14=1: resident workgroups at N = 16384 as well -- no row-prefetch registers there, so nothing to
+// overlap: C3 relinearise 108.1-109.7 k against 111.0-111.3 k ops/s, profiles/r02_ks_persist_ab.txt)
+// TT (threads per workgroup, 0 = ks_threads_c(LOGN)): TT = N / 16 at N = 8192 is the two-workgroups-per-CU cut -- 512
+// threads x 16 coefficients, BOTH accumulator sets in registers (64 VGPRs, as at N = 16384), only the 68 KiB row tile
+// in LDS, so that a second workgroup is resident and runs its butterflies while this one sits in a barrier.
+constexpr int ks_threads_tt(int logn, int tt) { return tt ? tt : ks_threads_c(logn); }
+constexpr bool ks_acc1_in_lds_tt(int logn, int tt) { return tt == 0 && ks_acc1_in_lds_c(logn); }
+template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0>
+__global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), 4)
+    ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
+                    u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
+                    u64 addend_poly_stride, const u64 *__restrict__ k0, const u64 *__restrict__ k0s,
+                    const u64 *__restrict__ k1, const u64 *__restrict__ k1s, const DevMod *__restrict__ mods,
+                    const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk, uint32_t digit_arg,
+                    const u64 *__restrict__ xhat, u64 xhat_poly_stride, uint32_t total) {
+    FHE_DYN_SMEM(u64, lds);
+    constexpr int T = ks_threads_tt(LOGN, TT);
+    constexpr int N = 1 << LOGN;
+    constexpr int CH = tile_chunks_c(LOGN, T);
+    constexpr int NE = CH > 0 ? 2 * CH : 1;  // coefficients owned by a thread
+    // GM: radix (log2) of the LDS passes.  8 everywhere but N = 16384, whose 1024 threads hold both accumulator sets in
+    // registers (64 VGPRs): beside a per-lane-twiddle radix-8 pass that spills 24 VGPRs (100 B of scratch per lane,
+    // 5 GB of extra HBM traffic per 512-polynomial launch, PMC).  GM_MIXED keeps radix 8 for the passes whose
+    // twiddles are scalar and takes radix 4 for the rest (3+3+2+2+2+2 stages, 124 VGPRs, no scratch): C3 relinearise
+    // 99.2 k (radix 8) -> 110.5 k (radix 4 throughout) -> 111.7-112.9 k ops/s.
+    const uint32_t tid0 = threadIdx.x;
+    // (an XCD-aware order that puts the lk workgroups of one polynomial on one L2, as tensor_intt_kernel
+    // does, was measured: no change -- this kernel is nowhere near the HBM limit)
+    // The (ciphertext, key modulus) items of a launch are dealt round-robin to the gridDim.x workgroups (`total` of
+    // them; the host launches one workgroup per item except at N = 8192, where a workgroup owns its CU: there
+    // gridDim.x is the number of CUs and, while an item's result is on its way out, the next item's first digit row
+    // is already coming in -- neither that load nor a workgroup launch sits between two items).
+    u64x2 pre[ks_acc1_in_lds_tt(LOGN, TT) ? CH : 1];
+    bool have_pre = false;   // (block-uniform) `pre` already holds this item's first digit row
+#if defined(FHE_HOST_EMULATION)
+    constexpr bool ITEM_LOOP = true;    // (every size, so that the emulated suite walks the loop)
+#else
+    constexpr bool ITEM_LOOP = (LOGN == 13 && TT == 0) || (FHE_KS_PERSIST14 && LOGN == 14);
+#endif
+    uint32_t item = blockIdx.x;
+    if (item >= total) return;
+    do {
+    const uint32_t b = to_sgpr(item / lk), j = item - b * lk;
+    const DevMod md = mods[j];
+    const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
+    const u64x2 *twr = tw + (u64)j * N;
+    // N = 8192: 1024 threads cap a thread at 128 VGPRs, which 2 x 16 accumulators plus a radix-8
+    // pass do not fit; the c1 accumulators live in LDS behind the row tile instead (each thread
+    // only ever touches its own 16-byte chunks, so no extra barrier).
+    constexpr bool ACC1_LDS = ks_acc1_in_lds_tt(LOGN, TT);
+    u64 acc0[NE], acc1[ACC1_LDS ? 1 : NE];
+    u64x2 *const acc1_lds = reinterpret_cast<u64x2 *>(lds + lds_words(N));
+#pragma unroll
+    for (int e = 0; e < NE; e++) acc0[e] = 0;
+    if constexpr (ACC1_LDS) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) acc1_lds[c * T + tid0] = u64x2{0, 0};
+    } else {
+#pragma unroll
+        for (int e = 0; e < NE; e++) acc1[e] = 0;
+    }
+    // `digit_arg` = digit_shift_bits | lift_mode << 8.  lift_mode says how far a source residue can exceed
+    // the key moduli (host-side, from the moduli): 1 -> below 2 q_j (one conditional subtraction lifts
+    // it), 2 -> below 4 q_j (two), 0 -> anything (Barrett).  RNS digits of same-width moduli are mode 1.
+    const uint32_t digit_shift_bits = digit_arg & 0xff, lift_mode = digit_arg >> 8;
+    auto lift = [&](u64 v) -> u64 {
+        if (lift_mode == 1) return csub_n(v, p, pm.np);
+        if (lift_mode == 2) return csub_n(csub_n(v, p2, pm.np2), p, pm.np);
+        return reduce_u64(v, md);
+    };
+    // digit_shift_bits == 0: digit i is residue row i of p (RNS decomposition, :256-268).
+    // otherwise: base-2^bits digits of the single row 0 (key_switch_decomposition, :323-362).
+    const u64 *const src0 = pin + (u64)b * src_poly_stride;
+    const u64 dstride = digit_shift_bits ? 0 : (u64)N;
+    const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+    // `xhat` (callers that hold the digit polynomial in Ntt form -- relinearise, Galois, RGSW: [digits][N] per
+    // polynomial over the ciphertext moduli, canonical): the RNS digit j reduced mod q_j is row j itself and its
+    // transform under key modulus j IS xhat's row j (the ciphertext moduli are a prefix of the key moduli), so that
+    // one of the L transforms of this workgroup is not computed: its product initialises the accumulators.
+    const bool own = xhat != nullptr && digit_shift_bits == 0 && j < ndigits;   // (block-uniform)
+    if (own) {
+        const u64 koff = ((u64)j * lk + j) * N;
+        const u64 *xr = xhat + (u64)b * xhat_poly_stride + (u64)j * N;
+        if constexpr (CH > 0) {
+            const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
+            const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t ci = c * T + tid0;
+                const u64x2 v = reinterpret_cast<const u64x2 *>(xr)[ci];
+                const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+                acc0[2 * c] = mul_shoup_lazy_n(v.x, q0.x, q0s.x, pm.np);        // below 2p, like every accumulator value
+                acc0[2 * c + 1] = mul_shoup_lazy_n(v.y, q0.y, q0s.y, pm.np);
+                const u64x2 a{mul_shoup_lazy_n(v.x, q1.x, q1s.x, pm.np), mul_shoup_lazy_n(v.y, q1.y, q1s.y, pm.np)};
+                if constexpr (ACC1_LDS) {
+                    acc1_lds[ci] = a;
+                } else {
+                    acc1[ACC1_LDS ? 0 : 2 * c] = a.x;
+                    acc1[ACC1_LDS ? 0 : 2 * c + 1] = a.y;
+                }
+            }
+        } else if (tid0 < N) {
+            const u64 v = xr[tid0];
+            acc0[0] = mul_shoup_lazy_n(v, k0[koff + tid0], k0s[koff + tid0], pm.np);
+            acc1[0] = mul_shoup_lazy_n(v, k1[koff + tid0], k1s[koff + tid0], pm.np);
+        }
+    }
+    const uint32_t nloop = ndigits - (own ? 1u : 0u);          // digits that go through the transform
+    auto digit_of = [&](uint32_t ii) -> uint32_t { return ii + ((own && ii >= j) ? 1u : 0u); };
+    // The workgroup is alone on its CU (LDS), so nothing else hides the row load: digit i+1's
+    // row is fetched into registers while digit i goes through its passes.
+    constexpr bool PREFETCH = ks_acc1_in_lds_tt(LOGN, TT);   // (needs the VGPRs the LDS accumulators free)
+    // (Feeding the first pass from these registers instead of staging the lifted row in LDS was
+    // measured: 2.5 % slower -- the extra register shuffling outweighs the saved barrier.)
+    if constexpr (PREFETCH) {
+        if (nloop > 0 && !have_pre) {
+            const u64x2 *first = reinterpret_cast<const u64x2 *>(src0 + (u64)digit_of(0) * dstride);
+#pragma unroll
+            for (int c = 0; c < CH; c++) pre[c] = first[c * T + tid0];
+        }
+    }
+    for (uint32_t ii = 0; ii < nloop; ii++) {
+        const uint32_t i = digit_of(ii);
+        const uint32_t tid = opaque(tid0);
+        const uint32_t sh = i * digit_shift_bits;
+        FHE_TS(0);
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t e = 2 * (c * T + tid);
+                lds[padi(e)] = lift((pre[c].x >> sh) & mask);
+                lds[padi(e + 1)] = lift((pre[c].y >> sh) & mask);
+            }
+        } else {
+            // (address and mask are recomputed per digit on purpose: hoisted, they cost VGPRs that the
+            // N = 16384 variant does not have)
+            const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N);
+            const u64 mask_i = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+            tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return lift((v >> sh) & mask_i); });
+        }
+        FHE_TS(1);
+        FHE_BARRIER();
+        FHE_TS(2);
+        if constexpr (PREFETCH) {
+            if (ii + 1 < nloop) {
+                const u64x2 *nx = reinterpret_cast<const u64x2 *>(src0 + (u64)digit_of(ii + 1) * dstride);
+#pragma unroll
+                for (int c = 0; c < CH; c++) pre[c] = nx[c * T + tid];
+            }
+        }
+        const u64 koff = ((u64)i * lk + j) * N;
+        if constexpr (CH > 0) {
+            const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
+            const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
+            // KPF: the key words of the first two chunks are requested before the barrier that ends the
+            // transform, so their L2 latency is spent waiting for the other waves, not after them
+            constexpr bool KPF = PREFETCH && CH >= 2;
+            // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
+            ntt_fwd_lds<LOGN, T, GM, FHE_KS_TWPF && LOGN == 13, !KPF, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
+            // (all four chunks prefetched -- 118 VGPRs, no scratch: no change; three: 2 % slower.  ABBA runs in
+            // profiles/r02_ks_kpf_ab.txt: the key words' latency is not what the MAC waits for)
+            constexpr int KPFN = KPF ? (FHE_KS_KPF_CHUNKS < CH ? FHE_KS_KPF_CHUNKS : CH) : 0;   // chunks whose key words are prefetched
+            u64x2 kq[KPF ? 4 * KPFN : 1];
+            if constexpr (KPF) {
+#pragma unroll
+                for (int c = 0; c < KPFN; c++) {
+                    const uint32_t ci = c * T + tid;
+                    kq[4 * c] = a0[ci], kq[4 * c + 1] = a0s[ci], kq[4 * c + 2] = a1[ci], kq[4 * c + 3] = a1s[ci];
+                }
+                FHE_TS(3);
+                FHE_BARRIER();
+                FHE_TS(4);
+            }
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t ci = c * T + tid;
+                u64x2 q0, q0s, q1, q1s;
+                if (KPF && c < KPFN) {
+                    q0 = kq[KPF ? 4 * c : 0], q0s = kq[KPF ? 4 * c + 1 : 0], q1 = kq[KPF ? 4 * c + 2 : 0], q1s = kq[KPF ? 4 * c + 3 : 0];
+                } else {
+                    q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+                }
+                const u64 vx = lds[padi(2 * ci)], vy = lds[padi(2 * ci + 1)];  // < 4p: Shoup accepts any u64
+                acc0[2 * c] = csub_n(acc0[2 * c] + mul_shoup_lazy_n(vx, q0.x, q0s.x, pm.np), p2, pm.np2);
+                acc0[2 * c + 1] = csub_n(acc0[2 * c + 1] + mul_shoup_lazy_n(vy, q0.y, q0s.y, pm.np), p2, pm.np2);
+                if constexpr (ACC1_LDS) {
+                    u64x2 a = acc1_lds[ci];
+                    a.x = csub_n(a.x + mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np), p2, pm.np2);
+                    a.y = csub_n(a.y + mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np), p2, pm.np2);
+                    acc1_lds[ci] = a;
+                } else {
+                    acc1[2 * c] = csub_n(acc1[2 * c] + mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np), p2, pm.np2);
+                    acc1[2 * c + 1] = csub_n(acc1[2 * c + 1] + mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np), p2, pm.np2);
+                }
+                if (c & 1) sched_fence();  // at most two chunks of key loads (32 VGPRs) in flight
+            }
+        } else {
+            ntt_fwd_lds<LOGN, T, GM, false, true, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
+            if (tid < N) {
+            const u64 v = lds[padi(tid)];
+            acc0[0] = csub_n(acc0[0] + mul_shoup_lazy_n(v, k0[koff + tid], k0s[koff + tid], pm.np), p2, pm.np2);
+            acc1[0] = csub_n(acc1[0] + mul_shoup_lazy_n(v, k1[koff + tid], k1s[koff + tid], pm.np), p2, pm.np2);
+            }
+        }
+        // (wave-contiguous chunk ownership, which makes this barrier and the one before the MAC wave-local as
+        // well, was measured: nothing beyond what the late pass plan already gives)
+        FHE_TS(5);
+        FHE_BARRIER();
+        FHE_TS(6);
+    }
+    // (FHE_DEBUG_KS_NOMEM -- every polynomial aliased to the first: rows, addends and outputs out of L2 -- makes this
+    // kernel 11 % faster at C2: what its one workgroup per CU cannot hide.  Requesting the addends during the last
+    // digit, into the row-prefetch registers that are idle then, was built: those 16 registers stay live through the
+    // last MAC and spill (84-164 B of scratch); not kept.)
+    const uint32_t tid = opaque(tid0);  // keeps the epilogue's address arithmetic below the digit loop
+    have_pre = false;
+    if constexpr (PREFETCH && ITEM_LOOP) {
+        const uint32_t nitem = item + gridDim.x;
+        if (nitem < total) {   // the next item's first digit row (the same selection as at the top of the loop)
+            const uint32_t nb = nitem / lk, nj = nitem - nb * lk;
+            const bool nown = xhat != nullptr && digit_shift_bits == 0 && nj < ndigits;
+            if (ndigits - (nown ? 1u : 0u) > 0) {
+                const uint32_t nd = (nown && nj == 0) ? 1u : 0u;
+                const u64x2 *first = reinterpret_cast<const u64x2 *>(pin + (u64)nb * src_poly_stride + (u64)nd * dstride);
+#pragma unroll
+                for (int c = 0; c < CH; c++) pre[c] = first[c * T + tid];
+                have_pre = true;
+            }
+        }
+    }
+    const u64 ooff = (u64)b * out_poly_stride + (u64)j * N;
+    const u64 aoff = (u64)b * addend_poly_stride + (u64)j * N;
+    if constexpr (CH > 0) {
+        u64x2 *o0 = reinterpret_cast<u64x2 *>(out0 + ooff), *o1 = reinterpret_cast<u64x2 *>(out1 + ooff);
+        const u64x2 *d0 = reinterpret_cast<const u64x2 *>(addend0 ? addend0 + aoff : nullptr);
+        const u64x2 *d1 = reinterpret_cast<const u64x2 *>(addend1 ? addend1 + aoff : nullptr);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t ci = c * T + tid;
+            u64x2 r0, r1;
+            r0.x = csub_n(acc0[2 * c], p, pm.np);
+            r0.y = csub_n(acc0[2 * c + 1], p, pm.np);
+            const u64x2 a1 = ACC1_LDS ? acc1_lds[ci] : u64x2{acc1[ACC1_LDS ? 0 : 2 * c], acc1[ACC1_LDS ? 0 : 2 * c + 1]};
+            r1.x = csub_n(a1.x, p, pm.np);
+            r1.y = csub_n(a1.y, p, pm.np);
+            if (d0) {
+                const u64x2 a = d0[ci];
+                r0.x = add_mod_n(r0.x, a.x, pm);
+                r0.y = add_mod_n(r0.y, a.y, pm);
+            }
+            if (d1) {
+                const u64x2 a = d1[ci];
+                r1.x = add_mod_n(r1.x, a.x, pm);
+                r1.y = add_mod_n(r1.y, a.y, pm);
+            }
+            o0[ci] = r0;
+            o1[ci] = r1;
+        }
+    } else if (tid < N) {
+        u64 r0 = csub(acc0[0], p), r1 = csub(acc1[0], p);
+        if (addend0) r0 = add_mod(r0, addend0[aoff + tid], p);
+        if (addend1) r1 = add_mod(r1, addend1[aoff + tid], p);
+        out0[ooff + tid] = r0;
+        out1[ooff + tid] = r1;
+    }
+    } while (ITEM_LOOP && (item += gridDim.x) < total);
+}
+
+// The same for rows that do not fit LDS (N = 2^(13+G0) >= 32768): one workgroup per (ciphertext,
+// key modulus j, 8192-point sub-block).  The first G0 Cooley-Tukey stages (native.rs:142-175,
+// blocks larger than the tile) are folded into the loader: coefficient e of sub-block `sub`
+// depends on the 2^G0 source coefficients e + k*8192 through G0 butterflies of which only the
+// branch leading to `sub` is evaluated (2^G0 - 1 Shoup multiplications per coefficient instead
+// of G0/2 amortised, but no round trip of the lifted row through HBM); the remaining 13 stages
+// run in LDS with twiddle base 2^G0 + sub, exactly like ntt_kernel's sub-block mode.
+template <int G0, int LOGM = 13, bool NARROW = false>
+__global__ void __launch_bounds__((1 << LOGM) / 8, 4)
+    ks_fused_split_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0,
+                          u64 *__restrict__ out1, u64 out_poly_stride, const u64 *__restrict__ addend0,
+                          const u64 *__restrict__ addend1, u64 addend_poly_stride, const u64 *__restrict__ k0,
+                          const u64 *__restrict__ k0s, const u64 *__restrict__ k1, const u64 *__restrict__ k1s,
+                          const DevMod *__restrict__ mods, const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk,
+                          uint32_t digit_arg, const u64 *__restrict__ xhat, u64 xhat_poly_stride) {
+    FHE_DYN_SMEM(u64, lds);
+    constexpr int M = 1 << LOGM, T = M / 8, CH = M / (2 * T), NS = 1 << G0;
+    constexpr u64 N = (u64)M << G0;
+    const uint32_t tid0 = threadIdx.x;
+    const uint32_t sub = blockIdx.x & (NS - 1);
+    const uint32_t bj = blockIdx.x >> G0;
+    const uint32_t b = to_sgpr(bj / lk), j = bj - b * lk;
+    const DevMod md = mods[j];
+    const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
+    const u64x2 *twr = tw + (u64)j * N;
+    const uint32_t digit_shift_bits = digit_arg & 0xff, lift_mode = digit_arg >> 8;  // see ks_fused_kernel
+    auto lift = [&](u64 v) -> u64 {
+        if (lift_mode == 1) return csub_n(v, p, pm.np);
+        if (lift_mode == 2) return csub_n(csub_n(v, p2, pm.np2), p, pm.np);
+        return reduce_u64(v, md);
+    };
+    u64 acc0[2 * CH];
+    u64x2 *const acc1_lds = reinterpret_cast<u64x2 *>(lds + lds_words(M));
+#pragma unroll
+    for (int e = 0; e < 2 * CH; e++) acc0[e] = 0;
+#pragma unroll
+    for (int c = 0; c < CH; c++) acc1_lds[c * T + tid0] = u64x2{0, 0};
+    // (see ks_fused_kernel: digit j under key modulus j is the caller's Ntt-form row j -- no transform)
+    const bool own = xhat != nullptr && digit_shift_bits == 0 && j < ndigits;
+    if (own) {
+        const u64 koff = ((u64)j * lk + j) * N + (u64)sub * M;
+        const u64x2 *xr = reinterpret_cast<const u64x2 *>(xhat + (u64)b * xhat_poly_stride + (u64)j * N + (u64)sub * M);
+        const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
+        const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t ci = c * T + tid0;
+            const u64x2 v = xr[ci], q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+            acc0[2 * c] = mul_shoup_lazy_n(v.x, q0.x, q0s.x, pm.np);
+            acc0[2 * c + 1] = mul_shoup_lazy_n(v.y, q0.y, q0s.y, pm.np);
+            acc1_lds[ci] = u64x2{mul_shoup_lazy_n(v.x, q1.x, q1s.x, pm.np), mul_shoup_lazy_n(v.y, q1.y, q1s.y, pm.np)};
+        }
+    }
+    const uint32_t nloop = ndigits - (own ? 1u : 0u);
+    for (uint32_t ii = 0; ii < nloop; ii++) {
+        const uint32_t i = ii + ((own && ii >= j) ? 1u : 0u);
+        const uint32_t tid = opaque(tid0);
+        const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N);
+        const uint32_t sh = i * digit_shift_bits;
+        const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t ci = c * T + tid;
+            u64x2 v[NS];
+#pragma unroll
+            for (int k = 0; k < NS; k++) v[k] = reinterpret_cast<const u64x2 *>(src + (u64)k * M)[ci];
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                v[k].x = lift((v[k].x >> sh) & mask);
+                v[k].y = lift((v[k].y >> sh) & mask);
+            }
+            // stage s keeps the half of the pairs whose output leads to `sub`
+#pragma unroll
+            for (int st = 0; st < G0; st++) {
+                const int half = NS >> (st + 1);
+                const u64x2 w = twr[(1u << st) + (sub >> (G0 - st))];
+                const bool minus = (sub >> (G0 - st - 1)) & 1;
+#pragma unroll
+                for (int m = 0; m < half; m++) {
+                    const u64 lx = csub_n(v[m].x, p2, pm.np2), ly = csub_n(v[m].y, p2, pm.np2);
+                    const u64 tx = mul_shoup_lazy_n(v[m + half].x, w.x, w.y, pm.np);
+                    const u64 ty = mul_shoup_lazy_n(v[m + half].y, w.x, w.y, pm.np);
+                    v[m].x = minus ? lx + p2 - tx : lx + tx;
+                    v[m].y = minus ? ly + p2 - ty : ly + ty;
+                }
+            }
+            lds[padi(2 * ci)] = v[0].x;
+            lds[padi(2 * ci + 1)] = v[0].y;
+        }
+        FHE_BARRIER();
+        // (NARROW: the folded loader stages leave values below 4p)
+        ntt_fwd_lds<LOGM, T, KS_GMAX, false, true, (NARROW ? 4 : 0), NoSrc, KS_LATE>(lds, twr, NS + sub, pm, tid);
+        const u64 koff = ((u64)i * lk + j) * N + (u64)sub * M;
+        const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
+        const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t ci = c * T + tid;
+            const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+            const u64 vx = lds[padi(2 * ci)], vy = lds[padi(2 * ci + 1)];
+            acc0[2 * c] = csub_n(acc0[2 * c] + mul_shoup_lazy_n(vx, q0.x, q0s.x, pm.np), p2, pm.np2);
+            acc0[2 * c + 1] = csub_n(acc0[2 * c + 1] + mul_shoup_lazy_n(vy, q0.y, q0s.y, pm.np), p2, pm.np2);
+            u64x2 a = acc1_lds[ci];
+            a.x = csub_n(a.x + mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np), p2, pm.np2);
+            a.y = csub_n(a.y + mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np), p2, pm.np2);
+            acc1_lds[ci] = a;
+            if (c & 1) sched_fence();
+        }
+        FHE_BARRIER();
+    }
+    const uint32_t tid = opaque(tid0);
+    const u64 ooff = (u64)b * out_poly_stride + (u64)j * N + (u64)sub * M;
+    const u64 aoff = (u64)b * addend_poly_stride + (u64)j * N + (u64)sub * M;
+    u64x2 *o0 = reinterpret_cast<u64x2 *>(out0 + ooff), *o1 = reinterpret_cast<u64x2 *>(out1 + ooff);
+    const u64x2 *d0 = reinterpret_cast<const u64x2 *>(addend0 ? addend0 + aoff : nullptr);
+    const u64x2 *d1 = reinterpret_cast<const u64x2 *>(addend1 ? addend1 + aoff : nullptr);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t ci = c * T + tid;
+        u64x2 r0, r1;
+        r0.x = csub_n(acc0[2 * c], p, pm.np);
+        r0.y = csub_n(acc0[2 * c + 1], p, pm.np);
+        const u64x2 a1v = acc1_lds[ci];
+        r1.x = csub_n(a1v.x, p, pm.np);
+        r1.y = csub_n(a1v.y, p, pm.np);
+        if (d0) {
+            const u64x2 a = d0[ci];
+            r0.x = add_mod_n(r0.x, a.x, pm);
+            r0.y = add_mod_n(r0.y, a.y, pm);
+        }
+        if (d1) {
+            const u64x2 a = d1[ci];
+            r1.x = add_mod_n(r1.x, a.x, pm);
+            r1.y = add_mod_n(r1.y, a.y, pm);
+        }
+        o0[ci] = r0;
+        o1[ci] = r1;
+    }
+}
+
+}  // namespace k
+}  // namespace fhe

@@ -229,9 +229,11 @@ FHE_HD u64 add_mod_n(u64 a, u64 b, const PM &m) { return csub_n(a + b, m.p, m.np
 template <bool SU = false>
 FHE_HD void fwd_butterfly(u64 &x, u64 &y, u64 w, u64 ws, const PM &m) {
     x = csub_n(x, m.p2, m.np2);
-    u64 t = mul_shoup_lazy_n<SU>(y, w, ws, m.np);
-    y = x + m.p2 - t;
-    x = x + t;
+    // x + t with x as the addend of the product chain (v_mad_u64_u32 adds a 64-bit value for free), and
+    // x + 2p - t = (2x + 2p) - (x + t): one 64-bit operation less than forming t, x + t and x + 2p - t separately
+    const u64 xt = x + y * w + mulhi64_t<SU>(y, ws) * m.np;
+    y = ((x << 1) + m.p2) - xt;
+    x = xt;
 }
 // Forward butterflies for moduli below 2^60 (16p < 2^64): the conditional subtraction on x is not
 // needed every stage.  With every value below b*p before a stage, both outputs are below (b+2)*p
@@ -268,18 +270,20 @@ FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, boo
         x = csub_n(x, p8, np8);
         x = csub_n(x, p4, np4);
     }
+    // (x + t formed inside the product chain, x + pk - t as (2x + pk) - (x + t): see fwd_butterfly; 2x may wrap
+    // around 2^64, the difference is exact because x + pk - t < 16p < 2^64)
 #if FHE_APPROX_SHOUP
-    const u64 t = y * w + mulhi64_approx<SU>(y, ws) * m.np;   // below 3p
+    const u64 xt = x + y * w + mulhi64_approx<SU>(y, ws) * m.np;   // t below 3p
     const u64 pk = m.p2 + m.p;
 #else
-    const u64 t = mul_shoup_lazy_n<SU>(y, w, ws, m.np);
+    const u64 xt = x + y * w + mulhi64_t<SU>(y, ws) * m.np;
     const u64 pk = m.p2;
 #endif
 #if defined(FHE_HOST_EMULATION)
-    if (t >= pk || x > ~0ull - pk) __builtin_trap();  // range tracking broken
+    if (xt - x >= pk || x > ~0ull - pk) __builtin_trap();  // range tracking broken
 #endif
-    y = x + pk - t;
-    x = x + t;
+    y = ((x << 1) + pk) - xt;
+    x = xt;
 }
 template <bool SU = false>
 FHE_HD void inv_butterfly(u64 &x, u64 &y, u64 z, u64 zs, const PM &m) {

@@ -467,7 +467,7 @@ inline void allow_big_lds(K kernel, size_t bytes) {
 // rejected kernel variants, selected by FHE_LAB_* environment switches in lab builds only (lab/lab_engine.hpp)
 struct Ksk;
 inline bool lab_try_ntt_fwd(const Ctx &c, unsigned rows_total, bool narrow, const u64 *in, u64 *out, const k::RowMap &map,
-                            uint32_t prologue, hipStream_t s);
+                            hipStream_t s);
 template <int LOGN>
 inline bool lab_try_ks_pair(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride, const u64 *a0,
                             const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s);
@@ -476,13 +476,13 @@ inline bool lab_try_ks_pair(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
 template <bool INV, bool NARROW = false>
 inline void launch_ntt_lds(const char *name, uint32_t logm, unsigned grid, hipStream_t s, const u64 *in, u64 *out,
                            const k::RowMap &map, const DevMod *mods, const k::u64x2 *tw, const k::u64x2 *ninv,
-                           uint32_t logn, uint32_t prologue) {
+                           uint32_t logn) {
     const size_t lds = k::lds_words(1u << logm) * sizeof(u64);
 #define FHE_NTT_CASE(LM)                                                                                        \
     case LM:                                                                                                    \
         allow_big_lds((k::ntt_kernel<INV, LM, NARROW>), lds);                                                   \
         FHE_LAUNCH(name, (k::ntt_kernel<INV, LM, NARROW>), dim3(grid), dim3(k::ntt_threads_c(LM)), lds, s, in,   \
-                   out, map, mods, tw, ninv, logn, prologue);                                                   \
+                   out, map, mods, tw, ninv, logn);                                                             \
         break;
     switch (logm) {
         FHE_NTT_CASE(3) FHE_NTT_CASE(4) FHE_NTT_CASE(5) FHE_NTT_CASE(6) FHE_NTT_CASE(7) FHE_NTT_CASE(8)
@@ -495,7 +495,7 @@ inline void launch_ntt_lds(const char *name, uint32_t logm, unsigned grid, hipSt
 // Forward / inverse NTT of `npolys * map.rows` residue rows.  N <= 16384: one LDS-resident
 // kernel.  N = 32768 / 65536: G0 global radix stages + LDS kernel on 8192-point sub-blocks.
 inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::RowMap map, size_t npolys,
-                       uint32_t prologue, hipStream_t s) {
+                       hipStream_t s) {
     if (npolys == 0 || map.rows == 0) return;
     const uint32_t logn = (uint32_t)c.logn;
     const unsigned rows_total = (unsigned)(npolys * map.rows);
@@ -506,24 +506,22 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
             for (uint32_t r = 0; r < map.rows; r++)
                 narrow = narrow && (c.root->moduli[(size_t)((int32_t)(map.row_begin + r) + map.mod_offset)] >> 60) == 0;
 #if defined(FHE_LAB)
-            if (lab_try_ntt_fwd(c, rows_total, narrow, in, out, map, prologue, s)) return;   // lab/lab_engine.hpp
+            if (lab_try_ntt_fwd(c, rows_total, narrow, in, out, map, s)) return;   // lab/lab_engine.hpp
 #endif
             if (narrow)
                 launch_ntt_lds<false, true>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(),
-                                            logn, prologue);
+                                            logn);
             else
-                launch_ntt_lds<false>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(), logn,
-                                      prologue);
+                launch_ntt_lds<false>("ntt_fwd", logn, rows_total, s, in, out, map, c.dmods(), c.dtw(), c.dninv(), logn);
         } else {
             bool narrow = !FHE_LAB_FLAG("NO_NARROW");
             for (uint32_t r = 0; r < map.rows; r++)
                 narrow = narrow && (c.root->moduli[(size_t)((int32_t)(map.row_begin + r) + map.mod_offset)] >> 60) == 0;
             if (narrow)
                 launch_ntt_lds<true, true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(),
-                                           logn, prologue);
+                                           logn);
             else
-                launch_ntt_lds<true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn,
-                                     prologue);
+                launch_ntt_lds<true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
         }
         return;
     }
@@ -535,21 +533,20 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     if (!inverse) {
         if (g0 == 2)
             FHE_LAUNCH("ntt_fwd_global", (k::ntt_global_kernel<false, 2>), dim3(gblocks), dim3(gth), 0, s, in, out,
-                       map, c.dmods(), c.dtw(), c.dninv(), logn, prologue);
+                       map, c.dmods(), c.dtw(), c.dninv(), logn);
         else
             FHE_LAUNCH("ntt_fwd_global", (k::ntt_global_kernel<false, 3>), dim3(gblocks), dim3(gth), 0, s, in, out,
-                       map, c.dmods(), c.dtw(), c.dninv(), logn, prologue);
+                       map, c.dmods(), c.dtw(), c.dninv(), logn);
         launch_ntt_lds<false>("ntt_fwd", logm, rows_total << g0, s, out, out, inplace, c.dmods(), c.dtw(), c.dninv(),
-                              logn, (uint32_t)k::PRO_NONE);
+                              logn);
     } else {
-        launch_ntt_lds<true>("ntt_inv", logm, rows_total << g0, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn,
-                             prologue);
+        launch_ntt_lds<true>("ntt_inv", logm, rows_total << g0, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
         if (g0 == 2)
             FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 2>), dim3(gblocks), dim3(gth), 0, s, out, out,
-                       inplace, c.dmods(), c.ditw(), c.dninv(), logn, (uint32_t)k::PRO_NONE);
+                       inplace, c.dmods(), c.ditw(), c.dninv(), logn);
         else
             FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 3>), dim3(gblocks), dim3(gth), 0, s, out, out,
-                       inplace, c.dmods(), c.ditw(), c.dninv(), logn, (uint32_t)k::PRO_NONE);
+                       inplace, c.dmods(), c.ditw(), c.dninv(), logn);
     }
 }
 
@@ -617,16 +614,16 @@ inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, s
         const k::RowMap m = full_map(e, e.L);
         if (logn - logm == 2)
             FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 2>), dim3(gblocks), dim3(gth), 0, s, out, out, m,
-                       e.dmods(), e.ditw(), e.dninv(), logn, (uint32_t)k::PRO_NONE);
+                       e.dmods(), e.ditw(), e.dninv(), logn);
         else
             FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 3>), dim3(gblocks), dim3(gth), 0, s, out, out, m,
-                       e.dmods(), e.ditw(), e.dninv(), logn, (uint32_t)k::PRO_NONE);
+                       e.dmods(), e.ditw(), e.dninv(), logn);
     }
 }
 
 inline void ntt_polys(const Ctx &c, bool inverse, const u64 *in, u64 *out, size_t npolys, hipStream_t s) {
     c.need_device();
-    launch_ntt(c, inverse, in, out, full_map(c, c.L), npolys, k::PRO_NONE, s);
+    launch_ntt(c, inverse, in, out, full_map(c, c.L), npolys, s);
 }
 
 inline void ew_op(const Ctx &c, u64 *a, const u64 *b, size_t npolys, uint32_t op, hipStream_t s) {
@@ -650,7 +647,7 @@ inline void wire_serialize(const Ctx &c, const u64 *polys, uint8_t *bytes, size_
     const u64 pe = (u64)c.L * c.n;
     WsGuard pb(from_ntt ? npolys * pe * sizeof(u64) : 8, s);
     if (from_ntt) {
-        launch_ntt(c, true, polys, pb.u(), full_map(c, c.L), npolys, k::PRO_NONE, s);
+        launch_ntt(c, true, polys, pb.u(), full_map(c, c.L), npolys, s);
         polys = pb.u();
     }
     const unsigned groups = (unsigned)(c.n / 8), block = groups < 256 ? 64 : 256;
@@ -671,7 +668,7 @@ inline void wire_deserialize(const Ctx &c, const uint8_t *bytes, u64 *polys, siz
         FHE_LAUNCH("wire_unpack", k::wire_unpack_kernel, dim3(blocks_for(groups, block), (unsigned)c.L, (unsigned)np),
                    dim3(block), 0, s, bytes + p0 * wb, polys + p0 * pe, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, wb);
     }
-    if (to_ntt) launch_ntt(c, false, polys, polys, full_map(c, c.L), npolys, k::PRO_NONE, s);
+    if (to_ntt) launch_ntt(c, false, polys, polys, full_map(c, c.L), npolys, s);
 }
 
 // Poly::random_from_seed (M/rq/mod.rs:276-292): seeds [npolys][32] -> polys [npolys][L][N]
@@ -882,12 +879,12 @@ inline void scale_polys(const Scaler &sc, const u64 *in, u64 *out, size_t npolys
     if (sc.ncommon >= t.L) return;
     if (repr_is_ntt) {
         WsGuard pb(npolys * in_stride * sizeof(u64), s);
-        launch_ntt(f, true, in, pb.u(), full_map(f, f.L), npolys, k::PRO_NONE, s);
+        launch_ntt(f, true, in, pb.u(), full_map(f, f.L), npolys, s);
         launch_scale(sc, pb.u(), in_stride, out, out_stride, npolys, s);
         k::RowMap m = full_map(t, t.L);
         m.rows = (uint32_t)(t.L - sc.ncommon);
         m.row_begin = (uint32_t)sc.ncommon;
-        launch_ntt(t, false, out, out, m, npolys, k::PRO_NONE, s);
+        launch_ntt(t, false, out, out, m, npolys, s);
     } else {
         launch_scale(sc, in, in_stride, out, out_stride, npolys, s);
     }
@@ -1148,9 +1145,9 @@ inline void switch_down_to_ntt(const Ctx &from, size_t iters, const u64 *in, u64
     const Ctx &to = *from.at_level(iters);
     const u64 stride = (u64)from.L * from.n, ostride = (u64)to.L * to.n;
     WsGuard a(npolys * stride * sizeof(u64), s);
-    launch_ntt(from, true, in, a.u(), full_map(from, from.L), npolys, k::PRO_NONE, s);
+    launch_ntt(from, true, in, a.u(), full_map(from, from.L), npolys, s);
     switch_down_to_pb(from, iters, a.u(), stride, out, ostride, npolys, s);
-    launch_ntt(to, false, out, out, full_map(to, to.L), npolys, k::PRO_NONE, s);
+    launch_ntt(to, false, out, out, full_map(to, to.L), npolys, s);
 }
 
 // key switch followed by the level fix-up and "+= (a0, a1)" used by relinearise / rotate:
@@ -1234,7 +1231,7 @@ inline void galois_apply(const Ksk &ks, size_t exponent, const u64 *ct, u64 *out
     k::RowMap m = full_map(cc, cc.L);
     m.src_poly_stride = 2 * PL;
     m.dst_poly_stride = PL;
-    launch_ntt(cc, true, sub.u() + PL, c2.u(), m, batch, k::PRO_NONE, s);
+    launch_ntt(cc, true, sub.u() + PL, c2.u(), m, batch, s);
     // out0 = key_switch0 + substitute(c0) ; out1 = key_switch1   (galois_key.rs:66-79)
     // (substitute(c1) in Ntt form doubles as the transforms of digit j under key modulus j)
     key_switch_add(ks, c2.u(), PL, sub.u(), nullptr, 2 * PL, out, out + PL, 2 * PL, batch, s, sub.u() + PL, 2 * PL);
@@ -1250,7 +1247,7 @@ inline void rgsw_mul(const Ksk &k0, const Ksk &k1, const u64 *ct, u64 *out, size
     if (!batch) return;
     const u64 PL = (u64)cc.L * cc.n;
     WsGuard pb(batch * 2 * PL * sizeof(u64), s), t(batch * 2 * PL * sizeof(u64), s);
-    launch_ntt(cc, true, ct, pb.u(), full_map(cc, cc.L), batch * 2, k::PRO_NONE, s);   // ct0, ct1 -> PowerBasis
+    launch_ntt(cc, true, ct, pb.u(), full_map(cc, cc.L), batch * 2, s);   // ct0, ct1 -> PowerBasis
     // (c0, c1) = ksk0.key_switch(ct0);  out = (c0, c1) + ksk1.key_switch(ct1)
     key_switch_polys(k0, pb.u(), 2 * PL, t.u(), t.u() + PL, 2 * PL, nullptr, nullptr, 0, batch, s, ct, 2 * PL);
     key_switch_polys(k1, pb.u() + PL, 2 * PL, out, out + PL, 2 * PL, t.u(), t.u() + PL, 2 * PL, batch, s, ct + PL,
@@ -1292,7 +1289,7 @@ inline void decrypt(const Scaler &sc, u64 t, const u64 *s_ntt, const u64 *ct, si
     WsGuard ph(batch * PL * sizeof(u64), s, true), d(batch * pc.L * cc.n * sizeof(u64), s, true);
     FHE_LAUNCH("phase", k::phase_kernel, dim3(blocks_for(PL, EW_THREADS), (unsigned)batch), dim3(EW_THREADS), 0, s, ct,
                s_ntt, ph.u(), cc.dmods(), (uint32_t)nparts, (uint32_t)cc.logn, PL);
-    launch_ntt(cc, true, ph.u(), ph.u(), full_map(cc, cc.L), batch, k::PRO_NONE, s);
+    launch_ntt(cc, true, ph.u(), ph.u(), full_map(cc, cc.L), batch, s);
     scale_polys(sc, ph.u(), d.u(), batch, false, s);
     DevMod q0, tmd;
     static_assert(sizeof(DevMod) == sizeof(ModConsts), "DevMod layout");
@@ -1330,7 +1327,7 @@ inline void expand(const Ksk *const *gks, size_t nlevels, const u64 *ct, u64 *ou
     FHE_HIP_CHECK(hipMemsetAsync(mono.u(), 0, level * PL * sizeof(u64), s));
     FHE_LAUNCH("monomial", k::monomial_kernel, dim3(blocks_for(level * cc.L, 64)), dim3(64), 0, s, mono.u(), cc.dmods(),
                (uint32_t)level, (uint32_t)cc.L, (uint32_t)cc.logn);
-    launch_ntt(cc, false, mono.u(), mono.u(), full_map(cc, cc.L), level, k::PRO_NONE, s);
+    launch_ntt(cc, false, mono.u(), mono.u(), full_map(cc, cc.L), level, s);
     for (size_t l = 0; l < level; l++) {
         const size_t step = (size_t)1 << l, cnt = step * batch;
         const size_t nhigh = std::min(step, size - step) * batch;
@@ -1588,7 +1585,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
                            (uint32_t)L, (uint32_t)e.logn, (u64)nb, 0u);
             }
         }
-        if (!fused_tensor) launch_ntt(e, true, ten.u(), ten.u(), full_map(e, K), nb * 3, k::PRO_NONE, s);
+        if (!fused_tensor) launch_ntt(e, true, ten.u(), ten.u(), full_map(e, K), nb * 3, s);
         u64 *dst = m.mod_switch ? pre.u() : out + b0 * parts * PL;
         // DOWN-SCALE (mul.rs:204-206) to PowerBasis rows of d [3][nb][L][N]
         launch_scale(*m.down, ten.u(), PK, d.u(), PL, nb * 3, s);
@@ -1597,12 +1594,12 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
             // transforms c2 forward and, at mul.rs:212, back again; iNTT(NTT(x)) = x exactly).
             // (Transforming c2 as well and handing it to the key switch as `xhat` was measured at C2: the key
             // switch gains 1.0 ms per 10 steps, the larger forward launch costs 1.6: profiles/r02_mul_xhat_ab.txt.)
-            launch_ntt(b, false, d.u(), d.u(), full_map(b, L), nb * 2, k::PRO_NONE, s);
+            launch_ntt(b, false, d.u(), d.u(), full_map(b, L), nb * 2, s);
             // RELINEARIZE (mul.rs:211-227): (c0, c1) += key_switch(c2), written to the output layout
             key_switch_add(*m.rk, d.u() + 2 * nb * PL, PL, d.u(), d.u() + nb * PL, PL, dst, dst + PL, 2 * PL, nb, s);
         } else {
             // no relinearisation: three Ntt parts, slot-major scratch -> [b][3][L][N]
-            launch_ntt(b, false, d.u(), d.u(), full_map(b, L), nb * 3, k::PRO_NONE, s);
+            launch_ntt(b, false, d.u(), d.u(), full_map(b, L), nb * 3, s);
             for (size_t slot = 0; slot < 3; slot++) {
                 const u64 total = (u64)nb * PL;
                 FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0,

@@ -910,7 +910,7 @@ static void relinearize_run(const Ksk &ks, const u64 *ct3, u64 *out, size_t batc
     k::RowMap m = full_map(cc, cc.L);
     m.src_poly_stride = 3 * PL;
     m.dst_poly_stride = PL;
-    launch_ntt(cc, true, ct3 + 2 * PL, c2.u(), m, batch, k::PRO_NONE, s);
+    launch_ntt(cc, true, ct3 + 2 * PL, c2.u(), m, batch, s);
     // (c2 in Ntt form doubles as the transforms of digit j under key modulus j)
     key_switch_add(ks, c2.u(), PL, ct3, ct3 + PL, 3 * PL, out, out + PL, 2 * PL, batch, s, ct3 + 2 * PL, 3 * PL);
 }

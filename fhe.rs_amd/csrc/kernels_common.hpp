@@ -33,7 +33,6 @@ struct RowMap {
     u64 src_poly_stride, dst_poly_stride;  // in u64 elements
 };
 
-enum { PRO_NONE = 0, PRO_REDUCE = 1 };
 
 // LDS padding: one extra u64 every 16 keeps the 16-element-strided accesses of the last
 // radix pass (lane stride 128 B) on distinct banks (ds_read_b64: 64 banks x 4 B, conflicts

@@ -19,7 +19,7 @@ namespace k {
 template <bool INVERSE, int LOGM, bool NARROW = false>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     ntt_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map, const DevMod *__restrict__ mods,
-               const u64x2 *__restrict__ tw, const u64x2 *__restrict__ ninv, uint32_t logn, uint32_t prologue) {
+               const u64x2 *__restrict__ tw, const u64x2 *__restrict__ ninv, uint32_t logn) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ntt_threads_c(LOGM);
     constexpr int M = 1 << LOGM;
@@ -42,11 +42,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
 
     if constexpr (!INVERSE) {
         // the first pass reads its groups straight from global memory (no tile staging)
-        const bool red = prologue == PRO_REDUCE;
-        ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? 1 : 0)>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) {
-            const u64 v = src[i];
-            return red ? reduce_u64(v, md) : v;
-        });
+        ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? 1 : 0)>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) { return src[i]; });
         if constexpr (NARROW) {  // < 16p -> canonical
             const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
             lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) {
@@ -61,10 +57,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         const bool whole = logn == LOGM;  // ninv[2*mi] = {N^-1, shoup}, ninv[2*mi+1] = {z_last * N^-1, shoup}
         // (feeding the first pass straight from global memory, as the forward transform does, was
         // measured for the inverse: no gain -- its groups are runs of consecutive coefficients)
-        if (prologue == PRO_REDUCE)
-            tile_to_lds<CH, M, T>(lds, src, tid, [&](u64 v) { return reduce_u64(v, md); });
-        else
-            tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
+        tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
         FHE_BARRIER();
         ntt_inv_lds<LOGM, T, 0, 0, NARROW>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1], tw0);
         if (whole)
@@ -222,7 +215,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
 template <bool INVERSE, int G0>
 __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map,
                                   const DevMod *__restrict__ mods, const u64x2 *__restrict__ tw,
-                                  const u64x2 *__restrict__ ninv, uint32_t logn, uint32_t prologue) {
+                                  const u64x2 *__restrict__ ninv, uint32_t logn) {
     constexpr uint32_t R = 1u << G0;
     const uint32_t n = 1u << logn, logm = logn - G0, m = 1u << logm;
     const uint32_t chunks = (m + blockDim.x - 1) / blockDim.x;
@@ -242,10 +235,6 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
     u64 x[R];
 #pragma unroll
     for (uint32_t e = 0; e < R; e++) x[e] = src[lo + e * m];
-    if (prologue == PRO_REDUCE) {
-#pragma unroll
-        for (uint32_t e = 0; e < R; e++) x[e] = reduce_u64(x[e], md);
-    }
     if (!INVERSE) {
 #pragma unroll
         for (int u = 0; u < G0; u++) {

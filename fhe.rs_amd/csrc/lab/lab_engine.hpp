@@ -9,7 +9,7 @@
 namespace fhe {
 
 inline bool lab_try_ntt_fwd(const Ctx &c, unsigned rows_total, bool narrow, const u64 *in, u64 *out, const k::RowMap &map,
-                            uint32_t prologue, hipStream_t s) {
+                            hipStream_t s) {
     if (c.logn != 13) return false;
     static const bool swap_variant = FHE_LAB_INT("NTT_SWAP", 0) != 0;
     static const int cpt8 = FHE_LAB_INT("NTT_CPT8", 0);
@@ -18,11 +18,11 @@ inline bool lab_try_ntt_fwd(const Ctx &c, unsigned rows_total, bool narrow, cons
         if (narrow) {
             allow_big_lds((k::ntt_fwd_swap_kernel<true>), lds);
             FHE_LAUNCH("ntt_fwd", (k::ntt_fwd_swap_kernel<true>), dim3(rows_total), dim3(512), lds, s, in, out, map,
-                       c.dmods(), c.dtw(), prologue);
+                       c.dmods(), c.dtw());
         } else {
             allow_big_lds((k::ntt_fwd_swap_kernel<false>), lds);
             FHE_LAUNCH("ntt_fwd", (k::ntt_fwd_swap_kernel<false>), dim3(rows_total), dim3(512), lds, s, in, out, map,
-                       c.dmods(), c.dtw(), prologue);
+                       c.dmods(), c.dtw());
         }
         return true;
     }
@@ -31,7 +31,7 @@ inline bool lab_try_ntt_fwd(const Ctx &c, unsigned rows_total, bool narrow, cons
     do {                                                                                                           \
         allow_big_lds((k::ntt_fwd8_kernel<NW, GMV>), lds);                                                         \
         FHE_LAUNCH("ntt_fwd", (k::ntt_fwd8_kernel<NW, GMV>), dim3(rows_total), dim3(1024), lds, s, in, out, map,   \
-                   c.dmods(), c.dtw(), prologue);                                                                  \
+                   c.dmods(), c.dtw());                                                                  \
     } while (0)
         if (cpt8 == 3) {
             if (narrow) FHE_NTT8(true, 3); else FHE_NTT8(false, 3);

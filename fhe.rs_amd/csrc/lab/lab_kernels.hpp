@@ -13,7 +13,7 @@
 template <bool NARROW, int GM>
 __global__ void __launch_bounds__(1024, 8)
     ntt_fwd8_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map, const DevMod *__restrict__ mods,
-                    const u64x2 *__restrict__ tw, uint32_t prologue) {
+                    const u64x2 *__restrict__ tw) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int LOGM = 13, T = 1024, M = 1 << LOGM;
     constexpr int CH = tile_chunks_c(LOGM, T);
@@ -28,11 +28,7 @@ __global__ void __launch_bounds__(1024, 8)
                      (u64)(map.src_row_fixed >= 0 ? (uint32_t)map.src_row_fixed : r) * M;
     u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * M;
     const u64x2 *twr = tw + (u64)mi * M;
-    const bool red = prologue == PRO_REDUCE;
-    ntt_fwd_lds<LOGM, T, GM, false, true, (NARROW ? 1 : 0)>(lds, twr, 1, pm, tid, [&](uint32_t i, uint32_t) {
-        const u64 v = src[i];
-        return red ? reduce_u64(v, md) : v;
-    });
+    ntt_fwd_lds<LOGM, T, GM, false, true, (NARROW ? 1 : 0)>(lds, twr, 1, pm, tid, [&](uint32_t i, uint32_t) { return src[i]; });
     if constexpr (NARROW) {
         const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
         lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) {
@@ -89,7 +85,7 @@ __device__ __forceinline__ void lane_swap64(u64 &a, u64 &b, uint32_t tid, int bi
 template <bool NARROW>
 __global__ void __launch_bounds__(512, 4)
     ntt_fwd_swap_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map, const DevMod *__restrict__ mods,
-                        const u64x2 *__restrict__ tw, uint32_t prologue) {
+                        const u64x2 *__restrict__ tw) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int LOGM = 13, T = 512, M = 1 << LOGM, CH = tile_chunks_c(LOGM, T);
     constexpr int NB = NARROW ? 1 : 0;
@@ -112,12 +108,8 @@ __global__ void __launch_bounds__(512, 4)
     };
     // ---- pass 1: stages 0-2 from global memory (two groups of 8 per thread)
     {
-        const bool red = prologue == PRO_REDUCE;
-        FwdTw<3, LOGM, 0, T> none;
-        fwd_pass<3, LOGM, 0, T, true, NB>(lds, twr, 1, pm, tid, none, [&](uint32_t i, uint32_t) {
-            const u64 v = src[i];
-            return red ? reduce_u64(v, md) : v;
-        });
+            FwdTw<3, LOGM, 0, T> none;
+        fwd_pass<3, LOGM, 0, T, true, NB>(lds, twr, 1, pm, tid, none, [&](uint32_t i, uint32_t) { return src[i]; });
     }
     const uint32_t w = wave_uniform(tid >> 6), lane = tid & 63, l5 = lane >> 5, l4 = (lane >> 4) & 1;
     // per-lane twiddles of the two exchange stages, requested before the barrier

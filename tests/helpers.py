@@ -17,6 +17,9 @@ HIP_LIB = os.path.join(ROOT, "fhe.rs_amd", "libfhe_hip.so")
 
 
 def build_emu():
+    # tools/sanitize_emu.sh points this at an -fsanitize build of the same sources
+    if os.environ.get("FHE_EMU_LIB"):
+        return os.environ["FHE_EMU_LIB"]
     srcs = [os.path.join(ROOT, "fhe.rs_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "fhe.rs_amd", "csrc"))]
     srcs += [os.path.join(ROOT, "tests", "emu", "emu_rt.hpp"), os.path.join(ROOT, "include", "fhe_hip.h")]
     if (not os.path.exists(EMU_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs):

@@ -199,16 +199,16 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), 4)
                     q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
                 }
                 const u64 vx = lds[padi(2 * ci)], vy = lds[padi(2 * ci + 1)];  // < 4p: Shoup accepts any u64
-                acc0[2 * c] = csub_n(acc0[2 * c] + mul_shoup_lazy_n(vx, q0.x, q0s.x, pm.np), p2, pm.np2);
-                acc0[2 * c + 1] = csub_n(acc0[2 * c + 1] + mul_shoup_lazy_n(vy, q0.y, q0s.y, pm.np), p2, pm.np2);
+                acc0[2 * c] = csub_n(mul_shoup_lazy_add_n(acc0[2 * c], vx, q0.x, q0s.x, pm.np), p2, pm.np2);
+                acc0[2 * c + 1] = csub_n(mul_shoup_lazy_add_n(acc0[2 * c + 1], vy, q0.y, q0s.y, pm.np), p2, pm.np2);
                 if constexpr (ACC1_LDS) {
                     u64x2 a = acc1_lds[ci];
-                    a.x = csub_n(a.x + mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np), p2, pm.np2);
-                    a.y = csub_n(a.y + mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np), p2, pm.np2);
+                    a.x = csub_n(mul_shoup_lazy_add_n(a.x, vx, q1.x, q1s.x, pm.np), p2, pm.np2);
+                    a.y = csub_n(mul_shoup_lazy_add_n(a.y, vy, q1.y, q1s.y, pm.np), p2, pm.np2);
                     acc1_lds[ci] = a;
                 } else {
-                    acc1[2 * c] = csub_n(acc1[2 * c] + mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np), p2, pm.np2);
-                    acc1[2 * c + 1] = csub_n(acc1[2 * c + 1] + mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np), p2, pm.np2);
+                    acc1[2 * c] = csub_n(mul_shoup_lazy_add_n(acc1[2 * c], vx, q1.x, q1s.x, pm.np), p2, pm.np2);
+                    acc1[2 * c + 1] = csub_n(mul_shoup_lazy_add_n(acc1[2 * c + 1], vy, q1.y, q1s.y, pm.np), p2, pm.np2);
                 }
                 if (c & 1) sched_fence();  // at most two chunks of key loads (32 VGPRs) in flight
             }
@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), 4)
             ntt_fwd_lds<LOGN, T, GM, false, true, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
             if (tid < N) {
             const u64 v = lds[padi(tid)];
-            acc0[0] = csub_n(acc0[0] + mul_shoup_lazy_n(v, k0[koff + tid], k0s[koff + tid], pm.np), p2, pm.np2);
-            acc1[0] = csub_n(acc1[0] + mul_shoup_lazy_n(v, k1[koff + tid], k1s[koff + tid], pm.np), p2, pm.np2);
+            acc0[0] = csub_n(mul_shoup_lazy_add_n(acc0[0], v, k0[koff + tid], k0s[koff + tid], pm.np), p2, pm.np2);
+            acc1[0] = csub_n(mul_shoup_lazy_add_n(acc1[0], v, k1[koff + tid], k1s[koff + tid], pm.np), p2, pm.np2);
             }
         }
         // (wave-contiguous chunk ownership, which makes this barrier and the one before the MAC wave-local as
@@ -385,11 +385,11 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
             const uint32_t ci = c * T + tid;
             const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
             const u64 vx = lds[padi(2 * ci)], vy = lds[padi(2 * ci + 1)];
-            acc0[2 * c] = csub_n(acc0[2 * c] + mul_shoup_lazy_n(vx, q0.x, q0s.x, pm.np), p2, pm.np2);
-            acc0[2 * c + 1] = csub_n(acc0[2 * c + 1] + mul_shoup_lazy_n(vy, q0.y, q0s.y, pm.np), p2, pm.np2);
+            acc0[2 * c] = csub_n(mul_shoup_lazy_add_n(acc0[2 * c], vx, q0.x, q0s.x, pm.np), p2, pm.np2);
+            acc0[2 * c + 1] = csub_n(mul_shoup_lazy_add_n(acc0[2 * c + 1], vy, q0.y, q0s.y, pm.np), p2, pm.np2);
             u64x2 a = acc1_lds[ci];
-            a.x = csub_n(a.x + mul_shoup_lazy_n(vx, q1.x, q1s.x, pm.np), p2, pm.np2);
-            a.y = csub_n(a.y + mul_shoup_lazy_n(vy, q1.y, q1s.y, pm.np), p2, pm.np2);
+            a.x = csub_n(mul_shoup_lazy_add_n(a.x, vx, q1.x, q1s.x, pm.np), p2, pm.np2);
+            a.y = csub_n(mul_shoup_lazy_add_n(a.y, vy, q1.y, q1s.y, pm.np), p2, pm.np2);
             acc1_lds[ci] = a;
             if (c & 1) sched_fence();
         }

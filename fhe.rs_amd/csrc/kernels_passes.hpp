@@ -359,7 +359,7 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
                         } else {
                             x[a] = y + t;
 #if FHE_APPROX_SHOUP
-                            x[b] = diff * zv.x + mulhi64_approx<UNIFORM>(diff, zv.y) * pm.np;   // below 3p
+                            x[b] = shoup_lo<UNIFORM, false>(0, diff, zv.x, mulhi64_approx<UNIFORM>(diff, zv.y), pm.np);   // below 3p
 #else
                             x[b] = mul_shoup_lazy_n<UNIFORM>(diff, zv.x, zv.y, pm.np);
 #endif

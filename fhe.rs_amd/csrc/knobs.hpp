@@ -9,7 +9,7 @@
 #pragma once
 
 #if !defined(FHE_LAB)
-#if defined(FHE_SENS) || defined(FHE_MAD_CARRY) || defined(FHE_APPROX_SHOUP) || defined(FHE_KS_LATE) ||             \
+#if defined(FHE_SENS) || defined(FHE_MAD_CARRY) || defined(FHE_MAD_CROSS) || defined(FHE_APPROX_SHOUP) || defined(FHE_KS_LATE) ||             \
     defined(FHE_KS_TWPF) || defined(FHE_KS_PERSIST14) || defined(FHE_KS_KPF_CHUNKS) || defined(FHE_TENSOR_TW_EARLY) ||  \
     defined(FHE_KS_EXPERIMENTS) || defined(FHE_PHASE_TIMING) || defined(FHE_LDS_PAD) || defined(FHE_NO_WAVE_SYNC) || \
     defined(FHE_DIAG_NO_SGPR_ASM) || defined(FHE_KS_HALF13) || defined(FHE_KS_SPLIT_XCD)
@@ -23,6 +23,14 @@
 // High products through v_mad_u64_u32's carry-out (zq_dev.hpp); 0: the compiler's generic expansion.
 #ifndef FHE_MAD_CARRY
 #define FHE_MAD_CARRY 1
+#endif
+// Low word of the lazy Shoup products: the four 32-bit cross products summed by v_mad_u64_u32 used as a 32-bit
+// multiply-add (zq_dev.hpp shoup_lo).  Round 3: 4.3-4.7 % fewer VALU instructions in the forward transform, 2-3 % in
+// the inverse / tensor kernels -- and no change in kernel time (profiles/r03_shoup_lo_ab.txt): per
+// profiles/r03_ubench_issue.jsonl a v_mad_u64_u32 occupies a SIMD for 5.2 cycles against 4.4 for v_mul_lo_u32 and 4.7
+// for v_add3_u32, so 4 + 1 of the former cost what 4 + 2 of the latter do; at N = 16384 the key switch spills (C3 -2.5 %).
+#ifndef FHE_MAD_CROSS
+#define FHE_MAD_CROSS 0
 #endif
 // Narrow (< 2^60) butterflies take the Shoup quotient from three partial products (zq_dev.hpp).
 #ifndef FHE_APPROX_SHOUP

@@ -84,6 +84,45 @@ __device__ __forceinline__ u64 mulhi64_approx_c(u64 a, u64 b) {
 #define FHE_HAVE_MAD_CARRY 0
 #endif
 
+// add + a*b + q*np (mod 2^64): the low word of a lazy Shoup product, with an optional addend.
+// FHE_MAD_CROSS: the four 32-bit cross products (a0*b1, a1*b0, q0*np1, q1*np0: only their low words count) are
+// summed by a chain of v_mad_u64_u32 used as a 32-bit multiply-add (the upper half of its result is junk), and
+// their sum joins the upper word with one add -- 6 multiply-adds + 1 add against the compiler's 2 multiply-adds,
+// 4 v_mul_lo_u32 and 2 v_add3_u32.  SU: b is wave-uniform (np always is).
+template <bool SU = false, bool ADD = true>
+FHE_HD u64 shoup_lo(u64 add, u64 a, u64 b, u64 q, u64 np) {
+#if defined(__HIP_DEVICE_COMPILE__) && FHE_MAD_CROSS
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32), n0 = (uint32_t)np, n1 = (uint32_t)(np >> 32);
+    u64 t, r, sd;
+    constexpr bool no_add = !ADD;   // (no addend: the inline constant 0, not a register pair holding it)
+    if constexpr (SU) {
+        asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(t), "=s"(sd) : "v"(a0), "s"(b1));
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t), "=s"(sd) : "v"(a1), "s"(b0), "v"(t));
+        if constexpr (no_add)
+            asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(sd) : "v"(a0), "s"(b0));
+        else
+            asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sd) : "v"(a0), "s"(b0), "v"(add));
+    } else {
+        asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(t), "=s"(sd) : "v"(a0), "v"(b1));
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t), "=s"(sd) : "v"(a1), "v"(b0), "v"(t));
+        if constexpr (no_add)
+            asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(sd) : "v"(a0), "v"(b0));
+        else
+            asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sd) : "v"(a0), "v"(b0), "v"(add));
+    }
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t), "=s"(sd) : "v"(q0), "s"(n1), "v"(t));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t), "=s"(sd) : "v"(q1), "s"(n0), "v"(t));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sd) : "v"(q0), "s"(n0), "v"(r));
+    // (written as a 64-bit add the compiler builds the pair {0, t.lo} with two moves and adds it with v_lshl_add_u64)
+    uint32_t rh;
+    asm("v_add_u32 %0, %1, %2" : "=v"(rh) : "v"((uint32_t)(r >> 32)), "v"((uint32_t)t));
+    return ((u64)rh << 32) | (uint32_t)r;
+#else
+    return (ADD ? add : 0) + a * b + q * np;
+#endif
+}
+
 FHE_HD u64 mulhi64(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__) && FHE_MAD_CARRY
     return mulhi64_c<false>(a, b);
@@ -221,7 +260,12 @@ FHE_HD u64 mulhi64_t(u64 a, u64 b) {
 }
 template <bool SU = false>
 FHE_HD u64 mul_shoup_lazy_n(u64 a, u64 b, u64 bs, u64 np) {
-    return a * b + mulhi64_t<SU>(a, bs) * np;
+    return shoup_lo<SU, false>(0, a, b, mulhi64_t<SU>(a, bs), np);
+}
+// add + a*b mod p, lazily: the addend enters the product chain (below add + 2p)
+template <bool SU = false>
+FHE_HD u64 mul_shoup_lazy_add_n(u64 add, u64 a, u64 b, u64 bs, u64 np) {
+    return shoup_lo<SU, true>(add, a, b, mulhi64_t<SU>(a, bs), np);
 }
 FHE_HD u64 add_mod_n(u64 a, u64 b, const PM &m) { return csub_n(a + b, m.p, m.np); }
 
@@ -231,7 +275,7 @@ FHE_HD void fwd_butterfly(u64 &x, u64 &y, u64 w, u64 ws, const PM &m) {
     x = csub_n(x, m.p2, m.np2);
     // x + t with x as the addend of the product chain (v_mad_u64_u32 adds a 64-bit value for free), and
     // x + 2p - t = (2x + 2p) - (x + t): one 64-bit operation less than forming t, x + t and x + 2p - t separately
-    const u64 xt = x + y * w + mulhi64_t<SU>(y, ws) * m.np;
+    const u64 xt = shoup_lo<SU>(x, y, w, mulhi64_t<SU>(y, ws), m.np);
     y = ((x << 1) + m.p2) - xt;
     x = xt;
 }
@@ -273,10 +317,10 @@ FHE_HD void fwd_butterfly_narrow(u64 &x, u64 &y, u64 w, u64 ws, const PM &m, boo
     // (x + t formed inside the product chain, x + pk - t as (2x + pk) - (x + t): see fwd_butterfly; 2x may wrap
     // around 2^64, the difference is exact because x + pk - t < 16p < 2^64)
 #if FHE_APPROX_SHOUP
-    const u64 xt = x + y * w + mulhi64_approx<SU>(y, ws) * m.np;   // t below 3p
+    const u64 xt = shoup_lo<SU>(x, y, w, mulhi64_approx<SU>(y, ws), m.np);   // t below 3p
     const u64 pk = m.p2 + m.p;
 #else
-    const u64 xt = x + y * w + mulhi64_t<SU>(y, ws) * m.np;
+    const u64 xt = shoup_lo<SU>(x, y, w, mulhi64_t<SU>(y, ws), m.np);
     const u64 pk = m.p2;
 #endif
 #if defined(FHE_HOST_EMULATION)

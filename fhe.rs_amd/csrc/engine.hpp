@@ -705,7 +705,10 @@ inline void scaler_upload(Scaler &s) {
         return off;
     };
     // device-side derived tables (see scale_kernel): gamma_neg and the 16-entry fold tables
-    std::vector<u64> gneg(c.nto), vtab(c.nto * 16), c64(c.nto * 16), c128(c.nto * 16);
+    // (the kernel takes v's bits from limb 3 of the sum on: theta_garner_shift - 1 in [96, 126]; RnsScaler::new's
+    // choice, scaler.rs:130-142, is 123 ... 127 for moduli below 2^62 and at most 64 of them)
+    require(c.theta_garner_shift >= 97 && c.theta_garner_shift <= 127, E_ARG, "theta_garner_shift out of range");
+    std::vector<u64> gneg(c.nto), vtab(c.nto * 16), wtab(c.nto * 32), c128(c.nto * 16);
     for (size_t j = 0; j < c.nto; j++) {
         const u64 q = s.to->moduli[j];
         gneg[j] = (q - c.gamma[j] % q) % q;
@@ -714,7 +717,9 @@ inline void scaler_upload(Scaler &s) {
         const u64 g64 = mulmod(two64, gneg[j], q);
         for (u64 k = 0; k < 16; k++) {
             vtab[j * 16 + k] = mulmod(k % q, g64, q);
-            c64[j * 16 + k] = mulmod(k % q, two64, q);
+            // +w = w_hi 2^64 + w_lo: w_hi 2^64 mod q;  -w = ~w_lo + (1 - (w_hi + 1) 2^64): that constant mod q
+            wtab[j * 32 + k] = mulmod(k % q, two64, q);
+            wtab[j * 32 + 16 + k] = (q + 1 % q - mulmod((k + 1) % q, two64, q)) % q;
             c128[j * 16 + k] = mulmod(k % q, two128, q);
         }
     }
@@ -766,7 +771,7 @@ inline void scaler_upload(Scaler &s) {
     }
     wk = wk % BigUint::pow2(256);
     size_t o_fold = push(fold);
-    size_t o_gn = push(gneg), o_om = push(omega_p), o_vt = push(vtab), o_c64 = push(c64), o_c128 = push(c128);
+    size_t o_gn = push(gneg), o_om = push(omega_p), o_vt = push(vtab), o_wt = push(wtab), o_c128 = push(c128);
     size_t o_tol = push(padded(c.theta_omega_lo)), o_toh = push(padded(c.theta_omega_hi)), o_tos = push(padded(sign64));
     size_t o_tgl = push(padded(c.theta_garner_lo)), o_tgh = push(padded(c.theta_garner_hi));
     size_t o_tom = push(padded(mask64));
@@ -775,7 +780,7 @@ inline void scaler_upload(Scaler &s) {
     s.dev.gamma_neg = b + o_gn;
     s.dev.omega = b + o_om;
     s.dev.vhi_tab = b + o_vt;
-    s.dev.c64_tab = b + o_c64;
+    s.dev.w_tab = b + o_wt;
     s.dev.c128_tab = b + o_c128;
     s.dev.theta_omega_lo = b + o_tol;
     s.dev.theta_omega_hi = b + o_toh;
@@ -847,9 +852,15 @@ inline void launch_scale(const Scaler &sc, const u64 *in, u64 in_stride, u64 *ou
     const dim3 grid(blocks_for(total, EW_THREADS)), block(EW_THREADS);
     // profiler label: basis extension (more output rows than input) vs down-scaling
     const char *label = t.L > f.L ? "scale_extend" : "scale_down";
+    // PLAIN instances carry no w / v_hi code: factor-one scalers whose v fits one word (every basis extension of BFV)
+    const bool plain = sc.dev.is_one && sc.dev.v_fits_64;
 #define FHE_SCALE_CASE(NF)                                                                                   \
-    FHE_LAUNCH(label, (k::scale_kernel<NF>), grid, block, 0, s, in, out, in_stride, out_stride, sc.dev,      \
-               t.dmods(), (uint32_t)f.logn, total)
+    if (plain)                                                                                               \
+        FHE_LAUNCH(label, (k::scale_kernel<NF, true>), grid, block, 0, s, in, out, in_stride, out_stride,    \
+                   sc.dev, t.dmods(), (uint32_t)f.logn, total);                                              \
+    else                                                                                                     \
+        FHE_LAUNCH(label, (k::scale_kernel<NF, false>), grid, block, 0, s, in, out, in_stride, out_stride,   \
+                   sc.dev, t.dmods(), (uint32_t)f.logn, total)
     switch (scale_kernel_nf(f.L)) {   // (the same NF scaler_upload padded the tables to)
         case 4: FHE_SCALE_CASE(4); break;
         case 9: FHE_SCALE_CASE(9); break;

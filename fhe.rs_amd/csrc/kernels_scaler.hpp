@@ -10,7 +10,7 @@ struct ScalerDev {
     const u64 *gamma_neg;                                // [nto]      (q - gamma) mod q
     const u64 *omega;                                    // [nto][nfrom]
     const u64 *vhi_tab;                                  // [nto][16]  k * 2^64 * gamma_neg mod q
-    const u64 *c64_tab;                                  // [nto][16]  k * 2^64  mod q
+    const u64 *w_tab;                                    // [nto][32]  +w: k * 2^64 mod q;  -w: (1 - (k + 1) 2^64) mod q at 16 + k
     const u64 *c128_tab;                                 // [nto][16]  k * 2^128 mod q
     const u64 *theta_omega_lo, *theta_omega_hi;          // [nfrom]
     const u64 *theta_omega_sign;                         // [nfrom] (0/1)
@@ -38,22 +38,53 @@ struct Acc3x64 {
 };
 // x: per-lane value; y: WAVE-UNIFORM constant (scaler tables): its halves are SGPR operands of the multiplies
 // (one constant-bus read per instruction), which saves the two copies into VGPRs a "v" constraint costs per term.
+// C2_CARRY = false: the caller guarantees that the sum of the upper partial products xh * yh cannot leave 64 bits
+// (scale_kernel: one term below 2^62 and at most 11 below 2^60), so the third column keeps no overflow counter.
+// FIRST: the accumulator is zero (first term of a sum): only the second cross product can carry.
+template <bool C2_CARRY = true, bool FIRST = false>
 FHE_HD void mac3x64(Acc3x64 &a, u64 x, u64 y) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
     u64 s0, s1, s2;  // carry-outs (SGPR pairs)
-    asm("v_mad_u64_u32 %[c0], %[s0], %[xl], %[yl], %[c0]\n\t"
-        "v_mad_u64_u32 %[c1], %[s1], %[xl], %[yh], %[c1]\n\t"
-        "v_mad_u64_u32 %[c2], %[s2], %[xh], %[yh], %[c2]\n\t"
-        "v_addc_co_u32 %[o0], vcc, 0, %[o0], %[s0]\n\t"
-        "v_mad_u64_u32 %[c1], %[s0], %[xh], %[yl], %[c1]\n\t"
-        "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[s1]\n\t"
-        "v_addc_co_u32 %[o2], vcc, 0, %[o2], %[s2]\n\t"
-        "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[s0]"
-        : [c0] "+v"(a.c0), [c1] "+v"(a.c1), [c2] "+v"(a.c2), [o0] "+v"(a.o0), [o1] "+v"(a.o1), [o2] "+v"(a.o2),
-          [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
-        : [xl] "v"(xl), [xh] "v"(xh), [yl] "s"(yl), [yh] "s"(yh)   // y: the wave-uniform constant, straight from SGPRs
-        : "vcc");
+    if constexpr (FIRST) {
+        asm("v_mad_u64_u32 %[c1], %[s1], %[xl], %[yh], 0\n\t"
+            "v_mad_u64_u32 %[c0], %[s0], %[xl], %[yl], 0\n\t"
+            "v_mad_u64_u32 %[c2], %[s2], %[xh], %[yh], 0\n\t"
+            "v_mad_u64_u32 %[c1], %[s0], %[xh], %[yl], %[c1]\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32 %[o1], vcc, 0, 0, %[s0]"
+            : [c0] "=&v"(a.c0), [c1] "=&v"(a.c1), [c2] "=&v"(a.c2), [o1] "=&v"(a.o1),
+              [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
+            : [xl] "v"(xl), [xh] "v"(xh), [yl] "s"(yl), [yh] "s"(yh)
+            : "vcc");
+        a.o0 = 0, a.o2 = 0;
+    } else if constexpr (C2_CARRY) {
+        asm("v_mad_u64_u32 %[c0], %[s0], %[xl], %[yl], %[c0]\n\t"
+            "v_mad_u64_u32 %[c1], %[s1], %[xl], %[yh], %[c1]\n\t"
+            "v_mad_u64_u32 %[c2], %[s2], %[xh], %[yh], %[c2]\n\t"
+            "v_addc_co_u32 %[o0], vcc, 0, %[o0], %[s0]\n\t"
+            "v_mad_u64_u32 %[c1], %[s0], %[xh], %[yl], %[c1]\n\t"
+            "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[s1]\n\t"
+            "v_addc_co_u32 %[o2], vcc, 0, %[o2], %[s2]\n\t"
+            "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[s0]"
+            : [c0] "+v"(a.c0), [c1] "+v"(a.c1), [c2] "+v"(a.c2), [o0] "+v"(a.o0), [o1] "+v"(a.o1), [o2] "+v"(a.o2),
+              [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
+            : [xl] "v"(xl), [xh] "v"(xh), [yl] "s"(yl), [yh] "s"(yh)   // y: the wave-uniform constant, straight from SGPRs
+            : "vcc");
+    } else {
+        asm("v_mad_u64_u32 %[c0], %[s0], %[xl], %[yl], %[c0]\n\t"
+            "v_mad_u64_u32 %[c1], %[s1], %[xl], %[yh], %[c1]\n\t"
+            "v_mad_u64_u32 %[c2], %[s2], %[xh], %[yh], %[c2]\n\t"
+            "v_addc_co_u32 %[o0], vcc, 0, %[o0], %[s0]\n\t"
+            "v_mad_u64_u32 %[c1], %[s0], %[xh], %[yl], %[c1]\n\t"
+            "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[s1]\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32 %[o1], vcc, 0, %[o1], %[s0]"
+            : [c0] "+v"(a.c0), [c1] "+v"(a.c1), [c2] "+v"(a.c2), [o0] "+v"(a.o0), [o1] "+v"(a.o1),
+              [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)
+            : [xl] "v"(xl), [xh] "v"(xh), [yl] "s"(yl), [yh] "s"(yh)
+            : "vcc");
+    }
 #else  // host pass / host emulation: the same columns in plain C
     const u64 xl = (uint32_t)x, xh = x >> 32, yl = (uint32_t)y, yh = y >> 32;
     const u64 pr[4] = {xl * yl, xl * yh, xh * yh, xh * yl};
@@ -61,19 +92,12 @@ FHE_HD void mac3x64(Acc3x64 &a, u64 x, u64 y) {
     uint32_t *const os[4] = {&a.o0, &a.o1, &a.o2, &a.o1};
     for (int k = 0; k < 4; k++) {
         const u64 t = *cs[k] + pr[k];
+        if (!C2_CARRY && k == 2 && t < *cs[k]) __builtin_trap();   // the caller's bound on the third column is wrong
         *os[k] += t < *cs[k];
         *cs[k] = t;
     }
 #endif
 }
-// value = (c0 + o0 2^64) + (c1 + o1 2^64) 2^32 + (c2 + o2 2^64) 2^64  ->  low 128 bits and the rest
-FHE_HD void acc3x64_resolve(const Acc3x64 &a, u64 extra, u128_t &low, u64 &top) {
-    const u128_t l = (u128_t)a.c0 + ((u128_t)a.c1 << 32) + extra;                     // < 2^98
-    const u128_t m = (u128_t)a.c2 + a.o0 + ((u128_t)a.o1 << 32) + (l >> 64);         // weight 2^64, < 2^67
-    low = (u128_t)(u64)l | (m << 64);
-    top = (u64)(m >> 64) + a.o2;
-}
-
 // Sum of 64x64-bit products without carry detection: the low and the high 64-bit halves of the
 // products are summed separately (each sum of up to 2^32 terms fits 96 bits, so a plain
 // zero-extending 128-bit add never overflows and the compiler emits one add/addc chain, no
@@ -103,7 +127,12 @@ FHE_HD void acc192_resolve(const Acc192 &acc, u128_t &low, u64 &top) {
 // in: [npolys][nfrom][N] PowerBasis; out: rows [ncommon, nto) of [npolys][nto][N].
 // NF >= nfrom: the column's residues are loaded once, together, into registers (coalesced
 // along N; one batch of loads in flight); all scaler constants are wave-uniform scalar loads.
-template <int NF>
+// PLAIN: a factor-one scaler whose v fits one word (is_one && v_fits_64, every basis extension of the BFV
+// parameter sets): no w, no v_hi -- the instance carries none of that code.
+// Round 3: everything between the multiply-add blocks (column resolves, the 256-bit shifts, rounding, the small
+// addends of the output sums) is written on 32-bit limbs with add-with-carry chains (zq_dev.hpp): the u128 / U256 C
+// of rounds 1-2 compiled to roughly as many instructions as the multiplies themselves.
+template <int NF, bool PLAIN>
 __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs / 8 waves per SIMD measured 3 % faster)
     scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,
                              u64 out_poly_stride, ScalerDev s, const DevMod *__restrict__ to_mods, uint32_t logn,
@@ -126,106 +155,144 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
     // (all per-source tables are zero-padded to NF entries by the host, scaler_upload: the term loops run without
     // per-term bounds checks -- a padded term multiplies a zero residue by a zero constant -- so the constants of
     // a sum are fetched together, one scalar wait per sum instead of one per term)
-    Cols5 vc;
+    // ---- v = ceil((sum_i r_i theta_i >> (shift - 1)) / 2), scaler.rs:260-276.  The sum is below 2^198 (seven limbs);
+    // shift - 1 is in [96, 126] (scaler_upload checks), so the bits wanted start in limb 3; v is below 2^70.
+    u64 vlo;
+    uint32_t vhi;
+    {
+        Cols5 vc;
+        cols5_mac_64x128<true>(vc, rests[0], s.theta_garner_lo[0], s.theta_garner_hi[0]);
 #pragma unroll
-    for (int i = 0; i < NF; i++) cols5_mac_64x128(vc, rests[i], s.theta_garner_lo[i], s.theta_garner_hi[i]);
-    const U256 sum = cols_resolve(cols5_to_cols256(vc));
-    u64 vlo, vhi;
-    u256_shr_lo128(sum, s.shift - 1, vlo, vhi);
-    {  // v = div_ceil(v, 2)
-        const u64 odd = vlo & 1;
-        vlo = (vlo >> 1) | (vhi << 63);
-        vhi >>= 1;
-        vlo += odd;
-        vhi += (vlo < odd);
+        for (int i = 1; i < NF; i++) cols5_mac_64x128(vc, rests[i], s.theta_garner_lo[i], s.theta_garner_hi[i]);
+        uint32_t V[8];
+        cols5_limbs<7>(vc, V);
+        const uint32_t b = (s.shift - 1) & 31;
+        uint32_t x0 = funnel32(V[4], V[3], b), x1 = funnel32(V[5], V[4], b), x2 = funnel32(V[6], V[5], b);
+        ceil_half3(x0, x1, x2);
+        vlo = pack64(x0, x1);
+        vhi = x2;
     }
-    u64 wlo = 0, whi = 0;
-    bool w_sign = false;
-    if (!s.is_one) {
-        // t = sum_i +/- r_i * theta_omega_i  -/+  v * theta_gamma  (mod 2^256, scaler.rs:278-301).  ONE accumulator:
-        // a subtracted term  -x * theta  is written  (~x) * theta - (2^64 - 1) * theta  (mod 2^256), so every term is
-        // an addition of (x ^ mask) * theta with a wave-uniform mask of 0 or ~0, and the constants
-        // (2^64 - 1) * theta of the subtracted terms are one 256-bit constant the host summed (ScalerDev::w_const).
-        // Round 3: the two-accumulator form (added and subtracted terms summed separately) chose its accumulator by a
-        // uniform branch per term, and every merge of the two paths cost a copy of the ten accumulator registers.
-        Cols5 acc5;
+    u64 wx = 0;            // w's low word, complemented when w is subtracted (see the output sums)
+    uint32_t widx = 0;     // index of w's contribution in w_tab: 16 * (w subtracted) + (w >> 64)
+    if constexpr (!PLAIN) {
+        if (!s.is_one) {
+            // t = sum_i +/- r_i * theta_omega_i  -/+  v * theta_gamma  (mod 2^256, scaler.rs:278-301).  ONE accumulator:
+            // a subtracted term  -x * theta  is written  (~x) * theta - (2^64 - 1) * theta  (mod 2^256), so every term
+            // is an addition of (x ^ mask) * theta with a wave-uniform mask of 0 or ~0, and the constants
+            // (2^64 - 1) * theta of the subtracted terms are one 256-bit constant the host summed (ScalerDev::w_const).
+            // (the v * theta_gamma term first -- low word of v here, (high word) << 64 below; subtracted unless
+            // theta_gamma_sign -- so that the accumulator starts from a term that is always there)
+            const u64 gmask = s.theta_gamma_sign ? 0ull : ~0ull;
+            Cols5 acc5;
+            cols5_mac_64x128<true>(acc5, vlo ^ gmask, s.theta_gamma_lo, s.theta_gamma_hi);
 #pragma unroll
-        for (int i = 0; i < NF; i++) {
+            for (int i = 0; i < NF; i++) {
                 // theta_omega_i = 0 whenever the scaled Garner coefficient is an integer -- e.g. every
                 // source modulus outside the denominator when scaling Q*P -> Q by t/Q (5 of C2's 9)
                 const u64 tlo = s.theta_omega_lo[i], thi = s.theta_omega_hi[i];
                 if ((tlo | thi) == 0) continue;
                 cols5_mac_64x128(acc5, rests[i] ^ s.theta_omega_mask[i], tlo, thi);
             }
-        // v * theta_gamma (128 x 128 -> 256 wrapping): low word of v, then (high word) << 64; subtracted unless
-        // theta_gamma_sign
-        const u64 gmask = s.theta_gamma_sign ? 0ull : ~0ull;
-        cols5_mac_64x128(acc5, vlo ^ gmask, s.theta_gamma_lo, s.theta_gamma_hi);
-        Cols256 acc = cols5_to_cols256(acc5);
-        cols_mac_64x128_shl64(acc, vhi ^ gmask, s.theta_gamma_lo, s.theta_gamma_hi);
-        const U256 wk{(u128_t)s.w_const[0] | ((u128_t)s.w_const[1] << 64), (u128_t)s.w_const[2] | ((u128_t)s.w_const[3] << 64)};
-        const U256 t = u256_sub(cols_resolve(acc), wk);
-        w_sign = u256_ge_2_191(t);
-        if (w_sign) {
-            u256_shr_lo128(u256_not(t), 126, wlo, whi);
-            wlo += 1;
-            whi += (wlo == 0);
-            wlo = (wlo >> 1) | (whi << 63);
-            whi >>= 1;
-        } else {
-            u256_shr_lo128(t, 126, wlo, whi);
-            const u64 odd = wlo & 1;
-            wlo = (wlo >> 1) | (whi << 63);
-            whi >>= 1;
-            wlo += odd;
-            whi += (wlo < odd);
+            uint32_t W[8];
+            cols5_limbs<8>(acc5, W);
+            {
+                Cols5 h5;
+                cols5_mac_64x128<true>(h5, (u64)vhi ^ gmask, s.theta_gamma_lo, s.theta_gamma_hi);
+                uint32_t H[8];
+                cols5_limbs<6>(h5, H);     // (<< 64 mod 2^256 keeps 192 bits of it)
+                uint32_t k = 0;
+#pragma unroll
+                for (int i = 2; i < 8; i++) W[i] = addc32(W[i], H[i - 2], k);
+            }
+            {
+                uint32_t k = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    W[i] = subb32(W[i], (i & 1) ? hi32(s.w_const[i >> 1]) : lo32(s.w_const[i >> 1]), k);
+            }
+            // w = ceil(X / 2) with X = (t negative ? ~t : t) >> 126  -- scaler.rs:303-313 writes the negative case as
+            // ((!t >> 126) + 1) >> 1, which is the same rounding; |w| < 2^68, so three limbs of X are enough
+            const uint32_t m = (uint32_t)((int32_t)W[7] >> 31);   // all ones: t is negative, w is subtracted
+            uint32_t x0 = funnel32(W[4] ^ m, W[3] ^ m, 30), x1 = funnel32(W[5] ^ m, W[4] ^ m, 30),
+                     x2 = funnel32(W[6] ^ m, W[5] ^ m, 30);
+            ceil_half3(x0, x1, x2);
+            // -w = -(w_hi 2^64 + w_lo) = ~w_lo + (1 - (w_hi + 1) 2^64): the complemented low word goes into the output
+            // sums as it is, the rest is a per-target table entry (w_tab, 16 + w_hi)
+            wx = pack64(x0 ^ m, x1 ^ m);
+            widx = (m & 16) + (x2 & 15);
         }
     }
-    const uint32_t vh = (uint32_t)vhi & 15, wh = (uint32_t)whi & 15;
+    const uint32_t vh = vhi & 15;
     u64 *o = out + poly * out_poly_stride + col;
+    // third column of the output sums: v_hi32 * gamma_hi < 2^62 and NF products of two upper words below 2^30 each
+    constexpr bool C2C = NF > 11;
     for (uint32_t jt = s.ncommon; jt < s.nto; jt++) {
         const DevMod q = to_mods[jt];
         const u64 *om = s.omega + (u64)jt * NF;   // rows zero-padded to NF
-        Acc3x64 a192;
-        u128_t extra = 0;                                      // small addends of the sum (< 2^66)
-        mac3x64(a192, vlo, s.gamma_neg[jt]);                   // -v_lo * gamma
-        // -v_hi * 2^64 * gamma (< q) through a 16-entry table -- a per-lane load, skipped when the host-side bound
-        // on v (scaler_upload: v <= sum_i (q_i - 1) + 1) says v_hi is always zero
-        u64 small = s.v_fits_64 ? 0 : s.vhi_tab[jt * 16 + vh];
-        if (!s.is_one) {
-            // +/- w = +/- (w_hi * 2^64 + w_lo): the high part through the table, the low word straight
-            // into the 192-bit sum -- as w_lo, or as K - w_lo with K = q * ceil(2^64 / q) = 2^64 + K_lo = 0 (mod q)
-            const u64 c = s.c64_tab[jt * 16 + wh];             // w_hi * 2^64 mod q
-            small += w_sign ? (c ? q.p - c : 0) : c;           // < 2q
-            const u64 k_lo = q.p * (q.brt_hi + 1);             // K mod 2^64 (K >= 2^64 > w_lo)
-            extra = w_sign ? ((((u128_t)1 << 64) | k_lo) - wlo) : (u128_t)wlo;
-        }
+        Acc3x64 a;
+        mac3x64<C2C, true>(a, vlo, s.gamma_neg[jt]);           // -v_lo * gamma
 #pragma unroll
-        for (int i = 0; i < NF; i++) mac3x64(a192, rests[i], om[i]);
-        extra += small;
-        // (extra < 2^66 does not fit the u64 parameter: split it)
-        u128_t acc;
-        u64 top;
-        acc3x64_resolve(a192, (u64)extra, acc, top);
-        {
-            const u128_t hi_extra = (extra >> 64) << 64;       // at most 3 * 2^64
-            const bool c = __builtin_add_overflow(acc, hi_extra, &acc);
-            top += c ? 1 : 0;
+        for (int i = 0; i < NF; i++) mac3x64<C2C>(a, rests[i], om[i]);
+        // S = c0 + c1 2^32 + (c2 + o0) 2^64 + o1 2^96 (+ o2 2^128) + E, E = the small addends (below 2^65):
+        // limbs l0..l3 and `top`
+        uint32_t l0, l1, l2, l3, top;
+        if constexpr (PLAIN) {
+            uint32_t k = 0;
+            l0 = lo32(a.c0);
+            l1 = addc32(hi32(a.c0), lo32(a.c1), k);
+            l2 = addc32(lo32(a.c2), hi32(a.c1), k);
+            l3 = addc32(hi32(a.c2), a.o1, k);
+            top = k + (C2C ? a.o2 : 0);
+            k = 0;
+            l2 = addc32(l2, a.o0, k);
+            l3 = addc32(l3, 0, k);
+            top += k;
+        } else {
+            // -v_hi * 2^64 * gamma (< q) through a 16-entry table -- a per-lane load, skipped when the host-side
+            // bound on v (scaler_upload: v <= sum_i (q_i - 1) + 1) says v_hi is always zero; +/- w: its high part and
+            // the constant of the complement through w_tab, its (complemented) low word straight into the sum
+            u64 small = s.v_fits_64 ? 0 : s.vhi_tab[jt * 16 + vh];
+            if (!s.is_one) small += s.w_tab[jt * 32 + widx];   // below 2q
+            uint32_t k = 0;
+            const uint32_t e0 = addc32(lo32(wx), lo32(small), k), e1 = addc32(hi32(wx), hi32(small), k), e2 = k;
+            k = 0;
+            l0 = addc32(lo32(a.c0), e0, k);
+            l1 = addc32(hi32(a.c0), lo32(a.c1), k);
+            l2 = addc32(lo32(a.c2), hi32(a.c1), k);
+            l3 = addc32(hi32(a.c2), a.o1, k);
+            top = k + (C2C ? a.o2 : 0);
+            k = 0;
+            l1 = addc32(l1, e1, k);
+            l2 = addc32(l2, a.o0 + e2, k);
+            l3 = addc32(l3, 0, k);
+            top += k;
         }
+        u64 lo = pack64(l0, l1), hi = pack64(l2, l3);
         u64 r;
         if ((s.narrow_mask >> (jt & 63)) & 1) {
             // the whole sum is < 2^(2k+1) (hence top == 0): the single-word Barrett of zq_dev.hpp does it
-            r = barrett_reduce_wide((u64)(acc >> 64), (u64)acc, q);
+            r = barrett_reduce_wide(hi, lo, q);
         } else if ((s.fold_mask >> (jt & 63)) & 1) {
             // < 2^(2k+6): replace the bits above 2^(2k) by their residue (64-entry table), which leaves
             // < 2^(2k) + q < 2^(2k+1) for the same single-word Barrett
             const uint32_t f = 2 * q.k;
-            const uint32_t idx = (uint32_t)(acc >> f);
-            acc = (acc & ((((u128_t)1) << f) - 1)) + s.fold_tab[jt * 64 + idx];
-            r = barrett_reduce_wide((u64)(acc >> 64), (u64)acc, q);
+            uint32_t idx;
+            if (f >= 64) {
+                idx = (uint32_t)(hi >> (f - 64));
+                hi &= (1ull << (f - 64)) - 1;
+            } else {
+                idx = (uint32_t)((lo >> f) | (hi << (64 - f)));   // (f >= 2; the sum is below 2^(f+6))
+                lo &= (1ull << f) - 1;
+                hi = 0;
+            }
+            const u64 t = s.fold_tab[jt * 64 + idx];
+            uint32_t k = 0;
+            const uint32_t m0 = addc32(lo32(lo), lo32(t), k), m1 = addc32(hi32(lo), hi32(t), k);
+            hi += k;
+            r = barrett_reduce_wide(hi, pack64(m0, m1), q);
         } else {
-            r = reduce_u128((u64)(acc >> 64), (u64)acc, q);    // [0, q)
-            r = csub_n(r + s.c128_tab[jt * 16 + ((uint32_t)top & 15)], q.p, q.np);
+            r = reduce_u128(hi, lo, q);    // [0, q)
+            r = csub_n(r + s.c128_tab[jt * 16 + (top & 15)], q.p, q.np);
         }
         o[(u64)jt * n] = r;
     }

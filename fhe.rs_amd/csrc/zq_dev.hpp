@@ -155,7 +155,7 @@ FHE_HD u64 mul_shoup(u64 a, u64 b, u64 bs, u64 p) { return csub(mul_shoup_lazy(a
 // for x < 2^(2k) and by <= 3 for x < 2^(2k+1), so x - q*p < 4p < 2^64.
 FHE_HD u64 barrett_reduce_wide(u64 hi, u64 lo, const DevMod &m) {
     const uint32_t s = m.k - 1;
-    u64 xs = (s == 0) ? lo : ((lo >> s) | (hi << (64 - s)));  // x >> (k-1), < 2^(k+1)
+    u64 xs = (lo >> s) | (hi << (64 - s));  // x >> (k-1), < 2^(k+1)   (p >= 2, hostmath.hpp: k >= 2, s in [1, 61])
     u64 q = mulhi64(xs, m.mu);
     u64 r = lo + q * m.np;  // lo - q*p < 3p < 2^64
     r = csub_n(r, m.p2, m.np2);
@@ -199,7 +199,7 @@ FHE_HD void mac2_wide62(u64 a, u64 b, u64 c, u64 d, u64 &hi, u64 &lo) {
 // lazy: below 2p (what the inverse transform's first pass takes)
 FHE_HD u64 barrett_reduce_wide_lazy(u64 hi, u64 lo, const DevMod &m) {
     const uint32_t s = m.k - 1;
-    u64 xs = (s == 0) ? lo : ((lo >> s) | (hi << (64 - s)));
+    u64 xs = (lo >> s) | (hi << (64 - s));
     u64 q = mulhi64(xs, m.mu);
     return csub_n(lo + q * m.np, m.p2, m.np2);
 }
@@ -343,59 +343,13 @@ FHE_HD u64 splitmix64(u64 x) {
     return z ^ (z >> 31);
 }
 
-// 256-bit wrap-around accumulator == ethnum::U256 as used by RnsScaler::scale
-// (M/rns/scaler.rs:260-313), held as two 128-bit halves so that additions compile to
-// hardware carry chains (v_add_co / v_addc) instead of compare-and-select sequences.
-struct U256 {
-    u128_t lo, hi;
-};
-// acc +/-= r * (lo | hi << 64)   (mod 2^256)
-FHE_HD void u256_mac_64x128(U256 &acc, u64 r, u64 lo, u64 hi, bool negate) {
-    const u128_t p0 = (u128_t)r * lo, p1 = (u128_t)r * hi;  // product = p0 + (p1 << 64), < 2^192
-    u128_t t_lo;
-    const bool c = __builtin_add_overflow(p0, p1 << 64, &t_lo);
-    const u128_t t_hi = (p1 >> 64) + (c ? 1 : 0);
-    if (!negate) {
-        const bool c2 = __builtin_add_overflow(acc.lo, t_lo, &acc.lo);
-        acc.hi += t_hi + (c2 ? 1 : 0);
-    } else {
-        const bool b2 = __builtin_sub_overflow(acc.lo, t_lo, &acc.lo);
-        acc.hi -= t_hi + (b2 ? 1 : 0);
-    }
-}
-// The same sums without carry detection: 64-bit columns of the 64 x 128-bit products are added
-// into separate 128-bit accumulators (a column sum of < 2^32 terms stays below 2^96, so the
-// zero-extending adds cannot overflow and compile to plain add/addc chains); the 256-bit value
-// c0 + c1*2^64 + c2*2^128 + c3*2^192 (mod 2^256) is formed once.
-struct Cols256 {
-    u128_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-};
-// c += r * (lo | hi << 64)
-FHE_HD void cols_mac_64x128(Cols256 &c, u64 r, u64 lo, u64 hi) {
-    const u128_t p0 = (u128_t)r * lo, p1 = (u128_t)r * hi;
-    c.c0 += (u64)p0;
-    c.c1 += (u64)(p0 >> 64);
-    c.c1 += (u64)p1;
-    c.c2 += (u64)(p1 >> 64);
-}
-// c += (r * (lo | hi << 64)) << 64
-FHE_HD void cols_mac_64x128_shl64(Cols256 &c, u64 r, u64 lo, u64 hi) {
-    const u128_t p0 = (u128_t)r * lo, p1 = (u128_t)r * hi;
-    c.c1 += (u64)p0;
-    c.c2 += (u64)(p0 >> 64);
-    c.c2 += (u64)p1;
-    c.c3 += (u64)(p1 >> 64);
-}
-FHE_HD U256 cols_resolve(const Cols256 &c) {
-    const u128_t m1 = c.c1 + (c.c0 >> 64);
-    const u128_t m2 = c.c2 + (m1 >> 64);
-    const u128_t m3 = c.c3 + (m2 >> 64);  // bits >= 2^256 fall off: U256 arithmetic wraps
-    return U256{(u128_t)(u64)c.c0 | (m1 << 64), (u128_t)(u64)m2 | (m3 << 64)};
-}
-// The same sums on the device with the carry handling of the multiplier itself: the eight 32 x 32 partial products
+// RnsScaler::scale's 256-bit fixed-point sums (ethnum::U256 in M/rns/scaler.rs:260-313): sums of 64 x 128-bit products
+// held as five 64-bit columns while terms are added and resolved into 32-bit limbs once (cols5_limbs below).
+// (Rounds 1-2 kept them as U256 / four u128 columns in C; the history up to commit b60ee88 has that form.)
+// The carry handling is the multiplier's own: the eight 32 x 32 partial products
 // of r * (lo | hi << 64) go straight into five 64-bit column accumulators (weights 2^0, 2^32, ..., 2^128) THROUGH
 // v_mad_u64_u32's addend, and each accumulator's carry-out is banked in a 32-bit counter by one v_addc -- 17
-// instructions per term, against ~35 (plus wait states) for the u128 formulation above, whose zero-extending adds the
+// instructions per term, against ~35 (plus wait states) for a u128 formulation, whose zero-extending adds the
 // compiler expands into add/addc chains and register moves.  The hazard recognizer does not see inside asm: a
 // VALU-written SGPR needs two wait states before a VALU reads it as carry-in; the instruction order provides them
 // (one s_nop before the last addc).  Exact: value = sum_k (c_k + o_k 2^64) 2^(32 k).
@@ -404,11 +358,34 @@ struct Cols5 {
     uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
 };
 // r: per-lane; (lo, hi): a WAVE-UNIFORM constant (SGPR operands, one constant-bus read per multiply).
+// FIRST: the accumulator is empty (first term of a sum): the columns are written, not added to, and only the three
+// columns that take two partial products can carry -- 11 instructions and no zeroed registers.
+template <bool FIRST = false>
 FHE_HD void cols5_mac_64x128(Cols5 &a, u64 r, u64 lo, u64 hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t r0 = (uint32_t)r, r1 = (uint32_t)(r >> 32);
     const uint32_t t0 = (uint32_t)lo, t1 = (uint32_t)(lo >> 32), t2 = (uint32_t)hi, t3 = (uint32_t)(hi >> 32);
     u64 sa, sb, sc;  // carry-outs (SGPR pairs)
+    if constexpr (FIRST) {
+        u64 sx;
+        asm("v_mad_u64_u32 %[c0], %[sx], %[r0], %[t0], 0\n\t"
+            "v_mad_u64_u32 %[c1], %[sx], %[r0], %[t1], 0\n\t"
+            "v_mad_u64_u32 %[c2], %[sx], %[r0], %[t2], 0\n\t"
+            "v_mad_u64_u32 %[c3], %[sx], %[r0], %[t3], 0\n\t"
+            "v_mad_u64_u32 %[c1], %[sa], %[r1], %[t0], %[c1]\n\t"
+            "v_mad_u64_u32 %[c2], %[sb], %[r1], %[t1], %[c2]\n\t"
+            "v_mad_u64_u32 %[c3], %[sc], %[r1], %[t2], %[c3]\n\t"
+            "v_mad_u64_u32 %[c4], %[sx], %[r1], %[t3], 0\n\t"
+            "v_addc_co_u32 %[o1], vcc, 0, 0, %[sa]\n\t"
+            "v_addc_co_u32 %[o2], vcc, 0, 0, %[sb]\n\t"
+            "v_addc_co_u32 %[o3], vcc, 0, 0, %[sc]"
+            : [c0] "=&v"(a.c0), [c1] "=&v"(a.c1), [c2] "=&v"(a.c2), [c3] "=&v"(a.c3), [c4] "=&v"(a.c4), [o1] "=&v"(a.o1),
+              [o2] "=&v"(a.o2), [o3] "=&v"(a.o3), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [sx] "=&s"(sx)
+            : [r0] "v"(r0), [r1] "v"(r1), [t0] "s"(t0), [t1] "s"(t1), [t2] "s"(t2), [t3] "s"(t3)
+            : "vcc");
+        a.o0 = 0, a.o4 = 0;
+        return;
+    }
     asm("v_mad_u64_u32 %[c0], %[sa], %[r0], %[t0], %[c0]\n\t"
         "v_mad_u64_u32 %[c1], %[sb], %[r0], %[t1], %[c1]\n\t"
         "v_mad_u64_u32 %[c2], %[sc], %[r0], %[t2], %[c2]\n\t"
@@ -431,6 +408,7 @@ FHE_HD void cols5_mac_64x128(Cols5 &a, u64 r, u64 lo, u64 hi) {
         : [r0] "v"(r0), [r1] "v"(r1), [t0] "s"(t0), [t1] "s"(t1), [t2] "s"(t2), [t3] "s"(t3)   // (lo, hi): wave-uniform
         : "vcc");
 #else  // host pass / host emulation: the same columns in plain C
+    if (FIRST) a = Cols5{};
     const u64 rr[2] = {(uint32_t)r, r >> 32}, tt[4] = {(uint32_t)lo, lo >> 32, (uint32_t)hi, hi >> 32};
     u64 *const cs[5] = {&a.c0, &a.c1, &a.c2, &a.c3, &a.c4};
     uint32_t *const os[5] = {&a.o0, &a.o1, &a.o2, &a.o3, &a.o4};
@@ -442,30 +420,74 @@ FHE_HD void cols5_mac_64x128(Cols5 &a, u64 r, u64 lo, u64 hi) {
         }
 #endif
 }
-// -> the 64-bit columns of Cols256 (weights 2^0, 2^64, 2^128, 2^192; each sum stays far below 2^128)
-FHE_HD Cols256 cols5_to_cols256(const Cols5 &a) {
-    Cols256 c;
-    const u64 M32 = 0xffffffffull;
-    c.c0 = (u128_t)a.c0 + ((a.c1 & M32) << 32);
-    c.c1 = (u128_t)(a.c1 >> 32) + a.c2 + ((a.c3 & M32) << 32) + a.o0 + ((u64)a.o1 << 32);
-    c.c2 = (u128_t)(a.c3 >> 32) + a.c4 + a.o2 + ((u64)a.o3 << 32);
-    c.c3 = a.o4;
-    return c;
-}
-FHE_HD U256 u256_sub(const U256 &a, const U256 &b) {  // wrapping
-    U256 r;
-    const bool borrow = __builtin_sub_overflow(a.lo, b.lo, &r.lo);
-    r.hi = a.hi - b.hi - (borrow ? 1 : 0);
+// ---- 32-bit limb chains: what the scaler's glue (column resolves, 256-bit shifts, rounding) is written in since
+// round 3.  The compiler expands u128 / 256-bit C arithmetic into zero-extensions, 64-bit shifts and compare-select
+// carries (about half of scale_kernel's VALU instructions); a chain of add-with-carry on 32-bit limbs is one
+// instruction per limb.
+// a + b + k; k (0 or 1) is the carry in and out
+FHE_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t &k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned ko;
+    const uint32_t r = __builtin_addc(a, b, k, &ko);
+    k = ko;
     return r;
+#else
+    const u64 t = (u64)a + b + k;
+    k = (uint32_t)(t >> 32);
+    return (uint32_t)t;
+#endif
 }
-// bits [s, s+128) of a, for 1 <= s <= 127
-FHE_HD void u256_shr_lo128(const U256 &a, uint32_t s, u64 &lo, u64 &hi) {
-    const u128_t v = (a.lo >> s) | (a.hi << (128 - s));
-    lo = (u64)v;
-    hi = (u64)(v >> 64);
+// a - b - k; k (0 or 1) is the borrow in and out
+FHE_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t &k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned ko;
+    const uint32_t r = __builtin_subc(a, b, k, &ko);
+    k = ko;
+    return r;
+#else
+    const u64 t = (u64)a - b - k;
+    k = (uint32_t)(t >> 32) & 1;
+    return (uint32_t)t;
+#endif
 }
-FHE_HD U256 u256_not(const U256 &a) { return U256{~a.lo, ~a.hi}; }
-// any bit at position >= 191 set (the reference's sign test, scaler.rs:303)
-FHE_HD bool u256_ge_2_191(const U256 &a) { return (a.hi >> 63) != 0; }
+// low word of {hi, lo} >> s, s in [0, 31]
+FHE_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+    return s ? (lo >> s) | (hi << (32 - s)) : lo;
+#endif
+}
+FHE_HD uint32_t lo32(u64 v) { return (uint32_t)v; }
+FHE_HD uint32_t hi32(u64 v) { return (uint32_t)(v >> 32); }
+FHE_HD u64 pack64(uint32_t lo, uint32_t hi) { return (u64)lo | ((u64)hi << 32); }
+// ceil(X / 2) of a three-limb value
+FHE_HD void ceil_half3(uint32_t &x0, uint32_t &x1, uint32_t &x2) {
+    const uint32_t odd = x0 & 1;
+    uint32_t k = 0;
+    x0 = addc32(funnel32(x1, x0, 1), odd, k);
+    x1 = addc32(funnel32(x2, x1, 1), 0, k);
+    x2 = (x2 >> 1) + k;
+}
+
+// The value of a Cols5 accumulator, sum_k (c_k + o_k 2^64) 2^(32 k), mod 2^(32 NL) as limbs L[0 .. NL): two carry
+// chains, (c0 | c2 << 64 | c4 << 128) + (c1 << 32 | c3 << 96) and + (o0 | o1 << 32 | ...) << 64.
+template <int NL>
+FHE_HD void cols5_limbs(const Cols5 &a, uint32_t (&L)[8]) {
+    static_assert(NL >= 6 && NL <= 8, "limb count");
+    const uint32_t A[8] = {lo32(a.c0), hi32(a.c0), lo32(a.c2), hi32(a.c2), lo32(a.c4), hi32(a.c4), 0, 0};
+    const uint32_t B[8] = {0, lo32(a.c1), hi32(a.c1), lo32(a.c3), hi32(a.c3), 0, 0, 0};
+    const uint32_t C[8] = {0, 0, a.o0, a.o1, a.o2, a.o3, a.o4, 0};
+    uint32_t k = 0;
+    L[0] = A[0];
+#pragma unroll
+    for (int i = 1; i < NL; i++) L[i] = addc32(A[i], B[i], k);
+    k = 0;
+#pragma unroll
+    for (int i = 2; i < NL; i++) L[i] = addc32(L[i], C[i], k);
+#pragma unroll
+    for (int i = NL; i < 8; i++) L[i] = 0;
+}
+
 
 }  // namespace fhe

@@ -13,7 +13,7 @@ import csv, glob, json, os, sys, collections
 
 LABELS = [("ntt_kernel<true", "ntt_inv"), ("ntt_kernel<false", "ntt_fwd"), ("ntt_global_kernel", "ntt_global"),
           ("tensor_intt_kernel", "tensor_intt"), ("ks_fused_kernel", "key_switch_fused"),
-          ("scale_kernel<4>", "scale_extend"), ("scale_kernel<9>", "scale_down"),  # C2: L=4 -> K=9 and back
+          ("scale_kernel<4", "scale_extend"), ("scale_kernel<9", "scale_down"),  # C2: L=4 -> K=9 and back (<NF, PLAIN> since round 3)
           ("scale_kernel", "scale"), ("copy_rows_kernel", "copy_rows"), ("tensor_kernel", "tensor"),
           ("switch_down_kernel", "switch_down"), ("substitute_kernel", "substitute"),
           ("dot_kernel", "dot_product"), ("synth_kernel", "synth")]

@@ -1,17 +1,18 @@
 #!/bin/bash
-# Round 3, GPU call 14: scaler output sums without the third-column overflow counter (NF <= 11) and with a carry-free
-# first term -- scaler parity tests, then same-box A/B against the previous release build.
+# Round 3, GPU call 16: scaler with first-term variants of the 64 x 128 column sums and Barrett shifts without the
+# k = 1 select -- full GPU suite, then same-box A/B against the build before this round's scaler work.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-O=gpurun_out/r03n; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "scaler or extender or multiply or c2_ or decrypt or switcher or random" > $O/pytest_subset.log 2>&1
-tail -2 $O/pytest_subset.log
+O=gpurun_out/r03p; mkdir -p $O
+timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1
+tail -2 $O/pytest_gpu.log
 cp fhe.rs_amd/libfhe_hip.so /tmp/lib_new.so
-for round in 1 2 3 4; do
+for round in 1 2 3; do
 for v in prev new; do
   if [ $v = prev ]; then cp tools/_variants/libfhe_hip_prev.so fhe.rs_amd/libfhe_hip.so; else cp /tmp/lib_new.so fhe.rs_amd/libfhe_hip.so; fi
   echo "== $v (round $round)"
   timeout 300 python bench.py --no-cpu --no-extras --steps 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], {k:v['ms'] for k,v in d['roofline']['kernels'].items()})"
+  if [ $round = 1 ]; then timeout 300 python tools/bench_configs.py c5 2>/dev/null | cut -c1-150; fi
 done
-done > $O/scaler_c2carry_ab.txt 2>&1
+done > $O/scaler_limbs_ab.txt 2>&1
 cp /tmp/lib_new.so fhe.rs_amd/libfhe_hip.so
-cat $O/scaler_c2carry_ab.txt
+cat $O/scaler_limbs_ab.txt

@@ -1453,8 +1453,16 @@ inline ChunkPlan plan_chunks(const Ctx &base, const Ctx &mulc, size_t batch, siz
         return (batch + nc - 1) / nc;
     };
     if (streams_opt >= 2) {
-        const size_t c = equal_chunks((size_t)384 << 20, 8);
-        if (nchunks(c) >= 4) return ChunkPlan{c, true};
+        // Two streams: chunks small enough that a chunk's intermediates mostly stay in the 256 MiB Infinity Cache, at
+        // least four of them.  Round 3 (profiles/r03_chunk_sweep_event_free.jsonl, C2): 64 ... 256 pairs per chunk are
+        // within 1 % of each other, 96 - 128 best at 8,192 pairs -- but 66 pairs (what the 384 MB budget gave there)
+        // lost 5 %: 66 * 16 rows is two full rounds of the 512 resident workgroups plus a nearly empty third.  Chunks
+        // of 64 pairs or more are therefore cut to a multiple of 32.
+        for (const size_t budget : {(size_t)768 << 20, (size_t)384 << 20}) {
+            size_t c = equal_chunks(budget, 8);
+            if (c >= 64) c = c / 32 * 32;
+            if (nchunks(c) >= 4) return ChunkPlan{c, true};
+        }
     }
     const size_t c = equal_chunks((size_t)3 << 30, 1);
     return ChunkPlan{c, streams_opt >= 2 && nchunks(c) >= 2};

@@ -12,6 +12,7 @@
 #include "emu_rt.hpp"  // tests/emu/emu_rt.hpp (on the include path of the emulation build only)
 #else
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: a launch that carries its own start / stop events (profiler)
 #define FHE_DYN_SMEM(type, name)                                            \
     extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
     type *name = reinterpret_cast<type *>(name##_raw)

@@ -113,6 +113,13 @@ inline unsigned __brev(unsigned x) {
 
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
     emu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
+// (hipExtLaunchKernelGGL: the launch that carries its own start / stop events; the two are stamped around the run)
+#define hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, ev_start, ev_stop, flags, ...) \
+    do {                                                                                        \
+        (void)hipEventRecord((ev_start), (stream));                                             \
+        emu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); });                   \
+        (void)hipEventRecord((ev_stop), (stream));                                              \
+    } while (0)
 
 // ---- runtime API subset ---------------------------------------------------------------
 typedef int hipError_t;

@@ -307,7 +307,7 @@ def host_api_numbers(fhe, _lib, torch, mul, ctx, par, rk, batch, n, L, value_hin
         st.synchronize()
         dt = (time.perf_counter() - t0) / reps
         out["abi_device_buffers"] = dict(ops_per_s=round(batch / dt, 1), ms_per_call=round(dt * 1e3, 3), batch=batch,
-                                         note="fhe_buf_alloc / fhe_stream_create / fhe_bfv_mul_dev, outputs allocated per call")
+                                         note="fhe_buf_alloc(_async) / fhe_stream_create / fhe_bfv_mul_dev; every call allocates its result stream-ordered and drops the previous one")
         for x in (la, ra, o):
             x.free()
     st.destroy()

@@ -32,6 +32,8 @@ SIGNATURES = {
     "fhe_device_count": (i32, []),
     "fhe_buf_alloc": (i32, [i32, sz, C.POINTER(vp)]),
     "fhe_buf_free": (i32, [vp]),
+    "fhe_buf_alloc_async": (i32, [i32, sz, vp, C.POINTER(vp)]),
+    "fhe_buf_free_async": (i32, [vp, vp]),
     "fhe_buf_upload": (i32, [vp, vp, sz, vp]),
     "fhe_buf_upload_async": (i32, [vp, vp, sz, vp]),
     "fhe_buf_download": (i32, [vp, vp, sz, vp]),

@@ -70,16 +70,24 @@ class Stream:
 
 
 class DeviceArray:
-    """A device buffer owned through the C ABI (fhe_buf_alloc), with a shape: the device-resident shadow of a
+    """A device buffer owned through the C ABI (fhe_buf_alloc, or fhe_buf_alloc_async inside `with Stream`), with a shape: the device-resident shadow of a
     `[..., L, N]` coefficient array (`rq::Poly.coefficients`) for hosts that do not bring their own HIP allocator."""
 
     def __init__(self, shape, device=0, itemsize=8, _ptr=None, _base=None):
         self.shape = tuple(int(d) for d in shape)
         self.device, self.itemsize = device, itemsize
         self._base = _base
+        self._astream = None
         if _ptr is None:
             h = C.c_void_p()
-            check(_lib.lib().fhe_buf_alloc(device, max(self.nbytes, 1), C.byref(h)))
+            st = getattr(_tls, "stream", None)
+            if st is not None and st.device == device and st.handle is not None:
+                # inside `with Stream(...)`: stream-ordered allocation (no device synchronisation when results are
+                # allocated and dropped per call); the array remembers its stream for the matching free
+                check(_lib.lib().fhe_buf_alloc_async(device, max(self.nbytes, 1), st.handle, C.byref(h)))
+                self._astream = st
+            else:
+                check(_lib.lib().fhe_buf_alloc(device, max(self.nbytes, 1), C.byref(h)))
             self._p = h.value
         else:
             self._p = _ptr
@@ -143,14 +151,20 @@ class DeviceArray:
         check(_lib.lib().fhe_buf_download(out.ctypes.data_as(C.c_void_p), C.c_void_p(self._p), self.nbytes, _stream()))
         return out
 
+    def _release(self, L):
+        st = getattr(self, "_astream", None)
+        if st is not None and st.handle is not None:
+            return L.fhe_buf_free_async(C.c_void_p(self._p), st.handle)   # behind the work enqueued on its stream
+        return L.fhe_buf_free(C.c_void_p(self._p))                        # (hipFree: waits for the device)
+
     def free(self):
         if self._base is None and self._p is not None:
-            check(_lib.lib().fhe_buf_free(C.c_void_p(self._p)))
+            check(self._release(_lib.lib()))
         self._p = None
 
     def __del__(self):
         if getattr(self, "_base", None) is None and getattr(self, "_p", None) is not None and _lib._lib is not None:
-            _lib._lib.fhe_buf_free(C.c_void_p(self._p))
+            self._release(_lib._lib)
 
 
 def _is_dev(x):

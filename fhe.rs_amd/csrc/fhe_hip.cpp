@@ -192,6 +192,37 @@ fhe_status fhe_buf_free(void *buf) {
         if (buf) FHE_HIP_CHECK(hipFree(buf));
     });
 }
+// The default memory pool of a device is told once to keep what is freed into it (release threshold: everything), so
+// that a host which allocates its results per call does not go back to the driver each time.
+static void keep_default_pool(int device) {
+    static std::mutex mu;
+    static std::vector<char> done;
+    std::lock_guard<std::mutex> g(mu);
+    if ((size_t)device >= done.size()) done.resize((size_t)device + 1, 0);
+    if (done[(size_t)device]) return;
+    hipMemPool_t pool;
+    FHE_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device));
+    uint64_t keep = ~0ull;
+    FHE_HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    done[(size_t)device] = 1;
+}
+fhe_status fhe_buf_alloc_async(int device, size_t bytes, void *stream, void **out) {
+    return guard([&] {
+        need(out, "out");
+        *out = nullptr;
+        int ndev = 0;
+        FHE_HIP_CHECK(hipGetDeviceCount(&ndev));
+        require(device >= 0 && device < ndev, E_NO_DEVICE, "no such HIP device");
+        FHE_HIP_CHECK(hipSetDevice(device));
+        keep_default_pool(device);
+        FHE_HIP_CHECK(hipMallocAsync(out, std::max<size_t>(bytes, 1), as_stream(stream)));
+    });
+}
+fhe_status fhe_buf_free_async(void *buf, void *stream) {
+    return guard([&] {
+        if (buf) FHE_HIP_CHECK(hipFreeAsync(buf, as_stream(stream)));
+    });
+}
 static void copy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, void *stream, bool wait) {
     if (bytes) {
         need(dst, "dst");

@@ -254,7 +254,7 @@ impl CtxView<'_> {
         if ct.rows != self.nmoduli() || ct.degree != self.degree() || levels >= ct.rows {
             return Err(shape_error("switch_to_level_dev: ciphertexts do not live over this context"));
         }
-        let out = DeviceCiphertexts::alloc(self.device(), ct.batch, ct.parts, ct.rows - levels, ct.degree, ct.level + levels)?;
+        let out = DeviceCiphertexts::alloc_on(self.device(), ct.batch, ct.parts, ct.rows - levels, ct.degree, ct.level + levels, stream)?;
         check(unsafe {
             ffi::fhe_bfv_switch_to_level_dev(self.ptr, levels, ct.parts, ct.buf.as_ptr(), out.buf.as_mut_ptr(), ct.batch, stream.as_ptr())
         })?;
@@ -454,14 +454,14 @@ impl HipKsk {
     /// `relinearizes` on a device-resident batch, stream-ordered (`fhe_bfv_relinearize_dev`).
     pub fn relinearize_dev(&self, ct3: &DeviceCiphertexts, stream: &Stream) -> Result<DeviceCiphertexts> {
         self.check_resident("relinearize_dev", ct3, 3)?;
-        let out = DeviceCiphertexts::alloc(self.ct_ctx.device(), ct3.batch, 2, ct3.rows, ct3.degree, ct3.level)?;
+        let out = DeviceCiphertexts::alloc_on(self.ct_ctx.device(), ct3.batch, 2, ct3.rows, ct3.degree, ct3.level, stream)?;
         check(unsafe { ffi::fhe_bfv_relinearize_dev(self.ptr, ct3.buf.as_ptr(), out.buf.as_mut_ptr(), ct3.batch, stream.as_ptr()) })?;
         Ok(out)
     }
     /// `EvaluationKey::rotates_columns_by` / `rotates_rows` on a device-resident batch (`fhe_bfv_galois_dev`).
     pub fn galois_dev(&self, exponent: usize, ct: &DeviceCiphertexts, stream: &Stream) -> Result<DeviceCiphertexts> {
         self.check_resident("galois_dev", ct, 2)?;
-        let out = DeviceCiphertexts::alloc(self.ct_ctx.device(), ct.batch, 2, ct.rows, ct.degree, ct.level)?;
+        let out = DeviceCiphertexts::alloc_on(self.ct_ctx.device(), ct.batch, 2, ct.rows, ct.degree, ct.level, stream)?;
         check(unsafe {
             ffi::fhe_bfv_galois_dev(self.ptr, exponent, ct.buf.as_ptr(), out.buf.as_mut_ptr(), ct.batch, stream.as_ptr())
         })?;
@@ -533,7 +533,7 @@ impl HipMul {
                                   message: "multiply_dev: operands must be equal batches of 2-part ciphertexts at the multiplicator's level".into() });
         }
         let level = lhs.level + (lhs.rows - self.out_rows); // (one level deeper when the handle switches the modulus)
-        let out = DeviceCiphertexts::alloc(self.device, lhs.batch, self.out_parts, self.out_rows, self.degree, level)?;
+        let out = DeviceCiphertexts::alloc_on(self.device, lhs.batch, self.out_parts, self.out_rows, self.degree, level, stream)?;
         check(unsafe {
             ffi::fhe_bfv_mul_dev(self.ptr, lhs.buf.as_ptr(), rhs.buf.as_ptr(), out.buf.as_mut_ptr(), lhs.batch, stream.as_ptr())
         })?;
@@ -644,6 +644,20 @@ impl DeviceBuffer {
         check(unsafe { ffi::fhe_buf_alloc(device as c_int, len * 8, &mut out) })?;
         Ok(Self { ptr: out as *mut u64, len })
     }
+    /// Stream-ordered allocation (`fhe_buf_alloc_async`): usable by work enqueued on `stream` from here on, and no
+    /// device synchronisation -- what the `_dev` operations allocate their results with.
+    pub fn alloc_on(device: i32, len: usize, stream: &Stream) -> Result<Self> {
+        let mut out: *mut c_void = ptr::null_mut();
+        check(unsafe { ffi::fhe_buf_alloc_async(device as c_int, len * 8, stream.as_ptr(), &mut out) })?;
+        Ok(Self { ptr: out as *mut u64, len })
+    }
+    /// Gives the block back behind the work already enqueued on `stream` (`fhe_buf_free_async`) instead of waiting for
+    /// the device as `drop` does.
+    pub fn release_on(self, stream: &Stream) -> Result<()> {
+        let p = self.ptr as *mut c_void;
+        std::mem::forget(self);
+        check(unsafe { ffi::fhe_buf_free_async(p, stream.as_ptr()) })
+    }
     pub fn len(&self) -> usize { self.len }
     pub fn is_empty(&self) -> bool { self.len == 0 }
     pub fn as_ptr(&self) -> *const u64 { self.ptr }
@@ -680,6 +694,12 @@ impl DeviceCiphertexts {
     pub fn alloc(device: i32, batch: usize, parts: usize, rows: usize, degree: usize, level: usize) -> Result<Self> {
         Ok(Self { buf: DeviceBuffer::alloc(device, batch * parts * rows * degree)?, batch, parts, rows, degree, level })
     }
+    /// The same on `stream`'s allocation order (results of the `_dev` operations).
+    pub fn alloc_on(device: i32, batch: usize, parts: usize, rows: usize, degree: usize, level: usize, stream: &Stream) -> Result<Self> {
+        Ok(Self { buf: DeviceBuffer::alloc_on(device, batch * parts * rows * degree, stream)?, batch, parts, rows, degree, level })
+    }
+    /// Frees the batch behind the work enqueued on `stream` (no device synchronisation).
+    pub fn release_on(self, stream: &Stream) -> Result<()> { self.buf.release_on(stream) }
     pub fn words_per_ct(&self) -> usize { self.parts * self.rows * self.degree }
     pub fn buffer(&self) -> &DeviceBuffer { &self.buf }
     /// `flat`: the ciphertexts' polynomials' coefficients, concatenated `[batch][parts][rows][N]`.

@@ -117,7 +117,7 @@ int main(int argc, char **argv) {
     CHECK(fhe_buf_alloc(0, L * poly, (void **)&c1));
     CHECK(fhe_buf_alloc(0, batch * ct, (void **)&lhs));
     CHECK(fhe_buf_alloc(0, batch * ct, (void **)&rhs));
-    CHECK(fhe_buf_alloc(0, batch * ct, (void **)&out));
+    CHECK(fhe_buf_alloc_async(0, batch * ct, stream, (void **)&out));   /* the result: stream-ordered, as a chained host would */
 
     /* synthetic relinearisation key: digit i = generator parts 8 + 2i (c0) and 9 + 2i (c1) of ciphertext 0 */
     CHECK(fhe_synth_uniform_dev(ctx, seed, 0, 8, 2 * L, kraw, 1, stream));
@@ -174,7 +174,7 @@ int main(int argc, char **argv) {
     CHECK(fhe_buf_free(c1));
     CHECK(fhe_buf_free(lhs));
     CHECK(fhe_buf_free(rhs));
-    CHECK(fhe_buf_free(out));
+    CHECK(fhe_buf_free_async(out, stream));
     CHECK(fhe_stream_destroy(stream));
     fhe_params_destroy(par);
     printf("%s\n", bad ? "FAILED" : "ALL OK");

@@ -191,6 +191,12 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
 }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipMallocAsync(void **p, size_t n, hipStream_t) { return hipMalloc(p, n); }
+inline hipError_t hipFreeAsync(void *p, hipStream_t) { return hipFree(p); }
+typedef int hipMemPool_t;
+enum { hipMemPoolAttrReleaseThreshold = 4 };
+inline hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t *pool, int) { *pool = 0; return hipSuccess; }
+inline hipError_t hipMemPoolSetAttribute(hipMemPool_t, int, void *) { return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {

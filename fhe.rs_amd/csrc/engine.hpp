@@ -988,12 +988,27 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     constexpr bool ks_persist_size = LOGN == 13 || (FHE_KS_PERSIST14 && LOGN == 14);
 #endif
     if (ks_persist_size && ks_persist > 0) ks_grid = std::min<unsigned>(ks_grid, (unsigned)(device_cus(kc.device) * ks_persist));
-#define FHE_KS_LAUNCH(NW, GMV)                                                                                        \
-    allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV>), lds);                                                          \
-    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV>), dim3(ks_grid),                                \
+    // RNS instances (N = 4096, 8192): residue-row digits of same-width moduli, see the kernel.  (Not at N = 16384:
+    // that instance sits at 126 of 128 VGPRs and the simpler loader makes the compiler spill 52 B elsewhere.)
+    const bool rns = (LOGN == 12 || LOGN == 13) && k_.digit_arg() == (1u << 8);
+#define FHE_KS_LAUNCH_R(NW, GMV, RNS)                                                                                 \
+    allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 0, RNS>), lds);                                                  \
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV, 0, RNS>), dim3(ks_grid),                        \
                dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,       \
                k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,               \
                k_.digit_arg(), xhat, xhat_stride, (uint32_t)(npolys * kc.L))
+#define FHE_KS_LAUNCH(NW, GMV)                                                                                        \
+    do {                                                                                                              \
+        if constexpr (LOGN == 12 || LOGN == 13) {                                                                     \
+            if (rns) {                                                                                                \
+                FHE_KS_LAUNCH_R(NW, GMV, true);                                                                       \
+            } else {                                                                                                  \
+                FHE_KS_LAUNCH_R(NW, GMV, false);                                                                      \
+            }                                                                                                         \
+        } else {                                                                                                      \
+            FHE_KS_LAUNCH_R(NW, GMV, false);                                                                          \
+        }                                                                                                             \
+    } while (0)
 #if defined(FHE_LAB)
     if constexpr (LOGN == 13) {
         // FHE_LAB_KS13_T512 = 1: 512 threads x 16 coefficients, both accumulator sets in registers, tile-only LDS (two
@@ -1043,6 +1058,8 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
         FHE_KS_LAUNCH(false, k::KS_GMAX);
     }
 #undef FHE_KS_LAUNCH
+#undef FHE_KS_LAUNCH_R
+    (void)rns;
 }
 
 // KeySwitchingKey::key_switch (:241-320): p [npolys][L][N] PowerBasis (poly stride p_stride) ->
@@ -1082,11 +1099,19 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
 #define FHE_KS_SPLIT_LAUNCH_M(G0, LM, NW)                                                                          \
     do {                                                                                                           \
         const size_t lds_ = (k::lds_words(1u << LM) + ((size_t)1 << LM)) * sizeof(u64);                            \
-        allow_big_lds((k::ks_fused_split_kernel<G0, LM, NW>), lds_);                                               \
-        FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0, LM, NW>),                                     \
-                   dim3((unsigned)((npolys * kc.L) << G0)), dim3((1u << LM) / 8), lds_, s, p, p_stride, o0, o1,    \
-                   out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(),       \
-                   (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride);                       \
+        if (k_.digit_arg() == (1u << 8)) {   /* RNS instance: residue-row digits of same-width moduli */          \
+            allow_big_lds((k::ks_fused_split_kernel<G0, LM, NW, true>), lds_);                                     \
+            FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0, LM, NW, true>),                           \
+                       dim3((unsigned)((npolys * kc.L) << G0)), dim3((1u << LM) / 8), lds_, s, p, p_stride, o0,    \
+                       o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(),         \
+                       kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride);         \
+        } else {                                                                                                   \
+            allow_big_lds((k::ks_fused_split_kernel<G0, LM, NW, false>), lds_);                                    \
+            FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0, LM, NW, false>),                          \
+                       dim3((unsigned)((npolys * kc.L) << G0)), dim3((1u << LM) / 8), lds_, s, p, p_stride, o0,    \
+                       o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(),         \
+                       kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride);         \
+        }                                                                                                          \
     } while (0)
 #define FHE_KS_SPLIT_LAUNCH(G0, NW) FHE_KS_SPLIT_LAUNCH_M(G0, 13, NW)
 #if defined(FHE_LAB)

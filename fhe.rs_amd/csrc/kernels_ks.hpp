@@ -22,7 +22,9 @@ namespace k {
 // in LDS, so that a second workgroup is resident and runs its butterflies while this one sits in a barrier.
 constexpr int ks_threads_tt(int logn, int tt) { return tt ? tt : ks_threads_c(logn); }
 constexpr bool ks_acc1_in_lds_tt(int logn, int tt) { return tt == 0 && ks_acc1_in_lds_c(logn); }
-template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0>
+// RNS (the host sets it for LOGN >= 12 when digit_arg says so): the digits are residue rows of same-width moduli
+// (digit_shift_bits == 0, lift_mode == 1 -- relinearisation and Galois keys), lifted by one conditional subtraction.
+template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false>
 __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), 4)
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
                     u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
@@ -81,6 +83,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), 4)
     // the key moduli (host-side, from the moduli): 1 -> below 2 q_j (one conditional subtraction lifts
     // it), 2 -> below 4 q_j (two), 0 -> anything (Barrett).  RNS digits of same-width moduli are mode 1.
     const uint32_t digit_shift_bits = digit_arg & 0xff, lift_mode = digit_arg >> 8;
+    constexpr bool rns_fast = RNS;
     auto lift = [&](u64 v) -> u64 {
         if (lift_mode == 1) return csub_n(v, p, pm.np);
         if (lift_mode == 2) return csub_n(csub_n(v, p2, pm.np2), p, pm.np);
@@ -142,19 +145,34 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), 4)
         const uint32_t tid = opaque(tid0);
         const uint32_t sh = i * digit_shift_bits;
         FHE_TS(0);
+        // RNS instances: one conditional subtraction per coefficient.  The generic lambda keeps the shift, the mask
+        // and three uniform branches PER ELEMENT (round 3, from the ISA).
         if constexpr (PREFETCH) {
+            if constexpr (rns_fast) {
 #pragma unroll
-            for (int c = 0; c < CH; c++) {
-                const uint32_t e = 2 * (c * T + tid);
-                lds[padi(e)] = lift((pre[c].x >> sh) & mask);
-                lds[padi(e + 1)] = lift((pre[c].y >> sh) & mask);
+                for (int c = 0; c < CH; c++) {
+                    const uint32_t e = 2 * (c * T + tid);
+                    lds[padi(e)] = csub_n(pre[c].x, p, pm.np);
+                    lds[padi(e + 1)] = csub_n(pre[c].y, p, pm.np);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    const uint32_t e = 2 * (c * T + tid);
+                    lds[padi(e)] = lift((pre[c].x >> sh) & mask);
+                    lds[padi(e + 1)] = lift((pre[c].y >> sh) & mask);
+                }
             }
         } else {
             // (address and mask are recomputed per digit on purpose: hoisted, they cost VGPRs that the
             // N = 16384 variant does not have)
             const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N);
-            const u64 mask_i = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
-            tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return lift((v >> sh) & mask_i); });
+            if constexpr (rns_fast) {
+                tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
+            } else {
+                const u64 mask_i = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+                tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return lift((v >> sh) & mask_i); });
+            }
         }
         FHE_TS(1);
         FHE_BARRIER();
@@ -291,7 +309,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), 4)
 // branch leading to `sub` is evaluated (2^G0 - 1 Shoup multiplications per coefficient instead
 // of G0/2 amortised, but no round trip of the lifted row through HBM); the remaining 13 stages
 // run in LDS with twiddle base 2^G0 + sub, exactly like ntt_kernel's sub-block mode.
-template <int G0, int LOGM = 13, bool NARROW = false>
+template <int G0, int LOGM = 13, bool NARROW = false, bool RNS = false>
 __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
     ks_fused_split_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0,
                           u64 *__restrict__ out1, u64 out_poly_stride, const u64 *__restrict__ addend0,
@@ -351,10 +369,18 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
             u64x2 v[NS];
 #pragma unroll
             for (int k = 0; k < NS; k++) v[k] = reinterpret_cast<const u64x2 *>(src + (u64)k * M)[ci];
+            if constexpr (RNS) {   // (see ks_fused_kernel's staging loop)
 #pragma unroll
-            for (int k = 0; k < NS; k++) {
-                v[k].x = lift((v[k].x >> sh) & mask);
-                v[k].y = lift((v[k].y >> sh) & mask);
+                for (int k = 0; k < NS; k++) {
+                    v[k].x = csub_n(v[k].x, p, pm.np);
+                    v[k].y = csub_n(v[k].y, p, pm.np);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    v[k].x = lift((v[k].x >> sh) & mask);
+                    v[k].y = lift((v[k].y >> sh) & mask);
+                }
             }
             // stage s keeps the half of the pairs whose output leads to `sub`
 #pragma unroll

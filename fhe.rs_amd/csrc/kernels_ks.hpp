@@ -387,14 +387,21 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
             for (int st = 0; st < G0; st++) {
                 const int half = NS >> (st + 1);
                 const u64x2 w = twr[(1u << st) + (sub >> (G0 - st))];
-                const bool minus = (sub >> (G0 - st - 1)) & 1;
+                const bool minus = (sub >> (G0 - st - 1)) & 1;   // (uniform over the workgroup: one branch per stage)
+                if (minus) {
 #pragma unroll
-                for (int m = 0; m < half; m++) {
-                    const u64 lx = csub_n(v[m].x, p2, pm.np2), ly = csub_n(v[m].y, p2, pm.np2);
-                    const u64 tx = mul_shoup_lazy_n(v[m + half].x, w.x, w.y, pm.np);
-                    const u64 ty = mul_shoup_lazy_n(v[m + half].y, w.x, w.y, pm.np);
-                    v[m].x = minus ? lx + p2 - tx : lx + tx;
-                    v[m].y = minus ? ly + p2 - ty : ly + ty;
+                    for (int m = 0; m < half; m++) {
+                        const u64 lx = csub_n(v[m].x, p2, pm.np2), ly = csub_n(v[m].y, p2, pm.np2);
+                        v[m].x = lx + p2 - mul_shoup_lazy_n(v[m + half].x, w.x, w.y, pm.np);
+                        v[m].y = ly + p2 - mul_shoup_lazy_n(v[m + half].y, w.x, w.y, pm.np);
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < half; m++) {
+                        const u64 lx = csub_n(v[m].x, p2, pm.np2), ly = csub_n(v[m].y, p2, pm.np2);
+                        v[m].x = mul_shoup_lazy_add_n(lx, v[m + half].x, w.x, w.y, pm.np);
+                        v[m].y = mul_shoup_lazy_add_n(ly, v[m + half].y, w.x, w.y, pm.np);
+                    }
                 }
             }
             lds[padi(2 * ci)] = v[0].x;

@@ -362,6 +362,14 @@ def case_scaler_extend_and_constants_api(fhe, dev, n=16):
              theta_garner_shift=s.theta_garner_shift)
     sc2 = fhe.Scaler.from_constants(cf, ct, 2, True, k)
     assert np.array_equal(x.back(sc2.scale(x.to(arr(pn)), ntt=True)), want)
+    # the kernel takes v's bits from limb 3 of the 256-bit sum on: a shift outside [97, 127] (never RnsScaler::new's
+    # choice, scaler.rs:130-142) is refused, not mis-shifted
+    for bad in (64, 96, 128):
+        try:
+            fhe.Scaler.from_constants(cf, ct, 2, True, dict(k, theta_garner_shift=bad))
+            raise AssertionError("theta_garner_shift %d accepted" % bad)
+        except fhe.FheError as err:
+            assert err.code == -1, err.code
     a, b = OCtx(MODULI5[:2], n), OCtx(MODULI5[3:], n)
     ca, cb = fhe.Context(MODULI5[:2], n), fhe.Context(MODULI5[3:], n)
     p = rand_poly(a, POWER_BASIS, rng)

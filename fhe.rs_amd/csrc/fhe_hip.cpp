@@ -194,17 +194,26 @@ fhe_status fhe_buf_free(void *buf) {
 }
 // The default memory pool of a device is told once to keep what is freed into it (release threshold: everything), so
 // that a host which allocates its results per call does not go back to the driver each time.
+static std::mutex g_pool_mu;
+static std::vector<char> g_pool_kept;   // devices whose default pool this library told to keep its blocks
 static void keep_default_pool(int device) {
-    static std::mutex mu;
-    static std::vector<char> done;
-    std::lock_guard<std::mutex> g(mu);
-    if ((size_t)device >= done.size()) done.resize((size_t)device + 1, 0);
-    if (done[(size_t)device]) return;
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    if ((size_t)device >= g_pool_kept.size()) g_pool_kept.resize((size_t)device + 1, 0);
+    if (g_pool_kept[(size_t)device]) return;
     hipMemPool_t pool;
     FHE_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device));
     uint64_t keep = ~0ull;
     FHE_HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-    done[(size_t)device] = 1;
+    g_pool_kept[(size_t)device] = 1;
+}
+// fhe_workspace_trim: hand the pools' idle blocks back to the driver as well
+static void trim_default_pools() {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    for (size_t d = 0; d < g_pool_kept.size(); d++) {
+        if (!g_pool_kept[d]) continue;
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, (int)d) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
+    }
 }
 fhe_status fhe_buf_alloc_async(int device, size_t bytes, void *stream, void **out) {
     return guard([&] {
@@ -1605,6 +1614,7 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
 }
 size_t fhe_workspace_trim(void) {
     AuxStreams::get().drop(-1, nullptr, true);   // internal streams and pooled events go too (recreated on demand)
+    trim_default_pools();                        // idle blocks of fhe_buf_alloc_async's pools
     return Workspace::get().trim();
 }
 fhe_status fhe_ubench_int(int device, int which, double min_seconds, double *ops_per_s) {

@@ -87,7 +87,8 @@ fhe_status fhe_buf_free(void *buf);                                   /* NULL is
 /* Stream-ordered twins (hipMallocAsync / hipFreeAsync on the device's default memory pool, which this library tells to
  * keep freed blocks): the block may be used by work enqueued on `stream` after the call, and a free takes effect
  * behind the work already enqueued on `stream` -- no device synchronisation, unlike hipMalloc / hipFree.  Using the
- * block on another stream needs the caller's own ordering (events).  fhe_buf_free also accepts such a block. */
+ * block on another stream needs the caller's own ordering (events).  fhe_buf_free also accepts such a block (and waits);
+ * fhe_buf_free_async is for blocks from fhe_buf_alloc_async only.  fhe_workspace_trim returns the pool's idle blocks. */
 fhe_status fhe_buf_alloc_async(int device, size_t bytes, void *stream, void **out);
 fhe_status fhe_buf_free_async(void *buf, void *stream);              /* NULL is a no-op                  */
 fhe_status fhe_buf_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);

@@ -197,6 +197,7 @@ typedef int hipMemPool_t;
 enum { hipMemPoolAttrReleaseThreshold = 4 };
 inline hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t *pool, int) { *pool = 0; return hipSuccess; }
 inline hipError_t hipMemPoolSetAttribute(hipMemPool_t, int, void *) { return hipSuccess; }
+inline hipError_t hipMemPoolTrimTo(hipMemPool_t, size_t) { return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {

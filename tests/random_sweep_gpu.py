@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Random-shape parity sweep on the GPU beyond the 48 shapes of tests/test_gpu_parity.py: every shape's multiply
 (+relinearise / modulus switch), relinearise and rotations against the C oracle (tests/full_size.py).
-Test infrastructure (lives in tests/ because it uses the oracle).  Usage: python tests/random_sweep_gpu.py [seconds]"""
+Test infrastructure (lives in tests/ because it uses the oracle).
+Usage: python tests/random_sweep_gpu.py [seconds [first_idx [last_idx]]]"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
@@ -10,7 +11,9 @@ import full_size
 fhe = load_engine("hip")
 t0 = time.time(); done = 0; fails = []
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 400
-for idx in range(48, 2000):
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+last = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+for idx in range(first, last):
     try:
         full_size.check_random_shape(fhe, idx)
         done += 1
@@ -18,4 +21,4 @@ for idx in range(48, 2000):
         fails.append((idx, full_size.random_shape(idx), repr(e)[:200]))
         break
     if time.time() - t0 > budget: break
-print(json.dumps({"shapes_checked": done, "first_idx": 48, "failures": fails, "seconds": round(time.time() - t0)}))
+print(json.dumps({"shapes_checked": done, "first_idx": first, "failures": fails, "seconds": round(time.time() - t0)}))

@@ -1410,6 +1410,59 @@ fhe_status fhe_bfv_mul_dev(const fhe_mul *m, const uint64_t *lhs, const uint64_t
         bfv_mul(*m->m, lhs, rhs, out, batch, as_stream(stream));
     });
 }
+// Host-pointer multiply of a large batch: the batch goes through in slices whose upload, pipeline and download overlap
+// (three internal streams: the link is full duplex and the GPU computes slice i while slice i + 1 arrives and slice
+// i - 1 leaves).  Values are those of the one-shot path: every ciphertext pair is independent.
+static void bfv_mul_host_sliced(const Mul &mm, const u64 *lhs, const u64 *rhs, u64 *out, size_t batch, size_t ie,
+                                size_t oe, size_t slice) {
+    static char tag_up, tag_comp, tag_down;   // keys of the three internal streams (no user stream has these addresses)
+    AuxStreams &ax = AuxStreams::get();
+    const int dev = mm.base->device;
+    hipStream_t s_up = ax.stream_for(dev, (hipStream_t)&tag_up), s_comp = ax.stream_for(dev, (hipStream_t)&tag_comp),
+                s_down = ax.stream_for(dev, (hipStream_t)&tag_down);
+    HostIO io;
+    const bool same = lhs == rhs;
+    u64 *dl = io.out(batch * ie), *dr = same ? dl : io.out(batch * ie), *dout = io.out(batch * oe);
+    const size_t nsl = (batch + slice - 1) / slice;
+    std::vector<hipEvent_t> up(nsl, nullptr), done(nsl, nullptr);
+    auto finish = [&] {   // nothing may still use the buffers when HostIO gives them back
+        (void)hipStreamSynchronize(s_up);
+        (void)hipStreamSynchronize(s_comp);
+        (void)hipStreamSynchronize(s_down);
+        for (auto *v : {&up, &done})
+            for (hipEvent_t &e : *v)
+                if (e) ax.give_event(e), e = nullptr;
+    };
+    try {
+        for (size_t i = 0; i < nsl + 2; i++) {
+            if (i < nsl) {
+                const size_t o = i * slice, n = std::min(slice, batch - o);
+                FHE_HIP_CHECK(hipMemcpyAsync(dl + o * ie, lhs + o * ie, n * ie * sizeof(u64), hipMemcpyHostToDevice, s_up));
+                if (!same)
+                    FHE_HIP_CHECK(hipMemcpyAsync(dr + o * ie, rhs + o * ie, n * ie * sizeof(u64), hipMemcpyHostToDevice, s_up));
+                up[i] = ax.take_event();
+                FHE_HIP_CHECK(hipEventRecord(up[i], s_up));
+            }
+            if (i >= 1 && i - 1 < nsl) {
+                const size_t c = i - 1, o = c * slice, n = std::min(slice, batch - o);
+                FHE_HIP_CHECK(hipStreamWaitEvent(s_comp, up[c], 0));
+                bfv_mul(mm, dl + o * ie, dr + o * ie, dout + o * oe, n, s_comp);
+                done[c] = ax.take_event();
+                FHE_HIP_CHECK(hipEventRecord(done[c], s_comp));
+            }
+            if (i >= 2) {
+                const size_t c = i - 2, o = c * slice, n = std::min(slice, batch - o);
+                FHE_HIP_CHECK(hipStreamWaitEvent(s_down, done[c], 0));
+                FHE_HIP_CHECK(hipMemcpyAsync(out + o * oe, dout + o * oe, n * oe * sizeof(u64), hipMemcpyDeviceToHost, s_down));
+            }
+        }
+    } catch (...) {
+        finish();
+        throw;
+    }
+    finish();
+}
+
 fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out, size_t batch) {
     return guard([&] {
         need(m, "mul");
@@ -1422,6 +1475,16 @@ fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rh
         mm.base->need_device();
         set_device(*mm.base);
         const size_t ie = 2 * mm.base->L * mm.base->n, oe = mm.out_parts() * mm.out_rows() * mm.base->n;
+        // slices of >= 32 MiB per operand, at least three of them: copies and pipeline overlap (see above)
+#if defined(FHE_HOST_EMULATION)
+        const size_t slice = 2;   // (so that the emulated suite walks the sliced path: batches of 6 and more)
+#else
+        const size_t slice = std::max<size_t>(8, (((size_t)32 << 20) / (ie * sizeof(u64)) + 7) / 8 * 8);
+#endif
+        if (batch >= 3 * slice) {
+            bfv_mul_host_sliced(mm, lhs, rhs, out, batch, ie, oe, slice);
+            return;
+        }
         HostIO io;
         u64 *dl = io.in(lhs, batch * ie), *dr = lhs == rhs ? dl : io.in(rhs, batch * ie), *dout = io.out(batch * oe);
         bfv_mul(mm, dl, dr, dout, batch, nullptr);   // (lhs == rhs: one upload, and the squaring shortcut of bfv_mul)

@@ -682,6 +682,30 @@ def case_multiply_square(fhe, dev, nmod=3, n=32, batch=5):
             assert np.array_equal(sq[i], want), (use_rk is not None, ms, i)
 
 
+def case_multiply_host_sliced(fhe, nmod=3, n=32, batch=7):
+    """fhe_bfv_mul on host pointers with a batch that goes through in slices (upload, pipeline and download of
+    successive slices overlap on three internal streams; emulation build: slices of 2 pairs): every ciphertext against
+    the oracle -- two operands, and one buffer as both (the squaring shortcut inside the slices)."""
+    opar, par = _params(fhe, nmod, n)
+    rng = random.Random(91)
+    sk = obfv.SecretKey.random(opar, rng)
+    ca = [sk.encrypt([rng.randrange(opar.plaintext) for _ in range(n)], rng) for _ in range(batch)]
+    cb = [sk.encrypt([rng.randrange(opar.plaintext) for _ in range(n)], rng) for _ in range(batch)]
+    a = np.array([ct_arr(c) for c in ca], dtype=np.uint64)
+    b = np.array([ct_arr(c) for c in cb], dtype=np.uint64)
+    ork = obfv.RelinearizationKey(sk, rng)
+    ctx = par.context_at_level(0)
+    rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, *ksk_arrays(ork.ksk)[::2]))
+    m = fhe.Multiplicator.default(par, rk, 0)
+    om = obfv.Multiplicator.default(ork)
+    out = m.multiply(a, b)
+    sq = m.multiply(a, a)
+    assert np.shares_memory(a, a)
+    for i in range(batch):
+        assert np.array_equal(out[i], ct_arr(om.multiply(ca[i], cb[i]))), i
+        assert np.array_equal(sq[i], ct_arr(om.multiply(ca[i], ca[i]))), i
+
+
 def case_multiply_custom_factors(fhe, dev, n=16):
     """ops/mul.rs:369-418 (`different_mul_strategy`): rhs pre-scaled by P/Q, post-scale t/P."""
     x = Xfer(dev)

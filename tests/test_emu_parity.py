@@ -260,5 +260,6 @@ def test_params_with_short_tables_fail_cleanly(fhe):
 
 def test_multiply_square_shortcut(fhe):
     cases.case_multiply_square(fhe, False)
+    cases.case_multiply_host_sliced(fhe)
     with fhe.Stream(0):
         cases.case_multiply_square(fhe, "abi", batch=3)

@@ -138,6 +138,30 @@ def test_multiply_square_shortcut(fhe, dev):
     cases.case_multiply_square(fhe, dev, nmod=2, n=1024, batch=3)
 
 
+def test_multiply_host_pointer_sliced(fhe):
+    """fhe_bfv_mul on host arrays with a batch large enough for the sliced path (N = 4096, 2 moduli: slices of 256
+    pairs, 773 pairs = three slices and a ragged fourth): bit-identical to the `_dev` entry point on the same inputs
+    for every ciphertext, sampled ciphertexts against the C oracle (full_size.check_mul does the latter on the device
+    path; the generator's output is the common input)."""
+    import torch
+    import full_size
+    n, sizes, batch, cfg = 4096, [60, 60], 773, 4242
+    full_size.check_mul(fhe, n, sizes, batch, relin=True, cfg=cfg, sample=(0, 255, 256, 511, 512, 767, 768, 772))
+    q = full_size.obfv.generate_moduli(sizes, n)
+    par = fhe.BfvParameters(n, full_size.plaintext_modulus(n), moduli=q)
+    ctx = par.context_at_level(0)
+    seed = full_size.synth.seed_for_config(cfg)
+    c0, c1 = full_size.device_key(ctx, seed, len(q))
+    m = fhe.Multiplicator.default(par, fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1)), 0)
+    lhs, rhs = ctx.synth_uniform(seed, 0, 0, 2, batch), ctx.synth_uniform(seed, 0, 2, 2, batch)
+    dev_out = m.multiply(lhs, rhs)
+    torch.cuda.synchronize()
+    hl, hr = lhs.cpu().numpy().view(np.uint64), rhs.cpu().numpy().view(np.uint64)
+    host_out = m.multiply(hl, hr)
+    assert np.array_equal(host_out, dev_out.cpu().numpy().view(np.uint64))
+    assert np.array_equal(m.multiply(hl, hl), m.multiply(lhs, lhs).cpu().numpy().view(np.uint64))   # squaring, sliced
+
+
 def test_multiply_custom_factors(fhe):
     cases.case_multiply_custom_factors(fhe, True)
 

@@ -126,6 +126,87 @@ struct HostIO {
     }
 };
 
+
+// Host-pointer calls on a large batch of independent items: the batch goes through in slices whose upload, kernels and
+// download overlap (three internal streams: the link is full duplex and the GPU works on slice i while slice i + 1
+// arrives and slice i - 1 leaves).  Values are those of the one-shot path.  `ins`: host arrays with their words per
+// item (equal pointers share one device copy: squaring); body(device inputs of the slice, device output of the slice,
+// items, stream).  Returns false -- nothing done -- when the batch is smaller than three slices of >= 32 MiB.
+struct HostIn {
+    const u64 *h;
+    size_t words;
+};
+template <class Body>
+static bool host_sliced(int dev, size_t batch, const std::vector<HostIn> &ins, u64 *out, size_t out_words, Body body) {
+    size_t widest = out_words;
+    for (const HostIn &in : ins) widest = std::max(widest, in.words);
+    if (!widest) return false;
+#if defined(FHE_HOST_EMULATION)
+    const size_t slice = 2;   // (so that the emulated suite walks the sliced path: batches of 6 and more)
+#else
+    const size_t slice = std::max<size_t>(8, (((size_t)32 << 20) / (widest * sizeof(u64)) + 7) / 8 * 8);
+#endif
+    if (batch < 3 * slice) return false;
+    static char tag_up, tag_comp, tag_down;   // keys of the three internal streams (no user stream has these addresses)
+    AuxStreams &ax = AuxStreams::get();
+    hipStream_t s_up = ax.stream_for(dev, (hipStream_t)&tag_up), s_comp = ax.stream_for(dev, (hipStream_t)&tag_comp),
+                s_down = ax.stream_for(dev, (hipStream_t)&tag_down);
+    HostIO io;
+    std::vector<u64 *> din(ins.size(), nullptr);
+    for (size_t k = 0; k < ins.size(); k++) {
+        for (size_t j = 0; j < k; j++)
+            if (ins[j].h == ins[k].h && ins[j].words == ins[k].words) din[k] = din[j];
+        if (!din[k]) din[k] = io.out(batch * ins[k].words);
+    }
+    u64 *dout = io.out(batch * out_words);
+    const size_t nsl = (batch + slice - 1) / slice;
+    std::vector<hipEvent_t> up(nsl, nullptr), done(nsl, nullptr);
+    auto finish = [&] {   // nothing may still use the buffers when HostIO gives them back
+        (void)hipStreamSynchronize(s_up);
+        (void)hipStreamSynchronize(s_comp);
+        (void)hipStreamSynchronize(s_down);
+        for (auto *v : {&up, &done})
+            for (hipEvent_t &e : *v)
+                if (e) ax.give_event(e), e = nullptr;
+    };
+    try {
+        for (size_t i = 0; i < nsl + 2; i++) {
+            if (i < nsl) {
+                const size_t o = i * slice, n = std::min(slice, batch - o);
+                for (size_t k = 0; k < ins.size(); k++) {
+                    bool first = true;
+                    for (size_t j = 0; j < k; j++) first = first && din[j] != din[k];
+                    if (first)
+                        FHE_HIP_CHECK(hipMemcpyAsync(din[k] + o * ins[k].words, ins[k].h + o * ins[k].words,
+                                                     n * ins[k].words * sizeof(u64), hipMemcpyHostToDevice, s_up));
+                }
+                up[i] = ax.take_event();
+                FHE_HIP_CHECK(hipEventRecord(up[i], s_up));
+            }
+            if (i >= 1 && i - 1 < nsl) {
+                const size_t c = i - 1, o = c * slice, n = std::min(slice, batch - o);
+                FHE_HIP_CHECK(hipStreamWaitEvent(s_comp, up[c], 0));
+                std::vector<const u64 *> ds(ins.size());
+                for (size_t k = 0; k < ins.size(); k++) ds[k] = din[k] + o * ins[k].words;
+                body(ds, dout + o * out_words, n, s_comp);
+                done[c] = ax.take_event();
+                FHE_HIP_CHECK(hipEventRecord(done[c], s_comp));
+            }
+            if (i >= 2) {
+                const size_t c = i - 2, o = c * slice, n = std::min(slice, batch - o);
+                FHE_HIP_CHECK(hipStreamWaitEvent(s_down, done[c], 0));
+                FHE_HIP_CHECK(hipMemcpyAsync(out + o * out_words, dout + o * out_words, n * out_words * sizeof(u64),
+                                             hipMemcpyDeviceToHost, s_down));
+            }
+        }
+    } catch (...) {
+        finish();
+        throw;
+    }
+    finish();
+    return true;
+}
+
 std::unique_ptr<Ksk> make_ksk(const Ctx &ct, const Ctx &kc, size_t ndigits, size_t log_base) {
     ksk_validate(ct, kc, ndigits, log_base);
     kc.need_device();
@@ -975,6 +1056,11 @@ fhe_status fhe_bfv_relinearize(const fhe_ksk *rk, const uint64_t *ct3, uint64_t 
         const Ksk &ks = *rk->k;
         set_device(*ks.ksk_ctx);
         const size_t pe = ks.ct_ctx->L * ks.ct_ctx->n;
+        if (host_sliced(ks.ksk_ctx->device, batch, {{ct3, 3 * pe}}, out, 2 * pe,
+                        [&](const std::vector<const u64 *> &d, u64 *o, size_t n, hipStream_t st) {
+                            relinearize_run(ks, d[0], o, n, st);
+                        }))
+            return;
         HostIO io;
         u64 *di = io.in(ct3, batch * 3 * pe), *dout = io.out(batch * 2 * pe);
         relinearize_run(ks, di, dout, batch, nullptr);
@@ -1007,6 +1093,11 @@ fhe_status fhe_bfv_galois(const fhe_ksk *gk, size_t exponent, const uint64_t *ct
         const Ksk &ks = *gk->k;
         set_device(*ks.ksk_ctx);
         const size_t pe = ks.ct_ctx->L * ks.ct_ctx->n;
+        if (host_sliced(ks.ksk_ctx->device, batch, {{ct, 2 * pe}}, out, 2 * pe,
+                        [&](const std::vector<const u64 *> &d, u64 *o, size_t n, hipStream_t st) {
+                            galois_run(ks, exponent, d[0], o, n, st);
+                        }))
+            return;
         HostIO io;
         u64 *di = io.in(ct, batch * 2 * pe), *dout = io.out(batch * 2 * pe);
         galois_run(ks, exponent, di, dout, batch, nullptr);
@@ -1410,59 +1501,6 @@ fhe_status fhe_bfv_mul_dev(const fhe_mul *m, const uint64_t *lhs, const uint64_t
         bfv_mul(*m->m, lhs, rhs, out, batch, as_stream(stream));
     });
 }
-// Host-pointer multiply of a large batch: the batch goes through in slices whose upload, pipeline and download overlap
-// (three internal streams: the link is full duplex and the GPU computes slice i while slice i + 1 arrives and slice
-// i - 1 leaves).  Values are those of the one-shot path: every ciphertext pair is independent.
-static void bfv_mul_host_sliced(const Mul &mm, const u64 *lhs, const u64 *rhs, u64 *out, size_t batch, size_t ie,
-                                size_t oe, size_t slice) {
-    static char tag_up, tag_comp, tag_down;   // keys of the three internal streams (no user stream has these addresses)
-    AuxStreams &ax = AuxStreams::get();
-    const int dev = mm.base->device;
-    hipStream_t s_up = ax.stream_for(dev, (hipStream_t)&tag_up), s_comp = ax.stream_for(dev, (hipStream_t)&tag_comp),
-                s_down = ax.stream_for(dev, (hipStream_t)&tag_down);
-    HostIO io;
-    const bool same = lhs == rhs;
-    u64 *dl = io.out(batch * ie), *dr = same ? dl : io.out(batch * ie), *dout = io.out(batch * oe);
-    const size_t nsl = (batch + slice - 1) / slice;
-    std::vector<hipEvent_t> up(nsl, nullptr), done(nsl, nullptr);
-    auto finish = [&] {   // nothing may still use the buffers when HostIO gives them back
-        (void)hipStreamSynchronize(s_up);
-        (void)hipStreamSynchronize(s_comp);
-        (void)hipStreamSynchronize(s_down);
-        for (auto *v : {&up, &done})
-            for (hipEvent_t &e : *v)
-                if (e) ax.give_event(e), e = nullptr;
-    };
-    try {
-        for (size_t i = 0; i < nsl + 2; i++) {
-            if (i < nsl) {
-                const size_t o = i * slice, n = std::min(slice, batch - o);
-                FHE_HIP_CHECK(hipMemcpyAsync(dl + o * ie, lhs + o * ie, n * ie * sizeof(u64), hipMemcpyHostToDevice, s_up));
-                if (!same)
-                    FHE_HIP_CHECK(hipMemcpyAsync(dr + o * ie, rhs + o * ie, n * ie * sizeof(u64), hipMemcpyHostToDevice, s_up));
-                up[i] = ax.take_event();
-                FHE_HIP_CHECK(hipEventRecord(up[i], s_up));
-            }
-            if (i >= 1 && i - 1 < nsl) {
-                const size_t c = i - 1, o = c * slice, n = std::min(slice, batch - o);
-                FHE_HIP_CHECK(hipStreamWaitEvent(s_comp, up[c], 0));
-                bfv_mul(mm, dl + o * ie, dr + o * ie, dout + o * oe, n, s_comp);
-                done[c] = ax.take_event();
-                FHE_HIP_CHECK(hipEventRecord(done[c], s_comp));
-            }
-            if (i >= 2) {
-                const size_t c = i - 2, o = c * slice, n = std::min(slice, batch - o);
-                FHE_HIP_CHECK(hipStreamWaitEvent(s_down, done[c], 0));
-                FHE_HIP_CHECK(hipMemcpyAsync(out + o * oe, dout + o * oe, n * oe * sizeof(u64), hipMemcpyDeviceToHost, s_down));
-            }
-        }
-    } catch (...) {
-        finish();
-        throw;
-    }
-    finish();
-}
-
 fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out, size_t batch) {
     return guard([&] {
         need(m, "mul");
@@ -1475,16 +1513,12 @@ fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rh
         mm.base->need_device();
         set_device(*mm.base);
         const size_t ie = 2 * mm.base->L * mm.base->n, oe = mm.out_parts() * mm.out_rows() * mm.base->n;
-        // slices of >= 32 MiB per operand, at least three of them: copies and pipeline overlap (see above)
-#if defined(FHE_HOST_EMULATION)
-        const size_t slice = 2;   // (so that the emulated suite walks the sliced path: batches of 6 and more)
-#else
-        const size_t slice = std::max<size_t>(8, (((size_t)32 << 20) / (ie * sizeof(u64)) + 7) / 8 * 8);
-#endif
-        if (batch >= 3 * slice) {
-            bfv_mul_host_sliced(mm, lhs, rhs, out, batch, ie, oe, slice);
+        // a large batch goes through in slices whose copies and pipeline overlap (host_sliced)
+        if (host_sliced(mm.base->device, batch, {{lhs, ie}, {rhs, ie}}, out, oe,
+                        [&](const std::vector<const u64 *> &d, u64 *o, size_t n, hipStream_t st) {
+                            bfv_mul(mm, d[0], d[1], o, n, st);
+                        }))
             return;
-        }
         HostIO io;
         u64 *dl = io.in(lhs, batch * ie), *dr = lhs == rhs ? dl : io.in(rhs, batch * ie), *dout = io.out(batch * oe);
         bfv_mul(mm, dl, dr, dout, batch, nullptr);   // (lhs == rhs: one upload, and the squaring shortcut of bfv_mul)

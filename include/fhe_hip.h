@@ -362,7 +362,8 @@ fhe_status fhe_mul_get_options(const fhe_mul *m, size_t *chunk, size_t *streams)
  * lhs, rhs [batch][2][L][N] Ntt -> out [batch][parts][rows][N] Ntt.  lhs == rhs (the same buffer: squaring, the
  * reference's `&c1 * &c1`) extends the operand once; the values are those of the general call.
  * The host-pointer form sends a large batch (>= 3 slices of >= 32 MiB per operand) through in slices whose upload,
- * pipeline and download overlap on internal streams; it returns when `out` is complete, like every host-pointer call. */
+ * pipeline and download overlap on internal streams (so do fhe_bfv_relinearize and fhe_bfv_galois); it returns when
+ * `out` is complete, like every host-pointer call. */
 fhe_status fhe_bfv_mul(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out, size_t batch);
 fhe_status fhe_bfv_mul_dev(const fhe_mul *m, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out,
                            size_t batch, void *stream);

@@ -704,6 +704,19 @@ def case_multiply_host_sliced(fhe, nmod=3, n=32, batch=7):
     for i in range(batch):
         assert np.array_equal(out[i], ct_arr(om.multiply(ca[i], cb[i]))), i
         assert np.array_equal(sq[i], ct_arr(om.multiply(ca[i], ca[i]))), i
+    # the other two host-pointer calls that go through in slices: relinearise (three parts in, two out) and a rotation
+    m3 = fhe.Multiplicator.default(par, None, 0)
+    t3 = m3.multiply(a, b)
+    rel = rk.relinearizes(t3)
+    ogk = obfv.GaloisKey(sk, 3, 0, 0, rng)
+    gk = fhe.GaloisKey(fhe.KeySwitchingKey(ctx, ctx, *ksk_arrays(ogk.ksk)[::2]), 3)
+    rot = gk.relinearize(a)
+    for i in range(batch):
+        c3 = ca[i].mul(cb[i])
+        assert np.array_equal(t3[i], ct_arr(c3)), i
+        ork.relinearizes(c3)
+        assert np.array_equal(rel[i], ct_arr(c3)), i
+        assert np.array_equal(rot[i], ct_arr(ogk.relinearize(ca[i]))), i
 
 
 def case_multiply_custom_factors(fhe, dev, n=16):

@@ -160,6 +160,12 @@ def test_multiply_host_pointer_sliced(fhe):
     host_out = m.multiply(hl, hr)
     assert np.array_equal(host_out, dev_out.cpu().numpy().view(np.uint64))
     assert np.array_equal(m.multiply(hl, hl), m.multiply(lhs, lhs).cpu().numpy().view(np.uint64))   # squaring, sliced
+    # relinearise (773 three-part ciphertexts: slices of 168) and a rotation through the same sliced host path
+    rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1))
+    t3 = fhe.Multiplicator.default(par, None, 0).multiply(lhs, rhs)
+    assert np.array_equal(rk.relinearizes(t3.cpu().numpy().view(np.uint64)), rk.relinearizes(t3).cpu().numpy().view(np.uint64))
+    gk = fhe.GaloisKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1), 3)
+    assert np.array_equal(gk.relinearize(hl), gk.relinearize(lhs).cpu().numpy().view(np.uint64))
 
 
 def test_multiply_custom_factors(fhe):

@@ -1034,6 +1034,29 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
         }
     }
 #endif
+#if defined(FHE_LAB)
+    if constexpr (LOGN == 14) {
+        // FHE_LAB_KS14_T512 = 1: 512 threads x 32 coefficients, 256 VGPRs (two waves per SIMD), both accumulator sets in
+        // registers, radix-16 passes (GM = 4), the RNS loader; = 2: the same with radix-8 passes
+        static const int t512 = FHE_LAB_INT("KS14_T512", 0);
+        if (t512 && k_.digit_arg() == (1u << 8)) {
+            const size_t lds2 = k::lds_words(1u << LOGN) * sizeof(u64);
+            const unsigned grid2 = (unsigned)(npolys * kc.L);
+#define FHE_KS14_T512(NW, GMV)                                                                                         \
+    allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 512, true>), lds2);                                               \
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV, 512, true>), dim3(grid2), dim3(512), lds2, s, p, \
+               p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(),       \
+               kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, grid2)
+            if (t512 == 2) {
+                if (narrow) { FHE_KS14_T512(true, 3); } else { FHE_KS14_T512(false, 3); }
+            } else {
+                if (narrow) { FHE_KS14_T512(true, 4); } else { FHE_KS14_T512(false, 4); }
+            }
+#undef FHE_KS14_T512
+            return;
+        }
+    }
+#endif
     if constexpr (LOGN == 14) {   // (radix-4 passes at N = 8192 measured slower: 0.559 vs 0.532 ms per launch)
         if (plan14 == 4) {
             if (narrow) {

@@ -24,8 +24,11 @@ constexpr int ks_threads_tt(int logn, int tt) { return tt ? tt : ks_threads_c(lo
 constexpr bool ks_acc1_in_lds_tt(int logn, int tt) { return tt == 0 && ks_acc1_in_lds_c(logn); }
 // RNS (the host sets it for LOGN >= 12 when digit_arg says so): the digits are residue rows of same-width moduli
 // (digit_shift_bits == 0, lift_mode == 1 -- relinearisation and Galois keys), lifted by one conditional subtraction.
+// (TT = 512 at N = 16384, lab: 32 coefficients per thread and a 256-register budget -- two waves per SIMD -- so that
+// both accumulator sets AND a radix-16 pass fit: 4 passes instead of 6, see engine.hpp FHE_LAB_KS14_T512)
+constexpr int ks_min_waves(int logn, int tt) { return (logn == 14 && tt == 512) ? 2 : 4; }
 template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false>
-__global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), 4)
+__global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT))
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
                     u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
                     u64 addend_poly_stride, const u64 *__restrict__ k0, const u64 *__restrict__ k0s,

@@ -1017,11 +1017,19 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
         if (t512) {
             const size_t lds2 = k::lds_words(1u << LOGN) * sizeof(u64);
             const unsigned grid2 = (unsigned)(npolys * kc.L);
+#define FHE_KS_T512_R(NW, GMV, RNS)                                                                                \
+    allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 512, RNS>), lds2);                                            \
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV, 512, RNS>), dim3(grid2), dim3(512), lds2, s, \
+               p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p,            \
+               kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, grid2)
 #define FHE_KS_T512(NW, GMV)                                                                                       \
-    allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 512>), lds2);                                                 \
-    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV, 512>), dim3(grid2), dim3(512), lds2, s, p,   \
-               p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(),   \
-               kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, grid2)
+    do {                                                                                                           \
+        if (rns) {                                                                                                 \
+            FHE_KS_T512_R(NW, GMV, true);                                                                          \
+        } else {                                                                                                   \
+            FHE_KS_T512_R(NW, GMV, false);                                                                         \
+        }                                                                                                          \
+    } while (0)
             if (t512 == 2) {
                 if (narrow) { FHE_KS_T512(true, 2); } else { FHE_KS_T512(false, 2); }
             } else if (t512 == 3) {
@@ -1030,6 +1038,7 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
                 if (narrow) { FHE_KS_T512(true, k::GM_MIXED); } else { FHE_KS_T512(false, k::GM_MIXED); }
             }
 #undef FHE_KS_T512
+#undef FHE_KS_T512_R
             return;
         }
     }

@@ -97,6 +97,8 @@ SIGNATURES = {
     "fhe_ksk_create": (i32, [vp, vp, sz, u64p, u64p, u64p, u64p, sz, C.POINTER(vp)]),
     "fhe_ksk_create_dev": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(vp)]),
     "fhe_ksk_destroy": (None, [vp]),
+    "fhe_ksk_set_mode": (i32, [vp, C.c_int, sz]),
+    "fhe_ksk_get_mode": (i32, [vp, C.POINTER(C.c_int), szp]),
     "fhe_key_switch": (i32, [vp, u64p, u64p, u64p, sz]),
     "fhe_key_switch_dev": (i32, [vp, vp, vp, vp, sz, vp]),
     "fhe_bfv_relinearize": (i32, [vp, u64p, u64p, sz]),
@@ -145,6 +147,9 @@ SIGNATURES = {
     "fhe_generate_moduli": (i32, [szp, sz, sz, u64p]),
     "fhe_synth_uniform_dev": (i32, [vp, u64, u64, u64, sz, vp, sz, vp]),
     "fhe_workspace_trim": (sz, []),
+    "fhe_workspace_set_limit": (i32, [sz, sz]),
+    "fhe_workspace_get_limit": (i32, [szp, szp]),
+    "fhe_workspace_stats": (i32, [szp, szp, szp, szp]),
     "fhe_prof_enable": (None, [i32]),
     "fhe_prof_reset": (None, []),
     "fhe_prof_count": (sz, []),

@@ -38,10 +38,18 @@ class Stream:
     """A HIP stream handed out by the C ABI (fhe_stream_create).  `with Stream(dev) as s:` makes it the stream every
     `_dev` call of this thread runs on (instead of torch's current stream)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _foreign=None):
+        if _foreign is not None:     # a hipStream_t the host made itself: used, never destroyed here
+            self._h, self.device, self._owned = C.c_void_p(_foreign), device, False
+            return
         h = C.c_void_p()
         check(_lib.lib().fhe_stream_create(device, C.byref(h)))
-        self._h, self.device = h, device
+        self._h, self.device, self._owned = h, device, True
+
+    @classmethod
+    def foreign(cls, handle, device=0):
+        """Wraps a HIP stream that the host created (and will destroy) itself -- what a torch / hip-rs host passes."""
+        return cls(device, _foreign=int(handle))
 
     @property
     def handle(self):
@@ -51,9 +59,9 @@ class Stream:
         check(_lib.lib().fhe_stream_sync(self._h))
 
     def destroy(self):
-        if self._h is not None:
+        if self._h is not None and self._owned:
             check(_lib.lib().fhe_stream_destroy(self._h))
-            self._h = None
+        self._h = None
 
     def __enter__(self):
         self._prev = getattr(_tls, "stream", None)
@@ -65,7 +73,7 @@ class Stream:
         return False
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and _lib._lib is not None:
+        if getattr(self, "_h", None) is not None and getattr(self, "_owned", False) and _lib._lib is not None:
             _lib._lib.fhe_stream_destroy(self._h)
 
 
@@ -153,8 +161,12 @@ class DeviceArray:
 
     def _release(self, L):
         st = getattr(self, "_astream", None)
-        if st is not None and st.handle is not None:
-            return L.fhe_buf_free_async(C.c_void_p(self._p), st.handle)   # behind the work enqueued on its stream
+        # stream-ordered free only while the allocating stream is still the current one: every use of the array was
+        # then enqueued on it.  Dropped outside its `with Stream` block (where calls go to another stream) the array
+        # takes the synchronous free, which waits for the device (hipFreeAsync on the allocating stream
+        # could hand the block back while another stream still read it).
+        if st is not None and st.handle is not None and getattr(_tls, "stream", None) is st:
+            return L.fhe_buf_free_async(C.c_void_p(self._p), st.handle)
         return L.fhe_buf_free(C.c_void_p(self._p))                        # (hipFree: waits for the device)
 
     def free(self):
@@ -611,10 +623,43 @@ class KeySwitchingKey:
                                    _ptr(a1), _ptr(s1) if s1 is not None else None, log_base, C.byref(h)))
         self.ndigits = nd
         self._h = h
+        if KeySwitchingKey.default_mode != (0, 0):     # (tests and A/B tools: every key made inside `forced_mode`)
+            self.set_mode(*KeySwitchingKey.default_mode)
+
+    default_mode = (0, 0)
+
+    @classmethod
+    def forced_mode(cls, mode, w_budget=0):
+        """Context manager: keys created inside take `mode` (the parity suites run their key-switch cases once per
+        evaluation strategy this way; the library itself has no process-wide switch)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = cls.default_mode
+            cls.default_mode = (int(mode), int(w_budget))
+            try:
+                yield
+            finally:
+                cls.default_mode = old
+        return cm()
 
     def __del__(self):
         if getattr(self, "_h", None) is not None and _lib._lib is not None:
             _lib._lib.fhe_ksk_destroy(self._h)
+
+    AUTO, FUSED, UNFUSED, UNFUSED_SUB = 0, 1, 2, 3
+
+    def set_mode(self, mode, w_budget=0):
+        """How every key switch through this handle is evaluated (fhe_ksk_set_mode): AUTO, FUSED, UNFUSED (batched
+        digit transforms + streaming lazy MAC), UNFUSED_SUB; `w_budget` bytes of transformed rows per launch pair."""
+        check(_lib.lib().fhe_ksk_set_mode(self._h, int(mode), int(w_budget)))
+        return self
+
+    def mode(self):
+        m, w = C.c_int(), C.c_size_t()
+        check(_lib.lib().fhe_ksk_get_mode(self._h, C.byref(m), C.byref(w)))
+        return dict(mode=m.value, w_budget=w.value)
 
     def key_switch(self, p):
         """KeySwitchingKey::key_switch: p [..., L, N] PowerBasis -> (c0, c1) [..., Lk, N] Ntt."""
@@ -1026,6 +1071,17 @@ def prof_report():
 def workspace_trim():
     """Frees the engine's idle scratch buffers; returns the bytes released."""
     return int(_lib.lib().fhe_workspace_trim())
+
+
+def workspace_set_limit(per_stream_bytes=0, total_bytes=0):
+    """Bounds on the scratch the engine retains between calls (fhe_workspace_set_limit; 0 = none)."""
+    check(_lib.lib().fhe_workspace_set_limit(int(per_stream_bytes), int(total_bytes)))
+
+
+def workspace_stats():
+    h, u, b, o = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    check(_lib.lib().fhe_workspace_stats(C.byref(h), C.byref(u), C.byref(b), C.byref(o)))
+    return dict(held_bytes=h.value, in_use_bytes=u.value, blocks=b.value, owners=o.value)
 
 
 UBENCH_KINDS = {"mad_u64_u32": 0, "mul_lo_u32": 1, "mul_hi_u32": 2, "shoup_lazy": 3, "fwd_butterfly": 4,

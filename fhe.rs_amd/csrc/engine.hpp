@@ -186,61 +186,92 @@ struct DevBuf {
     }
 };
 
-// Grow-only workspace blocks, reused in stream order: a block released by stream S is handed
-// out again only to work enqueued on S, so no cross-stream hazard and no per-call hipMalloc.
+// One PRIVATE stream-ordered memory pool per device (hipMemPoolCreate), told to keep what is freed into it: the
+// engine's scratch blocks and the ABI's fhe_buf_alloc_async come from it.  (Round 3 raised the release threshold of the
+// device's DEFAULT pool instead, which changed the behaviour of every other hipMallocAsync user in the process.)
+class DevPools {
+public:
+    static DevPools &get() {
+        static DevPools p;
+        return p;
+    }
+    hipMemPool_t pool(int device) {
+        std::lock_guard<std::mutex> g(mu);
+        if ((size_t)device >= pools.size()) pools.resize((size_t)device + 1, nullptr);
+        if (!pools[(size_t)device]) {
+            hipMemPoolProps props;
+            std::memset(&props, 0, sizeof(props));
+            props.allocType = hipMemAllocationTypePinned;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = device;
+            hipMemPool_t mp = nullptr;
+            FHE_HIP_CHECK(hipMemPoolCreate(&mp, &props));
+            uint64_t keep = ~0ull;
+            FHE_HIP_CHECK(hipMemPoolSetAttribute(mp, hipMemPoolAttrReleaseThreshold, &keep));
+            pools[(size_t)device] = mp;
+        }
+        return pools[(size_t)device];
+    }
+    void *alloc(int device, size_t bytes, hipStream_t s) {
+        void *p = nullptr;
+        FHE_HIP_CHECK(hipMallocFromPoolAsync(&p, bytes ? bytes : 8, pool(device), s));
+        return p;
+    }
+    // hands the pools' idle memory back to the driver
+    void trim() {
+        std::lock_guard<std::mutex> g(mu);
+        for (hipMemPool_t mp : pools)
+            if (mp) (void)hipMemPoolTrimTo(mp, 0);
+    }
+
+private:
+    std::mutex mu;
+    std::vector<hipMemPool_t> pools;
+};
+
+// Is `s` still a stream?  (A host that makes and destroys its own HIP streams -- torch, hip-rs -- never tells the
+// engine; hipStreamQuery answers hipSuccess / hipErrorNotReady for a live stream and an invalid-handle error for one
+// that is gone.)
+inline bool stream_alive(hipStream_t s) {
+    if (!s) return true;   // the null stream
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess || e == hipErrorNotReady) return true;
+    (void)hipGetLastError();   // (clear the sticky error of the failed query)
+    return false;
+}
+
+// Scratch blocks, reused in stream order: a block released by stream S is handed out again only to work enqueued on
+// S, so there is no cross-stream hazard and no allocation per call.  Round 4: bounded.
+//  * Blocks come from the device's private stream-ordered pool (DevPools) and go back to it stream-ordered
+//    (hipFreeAsync on the block's own stream), so growing a stream's block no longer synchronises the device.
+//  * Limits (fhe_workspace_set_limit; 0 = none): `per_stream` and `total` bound the bytes the engine RETAINS -- idle
+//    blocks beyond them are evicted least-recently-used first, on release and before growing.  Blocks in use are never
+//    refused: a call that needs more than the limit still runs, its blocks just are not kept afterwards.
+//  * Before it grows, acquire() drops what belongs to streams that no longer exist (stream_alive): their work is over
+//    or draining, their blocks are freed with hipFree (which waits for the device), and the internal second stream
+//    that shadowed them (AuxStreams) goes with them.  A recycled handle value that inherits an old block is harmless:
+//    everything that ran on the old stream has been waited for by then or is ordered before the new owner's work by
+//    the allocator itself.
 class Workspace {
 public:
     static Workspace &get() {
         static Workspace w;
         return w;
     }
-    void *acquire(size_t bytes, hipStream_t s) {
-        int dev = 0;
-        FHE_HIP_CHECK(hipGetDevice(&dev));
-        std::lock_guard<std::mutex> lk(mu);
-        Block *best = nullptr;
-        for (auto &b : blocks)
-            if (!b.in_use && b.device == dev && b.stream == s && b.bytes >= bytes && (!best || b.bytes < best->bytes))
-                best = &b;
-        if (!best) {
-            // free idle blocks of this (device, stream) that are too small before growing
-            for (auto &b : blocks)
-                if (!b.in_use && b.device == dev && b.stream == s && b.ptr) {
-                    (void)hipFree(b.ptr);
-                    b.ptr = nullptr;
-                    b.bytes = 0;
-                }
-            blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const Block &b) { return !b.ptr; }),
-                         blocks.end());
-            Block nb;
-            FHE_HIP_CHECK(hipMalloc(&nb.ptr, bytes ? bytes : 8));
-            nb.bytes = bytes;
-            nb.stream = s;
-            nb.device = dev;
-            blocks.push_back(nb);
-            best = &blocks.back();
-        }
-        best->in_use = true;
-        return best->ptr;
-    }
+    void *acquire(size_t bytes, hipStream_t s);
     void release(void *p) {
         std::lock_guard<std::mutex> lk(mu);
         for (auto &b : blocks)
-            if (b.ptr == p) b.in_use = false;
+            if (b.ptr == p) {
+                b.in_use = false;
+                b.last_use = ++tick;
+            }
+        enforce_limits_locked(nullptr, -1, 0);
     }
     // A stream is about to be destroyed: its idle blocks can never be handed out again.
     void drop_stream(hipStream_t s) {
         std::lock_guard<std::mutex> lk(mu);
-        int cur = 0;
-        (void)hipGetDevice(&cur);
-        for (auto &b : blocks)
-            if (!b.in_use && b.ptr && b.stream == s) {
-                (void)hipSetDevice(b.device);
-                (void)hipFree(b.ptr);
-                b.ptr = nullptr;
-            }
-        (void)hipSetDevice(cur);
-        blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const Block &b) { return !b.ptr; }), blocks.end());
+        drop_stream_locked(s, true);
     }
     // Frees every idle block (all devices); returns the number of bytes released.
     size_t trim() {
@@ -251,13 +282,45 @@ public:
         for (auto &b : blocks)
             if (!b.in_use && b.ptr) {
                 (void)hipSetDevice(b.device);
-                (void)hipFree(b.ptr);
+                (void)hipFree(b.ptr);   // (waits for the device: whatever still read the block is done)
                 freed += b.bytes;
                 b.ptr = nullptr;
             }
         (void)hipSetDevice(cur);
-        blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const Block &b) { return !b.ptr; }), blocks.end());
+        compact_locked();
         return freed;
+    }
+    void set_limits(size_t per_stream, size_t total) {
+        std::lock_guard<std::mutex> lk(mu);
+        limit_stream = per_stream;
+        limit_total = total;
+        enforce_limits_locked(nullptr, -1, 0);
+    }
+    void get_limits(size_t *per_stream, size_t *total) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (per_stream) *per_stream = limit_stream;
+        if (total) *total = limit_total;
+    }
+    // bytes held (idle + in use), bytes in use, number of blocks, number of distinct (device, stream) owners
+    void stats(size_t *held, size_t *in_use, size_t *nblocks, size_t *nstreams) {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t h = 0, u = 0;
+        std::vector<std::pair<int, hipStream_t>> owners;
+        for (auto &b : blocks) {
+            h += b.bytes;
+            if (b.in_use) u += b.bytes;
+            if (std::find(owners.begin(), owners.end(), std::make_pair(b.device, b.stream)) == owners.end())
+                owners.emplace_back(b.device, b.stream);
+        }
+        if (held) *held = h;
+        if (in_use) *in_use = u;
+        if (nblocks) *nblocks = blocks.size();
+        if (nstreams) *nstreams = owners.size();
+    }
+    // (AuxStreams tells the pool which of its keys are not real streams, and which internal streams it destroyed)
+    void drop_internal_stream(hipStream_t aux) {
+        std::lock_guard<std::mutex> lk(mu);
+        drop_stream_locked(aux, true);
     }
 
 private:
@@ -267,9 +330,66 @@ private:
         hipStream_t stream = nullptr;
         int device = 0;
         bool in_use = false;
+        uint64_t last_use = 0;
     };
     std::vector<Block> blocks;
     std::mutex mu;
+    uint64_t tick = 0;
+    size_t limit_stream = 0, limit_total = 0;
+
+    void compact_locked() {
+        blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const Block &b) { return !b.ptr; }), blocks.end());
+    }
+    // frees one idle block: stream-ordered on its own stream when that stream is known to be alive, else hipFree
+    void free_block_locked(Block &b, bool owner_alive) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != b.device) (void)hipSetDevice(b.device);
+        if (!owner_alive || hipFreeAsync(b.ptr, b.stream) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(b.ptr);
+        }
+        if (cur != b.device) (void)hipSetDevice(cur);
+        b.ptr = nullptr;
+        b.bytes = 0;
+    }
+    void drop_stream_locked(hipStream_t s, bool owner_alive) {
+        for (auto &b : blocks)
+            if (!b.in_use && b.ptr && b.stream == s) free_block_locked(b, owner_alive);
+        compact_locked();
+    }
+    // Evicts idle blocks, least recently used first, until the retained bytes respect the limits; `extra` bytes on
+    // (`dev`, `s`) are about to be added (acquire) and count against both.
+    void enforce_limits_locked(hipStream_t s, int dev, size_t extra) {
+        if (!limit_stream && !limit_total) return;
+        for (;;) {
+            size_t total = extra, mine = extra;
+            for (auto &b : blocks) {
+                total += b.bytes;
+                if (dev >= 0 && b.device == dev && b.stream == s) mine += b.bytes;
+            }
+            Block *victim = nullptr;
+            if (limit_total && total > limit_total) {
+                for (auto &b : blocks)
+                    if (!b.in_use && b.ptr && (!victim || b.last_use < victim->last_use)) victim = &b;
+            }
+            if (!victim && limit_stream) {
+                // any (device, stream) owner over its own limit gives up its oldest idle block
+                for (auto &b : blocks) {
+                    if (b.in_use || !b.ptr) continue;
+                    size_t own = (dev >= 0 && b.device == dev && b.stream == s) ? extra : 0;
+                    for (auto &o : blocks)
+                        if (o.device == b.device && o.stream == b.stream) own += o.bytes;
+                    if (own > limit_stream && (!victim || b.last_use < victim->last_use)) victim = &b;
+                }
+            }
+            (void)mine;
+            if (!victim) return;
+            free_block_locked(*victim, stream_alive(victim->stream));
+            compact_locked();
+        }
+    }
+    void sweep_stale_locked(int dev);
 };
 // `wipe`: the block held secret-dependent data (decryption intermediates, which the reference keeps in
 // Zeroizing buffers, F/bfv/keys/secret_key.rs:198-226): it is cleared on its stream before it returns to the pool.
@@ -941,7 +1061,15 @@ struct Ksk {
     }
     uint32_t digit_arg() const { return (uint32_t)log_base | (lift_mode() << 8); }
     DevBuf<u64> c0, c0s, c1, c1s;  // [ndigits][Lk][N]
+    // Execution options of this handle (fhe_ksk_set_mode; read once per call, like Mul's):
+    //   mode      KS_AUTO: the engine picks per shape (ks_use_unfused); KS_FUSED: ks_fused_kernel / ks_fused_split_kernel;
+    //             KS_UNFUSED: batched digit transforms + streaming MAC (RNS digits only; decomposition keys stay fused);
+    //             KS_UNFUSED_SUB: the same with 8192-point sub-block tiles at N = 16384 as well
+    //   w_budget  bytes of transformed digit rows (W) one stage-A / stage-B launch pair may have in flight; 0 = default
+    std::atomic<int> mode{0};
+    std::atomic<size_t> w_budget{0};
 };
+enum : int { KS_AUTO = 0, KS_FUSED = 1, KS_UNFUSED = 2, KS_UNFUSED_SUB = 3 };
 
 inline void ksk_validate(const Ctx &ct_ctx, const Ctx &ksk_ctx, size_t ndigits, size_t log_base) {
     require(ct_ctx.n == ksk_ctx.n, E_DEGREE_MISMATCH, "DegreeMismatch");
@@ -1094,6 +1222,106 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     (void)rns;
 }
 
+// ---- unfused key switch (kernels_ks.hpp: ks_ntt_kernel + ks_mac_kernel) ----
+// Default W budget.  Measured (profiles/r04_ks_unfused_ab.txt): keeping W on-die does not pay -- launch pairs cut to
+// 64 ... 256 MiB of W run 8-30 % slower than one pair over the whole batch (the cut launches are small, and stage B
+// streams at 3.4 TB/s either way) -- so the budget only bounds the scratch block.
+constexpr size_t KS_W_BUDGET_DEFAULT = (size_t)4 << 30;
+// Which shapes take the unfused path when the handle says KS_AUTO.  Measured on the MI355X, same process, alternating
+// (profiles/r04_ks_unfused_ab.txt; key-switch kernel time per launch, fused vs unfused stage A + stage B):
+//   C5  N = 32768, 16 moduli, 16 polynomials   1.198 ms   vs 0.809 + 0.345 = 1.154 ms   (inside the multiply: 3.25 vs 3.33 ms per step)
+//   C5  the same, 64 polynomials                4.713 ms   vs 3.396 + 1.308 = 4.704 ms
+//   C3  N = 16384,  8 moduli, 512 polynomials   3.545 ms   vs 2.802 + 1.492 = 4.294 ms   (8192-point tiles: 3.34 + 1.46)
+//   C2  N =  8192,  4 moduli, 1024 polynomials  0.831 ms   vs 0.553 + 0.420 = 0.973 ms
+// Stage A runs at the NTT kernels' rate (20 M 8192-point tiles/s with the two folded stages, 26 M without), but W
+// -- L * Lk rows per polynomial, 1 GiB at C5 / 16 -- costs stage B what the transforms gained: a tie at N = 32768, a
+// loss below.  KS_AUTO therefore stays on the fused kernels at every size; the unfused path remains selectable per
+// handle (and is parity-tested at every size) for hosts whose shapes differ (many digits, few key moduli).
+inline bool ks_use_unfused(const Ksk &k_, int mode) {
+    if (k_.log_base != 0) return false;                 // base-2^k digits of one row: the fused loader extracts them
+    if (mode == KS_UNFUSED || mode == KS_UNFUSED_SUB) return true;
+    if (mode == KS_FUSED) return false;
+    return k_.ksk_ctx->logn >= (size_t)FHE_LAB_INT("KS_UNFUSED_MIN_LOGN", 99);
+}
+template <int LOGM, int G0>
+inline void launch_ks_ntt(const Ksk &k_, bool narrow, bool rns, unsigned grid, hipStream_t s, const u64 *p, u64 p_stride,
+                          u64 *w, uint32_t j0, uint32_t jg, uint32_t skip_own) {
+    const Ctx &kc = *k_.ksk_ctx;
+    const size_t lds = k::lds_words(1u << LOGM) * sizeof(u64);
+#define FHE_KSN(NW, RNS)                                                                                         \
+    allow_big_lds((k::ks_ntt_kernel<LOGM, G0, NW, RNS>), lds);                                                   \
+    FHE_LAUNCH("ks_digit_ntt", (k::ks_ntt_kernel<LOGM, G0, NW, RNS>), dim3(grid), dim3(k::ntt_threads_c(LOGM)), \
+               lds, s, p, p_stride, w, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, j0, jg, k_.digit_arg(), skip_own)
+    if constexpr (LOGM >= 12) {
+        if (rns) {
+            if (narrow) { FHE_KSN(true, true); } else { FHE_KSN(false, true); }
+            return;
+        }
+    }
+    if (narrow) { FHE_KSN(true, false); } else { FHE_KSN(false, false); }
+#undef FHE_KSN
+    (void)rns;
+}
+inline void key_switch_polys_unfused(const Ksk &k_, int mode, const u64 *p, u64 p_stride, u64 *o0, u64 *o1,
+                                     u64 out_stride, const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys,
+                                     hipStream_t s, const u64 *xhat, u64 xhat_stride) {
+    const Ctx &kc = *k_.ksk_ctx;
+    const size_t N = kc.n, nd = k_.ndigits, Lk = kc.L;
+    const uint32_t logn = (uint32_t)kc.logn;
+    // tile geometry of stage A: whole rows up to 16384 points, 8192-point sub-blocks above (and at 16384 on request)
+    const uint32_t logm = logn > 14 ? 13 : (logn == 14 && mode == KS_UNFUSED_SUB) ? 13 : logn;
+    const uint32_t g0 = logn - logm;
+    bool narrow = !FHE_LAB_FLAG("NO_NARROW");
+    for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
+    const bool rns = k_.digit_arg() == (1u << 8);
+    // W = [pc][nd][jg][N]: groups of jg key moduli over chunks of pc polynomials, as large as the budget allows
+    // (key-modulus groups are cut first: a group's key slice is then still read once per launch pair)
+    size_t budget = k_.w_budget.load(std::memory_order_relaxed);
+    if (!budget) budget = KS_W_BUDGET_DEFAULT;
+    const size_t row_bytes = N * sizeof(u64);
+    size_t pc = npolys, jg = Lk;
+    if (pc * nd * jg * row_bytes > budget) {
+        jg = std::max<size_t>(1, budget / (pc * nd * row_bytes));
+        if (jg > Lk) jg = Lk;
+        if (pc * nd * jg * row_bytes > budget) pc = std::max<size_t>(1, budget / (nd * jg * row_bytes));
+    }
+    // (equal groups / chunks: no small tail launch)
+    jg = (Lk + ((Lk + jg - 1) / jg) - 1) / ((Lk + jg - 1) / jg);
+    pc = (npolys + ((npolys + pc - 1) / pc) - 1) / ((npolys + pc - 1) / pc);
+    WsGuard w(pc * nd * jg * row_bytes, s);
+    const uint32_t skip_own = xhat != nullptr ? 1u : 0u;
+    for (size_t b0 = 0; b0 < npolys; b0 += pc) {
+        const size_t nb = std::min(pc, npolys - b0);
+        for (size_t j0 = 0; j0 < Lk; j0 += jg) {
+            const size_t njg = std::min(jg, Lk - j0);
+            const unsigned grid_a = (unsigned)((nb * nd * njg) << g0);
+            const u64 *pp = p + b0 * p_stride;
+#define FHE_KSN_CASE(LM)                                                                                         \
+    case LM: launch_ks_ntt<LM, 0>(k_, narrow, rns, grid_a, s, pp, p_stride, w.u(), (uint32_t)j0, (uint32_t)njg, skip_own); break;
+            if (g0 == 0) {
+                switch (logm) {
+                    FHE_KSN_CASE(3) FHE_KSN_CASE(4) FHE_KSN_CASE(5) FHE_KSN_CASE(6) FHE_KSN_CASE(7) FHE_KSN_CASE(8)
+                    FHE_KSN_CASE(9) FHE_KSN_CASE(10) FHE_KSN_CASE(11) FHE_KSN_CASE(12) FHE_KSN_CASE(13) FHE_KSN_CASE(14)
+                    default: throw StatusError(E_ARG, "unsupported key-switch row size");
+                }
+            } else if (g0 == 1) {
+                launch_ks_ntt<13, 1>(k_, narrow, rns, grid_a, s, pp, p_stride, w.u(), (uint32_t)j0, (uint32_t)njg, skip_own);
+            } else if (g0 == 2) {
+                launch_ks_ntt<13, 2>(k_, narrow, rns, grid_a, s, pp, p_stride, w.u(), (uint32_t)j0, (uint32_t)njg, skip_own);
+            } else {
+                launch_ks_ntt<13, 3>(k_, narrow, rns, grid_a, s, pp, p_stride, w.u(), (uint32_t)j0, (uint32_t)njg, skip_own);
+            }
+#undef FHE_KSN_CASE
+            const uint32_t cpr = N >= 512 ? (uint32_t)(N / 512) : 1u;
+            const unsigned grid_b = (unsigned)((((njg * cpr) + 7) / 8) * nb * 8);
+            FHE_LAUNCH("ks_mac", k::ks_mac_kernel, dim3(grid_b), dim3(256), 0, s, w.u(), o0 + b0 * out_stride,
+                       o1 + b0 * out_stride, out_stride, a0 ? a0 + b0 * a_stride : nullptr, a1 ? a1 + b0 * a_stride : nullptr,
+                       a_stride, k_.c0.p, k_.c1.p, kc.dmods(), (uint32_t)nd, (uint32_t)Lk, (uint32_t)j0, (uint32_t)njg, logn,
+                       xhat ? xhat + b0 * xhat_stride : nullptr, xhat_stride, (uint32_t)nb);
+        }
+    }
+}
+
 // KeySwitchingKey::key_switch (:241-320): p [npolys][L][N] PowerBasis (poly stride p_stride) ->
 // o0,o1 [npolys][Lk][N] Ntt over ksk_ctx (poly stride out_stride).  If a0/a1 are given (and the
 // key lives at the ciphertext level) the result is added to them on the fly.
@@ -1107,6 +1335,13 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     const Ctx &kc = *k_.ksk_ctx;
     kc.need_device();
     if (!npolys) return;
+    {
+        const int mode = k_.mode.load(std::memory_order_relaxed);
+        if (ks_use_unfused(k_, mode)) {
+            key_switch_polys_unfused(k_, mode, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride);
+            return;
+        }
+    }
     // N = 16384: whole-row kernel (1024 threads x 16 coefficients, 24 VGPRs spilled) or two 8192-point sub-blocks
     // with the first stage folded into the loader (FHE_KS_SPLIT14=1)
     static const bool split14 = FHE_LAB_INT("KS_SPLIT14", 0) != 0;
@@ -1433,11 +1668,14 @@ public:
         static AuxStreams a;
         return a;
     }
-    hipStream_t stream_for(int device, hipStream_t user) {
+    // `tag_key`: `user` is not a stream but the address of a static tag (host_sliced's three internal streams): such
+    // keys are never probed with hipStreamQuery
+    hipStream_t stream_for(int device, hipStream_t user, bool tag_key = false) {
         std::lock_guard<std::mutex> lk(mu);
-        hipStream_t &a = reg[{device, user}];
-        if (!a) FHE_HIP_CHECK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
-        return a;
+        Entry &a = reg[{device, user}];
+        if (!a.aux) FHE_HIP_CHECK(hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking));
+        a.tag_key = tag_key;
+        return a.aux;
     }
     hipEvent_t take_event() {
         {
@@ -1457,14 +1695,18 @@ public:
         pool.push_back(e);
     }
     // the internal stream that shadows `user` on `device` (device < 0: on any device; all: every internal stream and the
-    // pooled events as well) is synchronised and destroyed
-    void drop(int device, hipStream_t user, bool all) {
+    // pooled events as well) is synchronised and destroyed; returns the destroyed internal handles, whose scratch
+    // blocks the caller hands back (Workspace::drop_internal_stream) -- ADVICE r03: they used to stay in the pool
+    // under a handle that no longer existed
+    std::vector<hipStream_t> drop(int device, hipStream_t user, bool all) {
+        std::vector<hipStream_t> gone;
         std::lock_guard<std::mutex> lk(mu);
         for (auto it = reg.begin(); it != reg.end();) {
             if (all || ((device < 0 || it->first.first == device) && it->first.second == user)) {
-                if (it->second) {
-                    (void)hipStreamSynchronize(it->second);
-                    (void)hipStreamDestroy(it->second);
+                if (it->second.aux) {
+                    (void)hipStreamSynchronize(it->second.aux);
+                    (void)hipStreamDestroy(it->second.aux);
+                    gone.push_back(it->second.aux);
                 }
                 it = reg.erase(it);
             } else {
@@ -1475,13 +1717,86 @@ public:
             for (hipEvent_t e : pool) (void)hipEventDestroy(e);
             pool.clear();
         }
+        return gone;
+    }
+    // internal streams whose user stream no longer exists
+    std::vector<hipStream_t> drop_stale(int device) {
+        std::vector<hipStream_t> gone;
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto it = reg.begin(); it != reg.end();) {
+            if (it->first.first == device && !it->second.tag_key && !stream_alive(it->first.second)) {
+                if (it->second.aux) {
+                    (void)hipStreamSynchronize(it->second.aux);
+                    (void)hipStreamDestroy(it->second.aux);
+                    gone.push_back(it->second.aux);
+                }
+                it = reg.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        return gone;
+    }
+    bool is_internal(hipStream_t s) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &kv : reg)
+            if (kv.second.aux == s) return true;
+        return false;
     }
 
 private:
+    struct Entry {
+        hipStream_t aux = nullptr;
+        bool tag_key = false;
+    };
     std::mutex mu;
-    std::map<std::pair<int, hipStream_t>, hipStream_t> reg;
+    std::map<std::pair<int, hipStream_t>, Entry> reg;
     std::vector<hipEvent_t> pool;
 };
+
+// (defined here: they need AuxStreams)
+inline void Workspace::sweep_stale_locked(int dev) {
+    // internal streams of user streams that are gone, then the blocks of those internal streams and of the dead
+    // user streams themselves
+    std::vector<hipStream_t> gone = AuxStreams::get().drop_stale(dev);
+    std::vector<hipStream_t> owners;
+    for (auto &b : blocks)
+        if (b.device == dev && !b.in_use && b.stream && std::find(owners.begin(), owners.end(), b.stream) == owners.end())
+            owners.push_back(b.stream);
+    for (hipStream_t t : owners) {
+        const bool was_internal = std::find(gone.begin(), gone.end(), t) != gone.end();
+        if (was_internal || (!AuxStreams::get().is_internal(t) && !stream_alive(t))) drop_stream_locked(t, false);
+    }
+}
+inline void *Workspace::acquire(size_t bytes, hipStream_t s) {
+    int dev = 0;
+    FHE_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    Block *best = nullptr;
+    for (auto &b : blocks)
+        if (!b.in_use && b.device == dev && b.stream == s && b.bytes >= bytes && (!best || b.bytes < best->bytes))
+            best = &b;
+    if (!best) {
+        // growing.  Idle blocks of this (device, stream) that are too small go back to the pool in stream order (the
+        // allocation below may reuse their memory, ordered behind whatever still reads them), dead streams' blocks
+        // go, the limits are enforced, then the new block is taken from the device's pool on this stream.
+        for (auto &b : blocks)
+            if (!b.in_use && b.device == dev && b.stream == s && b.ptr) free_block_locked(b, true);
+        compact_locked();
+        sweep_stale_locked(dev);
+        enforce_limits_locked(s, dev, bytes);
+        Block nb;
+        nb.ptr = DevPools::get().alloc(dev, bytes, s);
+        nb.bytes = bytes ? bytes : 8;
+        nb.stream = s;
+        nb.device = dev;
+        blocks.push_back(nb);
+        best = &blocks.back();
+    }
+    best->in_use = true;
+    best->last_use = ++tick;
+    return best->ptr;
+}
 
 // How a batch is cut into chunks, and whether the chunks alternate between two streams.
 // One stream: every launch should cover >> 512 workgroup slots (64-pair chunks are 15 % slower at C2), but beyond

@@ -149,8 +149,12 @@ static bool host_sliced(int dev, size_t batch, const std::vector<HostIn> &ins, u
     if (batch < 3 * slice) return false;
     static char tag_up, tag_comp, tag_down;   // keys of the three internal streams (no user stream has these addresses)
     AuxStreams &ax = AuxStreams::get();
-    hipStream_t s_up = ax.stream_for(dev, (hipStream_t)&tag_up), s_comp = ax.stream_for(dev, (hipStream_t)&tag_comp),
-                s_down = ax.stream_for(dev, (hipStream_t)&tag_down);
+    hipStream_t s_up = ax.stream_for(dev, (hipStream_t)&tag_up, true), s_comp = ax.stream_for(dev, (hipStream_t)&tag_comp, true),
+                s_down = ax.stream_for(dev, (hipStream_t)&tag_down, true);
+    // The staging blocks below come from the pool's NULL-stream blocks, which count as idle as soon as the call that
+    // used them has returned -- but an asynchronous `_dev` call on the null stream may still be running in them, and
+    // the three internal streams are non-blocking: they do not order against the null stream by themselves.
+    FHE_HIP_CHECK(hipStreamSynchronize(nullptr));
     HostIO io;
     std::vector<u64 *> din(ins.size(), nullptr);
     for (size_t k = 0; k < ins.size(); k++) {
@@ -273,29 +277,9 @@ fhe_status fhe_buf_free(void *buf) {
         if (buf) FHE_HIP_CHECK(hipFree(buf));
     });
 }
-// The default memory pool of a device is told once to keep what is freed into it (release threshold: everything), so
-// that a host which allocates its results per call does not go back to the driver each time.
-static std::mutex g_pool_mu;
-static std::vector<char> g_pool_kept;   // devices whose default pool this library told to keep its blocks
-static void keep_default_pool(int device) {
-    std::lock_guard<std::mutex> g(g_pool_mu);
-    if ((size_t)device >= g_pool_kept.size()) g_pool_kept.resize((size_t)device + 1, 0);
-    if (g_pool_kept[(size_t)device]) return;
-    hipMemPool_t pool;
-    FHE_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device));
-    uint64_t keep = ~0ull;
-    FHE_HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-    g_pool_kept[(size_t)device] = 1;
-}
-// fhe_workspace_trim: hand the pools' idle blocks back to the driver as well
-static void trim_default_pools() {
-    std::lock_guard<std::mutex> g(g_pool_mu);
-    for (size_t d = 0; d < g_pool_kept.size(); d++) {
-        if (!g_pool_kept[d]) continue;
-        hipMemPool_t pool;
-        if (hipDeviceGetDefaultMemPool(&pool, (int)d) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
-    }
-}
+// fhe_buf_alloc_async takes its memory from the device's PRIVATE stream-ordered pool (DevPools, engine.hpp), which is
+// told to keep what is freed into it -- a host that allocates its results per call does not go back to the driver
+// each time, and no other hipMallocAsync user of the process sees a changed default pool.
 fhe_status fhe_buf_alloc_async(int device, size_t bytes, void *stream, void **out) {
     return guard([&] {
         need(out, "out");
@@ -304,8 +288,7 @@ fhe_status fhe_buf_alloc_async(int device, size_t bytes, void *stream, void **ou
         FHE_HIP_CHECK(hipGetDeviceCount(&ndev));
         require(device >= 0 && device < ndev, E_NO_DEVICE, "no such HIP device");
         FHE_HIP_CHECK(hipSetDevice(device));
-        keep_default_pool(device);
-        FHE_HIP_CHECK(hipMallocAsync(out, std::max<size_t>(bytes, 1), as_stream(stream)));
+        *out = DevPools::get().alloc(device, std::max<size_t>(bytes, 1), as_stream(stream));
     });
 }
 fhe_status fhe_buf_free_async(void *buf, void *stream) {
@@ -376,7 +359,9 @@ fhe_status fhe_stream_destroy(void *stream) {
         if (!stream) return;   // the null stream is not ours to destroy
         FHE_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
         // what the engine keeps per caller stream: its internal second stream and its idle scratch blocks
-        AuxStreams::get().drop(-1, as_stream(stream), false);
+        // (the internal stream's own blocks too -- a ChunkWs and the split-extension scratch are keyed to it: ADVICE r03)
+        for (hipStream_t aux : AuxStreams::get().drop(-1, as_stream(stream), false))
+            Workspace::get().drop_internal_stream(aux);
         Workspace::get().drop_stream(as_stream(stream));
         FHE_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
     });
@@ -987,6 +972,21 @@ fhe_status fhe_ksk_create_dev(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, siz
     });
 }
 void fhe_ksk_destroy(fhe_ksk *k_) { delete k_; }
+fhe_status fhe_ksk_set_mode(fhe_ksk *k_, int mode, size_t w_budget) {
+    return guard([&] {
+        need(k_, "ksk");
+        require(mode >= KS_AUTO && mode <= KS_UNFUSED_SUB, E_ARG, "mode must be one of FHE_KS_AUTO ... FHE_KS_UNFUSED_SUB");
+        k_->k->mode.store(mode, std::memory_order_relaxed);
+        k_->k->w_budget.store(w_budget, std::memory_order_relaxed);
+    });
+}
+fhe_status fhe_ksk_get_mode(const fhe_ksk *k_, int *mode, size_t *w_budget) {
+    return guard([&] {
+        need(k_, "ksk");
+        if (mode) *mode = k_->k->mode.load(std::memory_order_relaxed);
+        if (w_budget) *w_budget = k_->k->w_budget.load(std::memory_order_relaxed);
+    });
+}
 
 fhe_status fhe_key_switch_dev(const fhe_ksk *k_, const uint64_t *p, uint64_t *c0_out, uint64_t *c1_out, size_t batch,
                               void *stream) {
@@ -1710,9 +1710,20 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
     });
 }
 size_t fhe_workspace_trim(void) {
-    AuxStreams::get().drop(-1, nullptr, true);   // internal streams and pooled events go too (recreated on demand)
-    trim_default_pools();                        // idle blocks of fhe_buf_alloc_async's pools
-    return Workspace::get().trim();
+    for (hipStream_t aux : AuxStreams::get().drop(-1, nullptr, true))   // internal streams and pooled events go too
+        Workspace::get().drop_internal_stream(aux);                      // (recreated on demand)
+    const size_t freed = Workspace::get().trim();
+    DevPools::get().trim();                      // what the private pools kept (scratch blocks, fhe_buf_alloc_async)
+    return freed;
+}
+fhe_status fhe_workspace_set_limit(size_t per_stream_bytes, size_t total_bytes) {
+    return guard([&] { Workspace::get().set_limits(per_stream_bytes, total_bytes); });
+}
+fhe_status fhe_workspace_get_limit(size_t *per_stream_bytes, size_t *total_bytes) {
+    return guard([&] { Workspace::get().get_limits(per_stream_bytes, total_bytes); });
+}
+fhe_status fhe_workspace_stats(size_t *held_bytes, size_t *in_use_bytes, size_t *blocks, size_t *owners) {
+    return guard([&] { Workspace::get().stats(held_bytes, in_use_bytes, blocks, owners); });
 }
 fhe_status fhe_ubench_int(int device, int which, double min_seconds, double *ops_per_s) {
     return guard([&] {

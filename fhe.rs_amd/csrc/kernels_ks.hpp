@@ -461,5 +461,158 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
     }
 }
 
+// ------------------------------------------------------------ unfused key switch ----
+// The same sum as ks_fused_kernel, cut into two launches (round 4; F/bfv/keys/key_switching_key.rs:241-320 with the
+// lazy accumulation pattern of F/bfv/ops/dot_product.rs:54-180):
+//   stage A  ks_ntt_kernel:  W[b][i][jj][:] = NTT_{q_j}( [p_i]_{q_j} ),  j = j0 + jj   (one workgroup per row tile)
+//   stage B  ks_mac_kernel:  (c0, c1)[b][j] (+)= sum_i W[b][i][jj] (.) (k0, k1)[i][j]  (one lane per coefficient pair)
+// Why: the fused kernel holds two accumulator sets next to its transform, which forces 8 coefficients per thread,
+// radix-8/4 passes and ONE workgroup per CU (N >= 8192); stage A is the plain NTT geometry instead (16 coefficients
+// per thread, radix-16 passes, two workgroups per CU at 8192-point tiles), and stage B is a streaming kernel that
+// multiplies 64 x 64 -> 128 bits into lazy 128-bit accumulators with ONE reduction per output -- no Shoup twins, so
+// only half of the key's bytes are read.  The price is W: L * Lk rows per polynomial written and read once, which the
+// host keeps small enough to stay on-die (groups of key moduli / of polynomials, engine.hpp).
+//
+// ks_ntt_kernel<LOGM, G0>: tile of 2^LOGM points; G0 > 0: the row has 2^(LOGM+G0) points and the first G0
+// Cooley-Tukey stages are folded into the loader exactly as in ks_fused_split_kernel.
+// Output range: NARROW (key moduli below 2^60) values below 4p < 2^62, otherwise canonical: both below 2^62, which
+// is what stage B's four-multiply product (mul_wide62) takes.
+template <int LOGM, int G0, bool NARROW, bool RNS>
+__global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
+    ks_ntt_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ w, const DevMod *__restrict__ mods,
+                  const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t j0, uint32_t jg, uint32_t digit_arg,
+                  uint32_t skip_own) {
+    FHE_DYN_SMEM(u64, lds);
+    constexpr int T = ntt_threads_c(LOGM);
+    constexpr int M = 1 << LOGM, NS = 1 << G0;
+    constexpr int CH = tile_chunks_c(LOGM, T);
+    constexpr u64 N = (u64)M << G0;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t sub = blockIdx.x & (NS - 1);
+    const uint32_t rowb = blockIdx.x >> G0;                       // (b * ndigits + i) * jg + jj
+    const uint32_t bi = to_sgpr(rowb / jg), jj = rowb - bi * jg, j = j0 + jj;
+    const uint32_t b = to_sgpr(bi / ndigits), i = bi - b * ndigits;
+    // (block-uniform) digit j under key modulus j is the caller's Ntt-form row (`xhat`): stage B reads it there
+    if (skip_own && i == j) return;
+    const DevMod md = mods[j];
+    const u64 p = md.p, p2 = md.p2;
+    const PM pm = make_pm(md);
+    const u64x2 *twr = tw + (u64)j * N;
+    const uint32_t digit_shift_bits = digit_arg & 0xff, lift_mode = digit_arg >> 8;  // see ks_fused_kernel
+    const uint32_t sh = i * digit_shift_bits;
+    const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+    auto lift = [&](u64 v) -> u64 {
+        if constexpr (RNS) return csub_n(v, p, pm.np);
+        v = (v >> sh) & mask;
+        if (lift_mode == 1) return csub_n(v, p, pm.np);
+        if (lift_mode == 2) return csub_n(csub_n(v, p2, pm.np2), p, pm.np);
+        return reduce_u64(v, md);
+    };
+    const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N) + (G0 ? 0 : (u64)sub * M);
+    auto load = [&](uint32_t idx, uint32_t) -> u64 {
+        if constexpr (G0 == 0) {
+            return lift(src[idx]);
+        } else {
+            u64 v[NS];
+#pragma unroll
+            for (int k = 0; k < NS; k++) v[k] = lift(src[idx + (u64)k * M]);
+#pragma unroll
+            for (int st = 0; st < G0; st++) {   // stage st keeps the half of the pairs whose output leads to `sub`
+                const int half = NS >> (st + 1);
+                const u64x2 wv = twr[(1u << st) + (sub >> (G0 - st))];
+                const bool minus = (sub >> (G0 - st - 1)) & 1;   // (uniform over the workgroup)
+                if (minus) {
+#pragma unroll
+                    for (int m = 0; m < half; m++)
+                        v[m] = csub_n(v[m], p2, pm.np2) + p2 - mul_shoup_lazy_n<true>(v[m + half], wv.x, wv.y, pm.np);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < half; m++)
+                        v[m] = mul_shoup_lazy_add_n<true>(csub_n(v[m], p2, pm.np2), v[m + half], wv.x, wv.y, pm.np);
+                }
+            }
+            return v[0];   // below 4p
+        }
+    };
+    ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? (G0 ? 4 : 1) : 0)>(lds, twr, NS + sub, pm, tid, load);
+    u64 *dst = w + (u64)rowb * N + (u64)sub * M;
+    if constexpr (NARROW) {   // below 16p -> below 4p
+        const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
+        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(csub_n(v, p8, np8), p4, np4); });
+    } else {                  // below 4p -> canonical
+        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return csub_n(csub_n(v, p2, pm.np2), p, pm.np); });
+    }
+}
+
+// Stage B.  One lane per 16-byte chunk of an output row (b, j); grid = (key range, polynomial) in an XCD-aware
+// order: the lanes of a block read nd * 2 * 4 KiB of key words that every polynomial of the launch needs again, so
+// the blocks of one key range get ids 8 apart (same XCD, dispatched back to back: the re-reads hit that L2).
+// Lazy accumulation: x < 2^62, k < 2^62 -> x * k < 2^124, sixteen terms fit 128 bits; longer digit loops fold the
+// accumulator through the 128-bit reduction every sixteen terms.
+__global__ void __launch_bounds__(256)
+    ks_mac_kernel(const u64 *__restrict__ w, u64 *__restrict__ out0, u64 *__restrict__ out1, u64 out_poly_stride,
+                  const u64 *__restrict__ addend0, const u64 *__restrict__ addend1, u64 addend_poly_stride,
+                  const u64 *__restrict__ k0, const u64 *__restrict__ k1, const DevMod *__restrict__ mods,
+                  uint32_t ndigits, uint32_t lk, uint32_t j0, uint32_t jg, uint32_t logn, const u64 *__restrict__ xhat,
+                  u64 xhat_poly_stride, uint32_t npolys) {
+    const uint32_t n = 1u << logn;
+    const uint32_t cpr = n >= 512 ? n / 512 : 1;          // 256-lane chunks per row
+    const uint32_t nkr = jg * cpr;                        // key ranges of this launch
+    const uint32_t grp = blockIdx.x >> 3, x8 = blockIdx.x & 7;
+    const uint32_t krhi = grp / npolys, b = grp - krhi * npolys;
+    const uint32_t kr = krhi * 8 + x8;
+    if (kr >= nkr) return;                                // (block-uniform) tail of the rounded-up grid
+    const uint32_t jj = kr / cpr, cb = kr - jj * cpr, j = j0 + jj;
+    const uint32_t ci = cb * 256 + threadIdx.x;           // 16-byte chunk inside the row
+    if (2 * ci >= n) return;
+    const DevMod md = mods[j];
+    const u64 roff = 2 * (u64)ci;
+    const u64 *wp = w + (((u64)b * ndigits) * jg + jj) * n + roff;      // + i * jg * n per digit
+    const u64 *kp0 = k0 + (u64)j * n + roff, *kp1 = k1 + (u64)j * n + roff;   // + i * lk * n per digit
+    const bool own = xhat != nullptr && j < ndigits;      // (block-uniform)
+    u128_t a0x = 0, a0y = 0, a1x = 0, a1y = 0;
+    auto mac = [&](u128_t &acc, u64 x, u64 k) {
+        u64 hi, lo;
+        mul_wide62(x, k, hi, lo);
+        acc += ((u128_t)hi << 64) | lo;
+    };
+    auto fold = [&](u128_t &acc) { acc = reduce_u128((u64)(acc >> 64), (u64)acc, md); };
+    for (uint32_t i0 = 0; i0 < ndigits; i0 += 16) {
+        const uint32_t i1 = i0 + 16 < ndigits ? i0 + 16 : ndigits;
+        if (i0) fold(a0x), fold(a0y), fold(a1x), fold(a1y);
+#pragma unroll 4
+        for (uint32_t i = i0; i < i1; i++) {
+            const u64x2 xv = (own && i == j)
+                                 ? *reinterpret_cast<const u64x2 *>(xhat + (u64)b * xhat_poly_stride + (u64)j * n + roff)
+                                 : *reinterpret_cast<const u64x2 *>(wp + (u64)i * jg * n);
+            const u64x2 q0 = *reinterpret_cast<const u64x2 *>(kp0 + (u64)i * lk * n);
+            const u64x2 q1 = *reinterpret_cast<const u64x2 *>(kp1 + (u64)i * lk * n);
+            mac(a0x, xv.x, q0.x);
+            mac(a0y, xv.y, q0.y);
+            mac(a1x, xv.x, q1.x);
+            mac(a1y, xv.y, q1.y);
+        }
+    }
+    u64x2 r0, r1;
+    r0.x = reduce_u128((u64)(a0x >> 64), (u64)a0x, md);
+    r0.y = reduce_u128((u64)(a0y >> 64), (u64)a0y, md);
+    r1.x = reduce_u128((u64)(a1x >> 64), (u64)a1x, md);
+    r1.y = reduce_u128((u64)(a1y >> 64), (u64)a1y, md);
+    const u64 ooff = (u64)b * out_poly_stride + (u64)j * n + roff;
+    const u64 aoff = (u64)b * addend_poly_stride + (u64)j * n + roff;
+    if (addend0) {
+        const u64x2 a = *reinterpret_cast<const u64x2 *>(addend0 + aoff);
+        r0.x = add_mod(r0.x, a.x, md.p);
+        r0.y = add_mod(r0.y, a.y, md.p);
+    }
+    if (addend1) {
+        const u64x2 a = *reinterpret_cast<const u64x2 *>(addend1 + aoff);
+        r1.x = add_mod(r1.x, a.x, md.p);
+        r1.y = add_mod(r1.y, a.y, md.p);
+    }
+    *reinterpret_cast<u64x2 *>(out0 + ooff) = r0;
+    *reinterpret_cast<u64x2 *>(out1 + ooff) = r1;
+}
+
 }  // namespace k
 }  // namespace fhe

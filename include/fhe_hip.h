@@ -84,8 +84,8 @@ int fhe_device_count(void);
  *    second stream and idle scratch blocks).  Handles (contexts, keys ...) are not tied to a stream. */
 fhe_status fhe_buf_alloc(int device, size_t bytes, void **out);      /* hipMalloc on `device`           */
 fhe_status fhe_buf_free(void *buf);                                   /* NULL is a no-op                  */
-/* Stream-ordered twins (hipMallocAsync / hipFreeAsync on the device's default memory pool, which this library tells to
- * keep freed blocks): the block may be used by work enqueued on `stream` after the call, and a free takes effect
+/* Stream-ordered twins (hipMallocFromPoolAsync / hipFreeAsync on a memory pool PRIVATE to this library, one per device,
+ * told to keep freed blocks -- the device's default pool is left alone): the block may be used by work enqueued on `stream` after the call, and a free takes effect
  * behind the work already enqueued on `stream` -- no device synchronisation, unlike hipMalloc / hipFree.  Using the
  * block on another stream needs the caller's own ordering (events).  fhe_buf_free also accepts such a block (and waits);
  * fhe_buf_free_async is for blocks from fhe_buf_alloc_async only.  fhe_workspace_trim returns the pool's idle blocks. */
@@ -236,6 +236,21 @@ fhe_status fhe_ksk_create(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, size_t 
 fhe_status fhe_ksk_create_dev(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, size_t ndigits, const uint64_t *c0,
                               const uint64_t *c1, size_t log_base, void *stream, fhe_ksk **out);
 void fhe_ksk_destroy(fhe_ksk *k);
+/* Execution options of every key switch through this handle (key_switch, relinearise, Galois, RGSW, the relinearise
+ * step of fhe_bfv_mul), kept on the handle like fhe_mul's: atomics read once per call; they only choose how the sum
+ * of KeySwitchingKey::key_switch (F/bfv/keys/key_switching_key.rs:241-320) is evaluated, never its value.
+ *   mode     FHE_KS_AUTO (default): the engine picks per shape; FHE_KS_FUSED: one kernel per (ciphertext, key modulus)
+ *            that transforms the digits in LDS and multiplies them into register accumulators (Shoup twins);
+ *            FHE_KS_UNFUSED: the digit transforms of a launch as one batched NTT into scratch, then a streaming
+ *            multiply-accumulate with lazy 128-bit sums (the pattern of F/bfv/ops/dot_product.rs:54-180) that reads
+ *            the key without its twins; FHE_KS_UNFUSED_SUB: the same on 8192-point sub-block tiles at N = 16384 too.
+ *            Decomposition keys (log_base != 0) always take the fused kernel.
+ *   w_budget bytes of transformed digit rows one launch pair may have in flight (0 = default, 4 GiB).
+ * Measured on the MI355X (profiles/r04_ks_unfused_ab.txt) the two strategies tie at N = 32768 and the fused one wins
+ * below, so FHE_KS_AUTO currently means FHE_KS_FUSED at every size. */
+enum { FHE_KS_AUTO = 0, FHE_KS_FUSED = 1, FHE_KS_UNFUSED = 2, FHE_KS_UNFUSED_SUB = 3 };
+fhe_status fhe_ksk_set_mode(fhe_ksk *k, int mode, size_t w_budget);
+fhe_status fhe_ksk_get_mode(const fhe_ksk *k, int *mode, size_t *w_budget);
 /* KeySwitchingKey::key_switch / key_switch_assign (:241-320): p [batch][L][N] PowerBasis over
  * ct_ctx -> c0_out, c1_out [batch][Lk][N] Ntt over ksk_ctx. */
 fhe_status fhe_key_switch(const fhe_ksk *k, const uint64_t *p, uint64_t *c0_out, uint64_t *c1_out, size_t batch);
@@ -433,6 +448,17 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
  * streams and a few pooled events between calls; this frees every idle one (call it while no engine call is
  * running) and returns the number of scratch bytes released. */
 size_t fhe_workspace_trim(void);
+/* Bounds on what the engine RETAINS between calls (0 = no bound, the default): `per_stream_bytes` for the scratch
+ * blocks keyed to one (device, stream), `total_bytes` over all of them.  Idle blocks beyond a bound are evicted
+ * least-recently-used first, when a block is released and before a stream's block grows; blocks in use are never
+ * refused (a call that needs more than the bound runs, its blocks are not kept afterwards).  Independently of any
+ * bound, scratch that belongs to streams which no longer exist -- a host that creates and destroys its own HIP streams
+ * never tells the engine -- is dropped the next time any stream's block has to grow.  Scratch blocks come from the
+ * private stream-ordered pool and return to it in stream order: growing does not synchronise the device.
+ * fhe_workspace_stats: bytes held (idle + in use), bytes in use, blocks, distinct (device, stream) owners. */
+fhe_status fhe_workspace_set_limit(size_t per_stream_bytes, size_t total_bytes);
+fhe_status fhe_workspace_get_limit(size_t *per_stream_bytes, size_t *total_bytes);
+fhe_status fhe_workspace_stats(size_t *held_bytes, size_t *in_use_bytes, size_t *blocks, size_t *owners);
 /* Integer-issue ceiling ("report both ceilings"): register-resident loops of the instructions /
  * butterflies the NTT-type kernels are made of, chip-wide, no memory traffic, run for at least min_seconds
  * (0 < min_seconds <= 10).  which: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32, 3 lazy Shoup product,

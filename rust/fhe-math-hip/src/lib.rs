@@ -467,6 +467,63 @@ impl HipKsk {
         })?;
         Ok(out)
     }
+    /// `EvaluationKey::computes_inner_sum` on a device-resident batch (`fhe_bfv_inner_sum_dev`): `keys[i]` is the
+    /// Galois key of element `exponents[i]`, in the reference's order (evaluation_key.rs:56-100).
+    pub fn inner_sum_dev(keys: &[Arc<HipKsk>], exponents: &[usize], ct: &DeviceCiphertexts, stream: &Stream) -> Result<DeviceCiphertexts> {
+        let first = keys.first().ok_or_else(|| shape_error("inner_sum_dev: no Galois keys"))?;
+        if keys.len() != exponents.len() {
+            return Err(shape_error("inner_sum_dev: one exponent per Galois key"));
+        }
+        first.check_resident("inner_sum_dev", ct, 2)?;
+        let ptrs: Vec<*const ffi::FheKsk> = keys.iter().map(|k| k.as_ptr()).collect();
+        let out = DeviceCiphertexts::alloc_on(first.ct_ctx.device(), ct.batch, 2, ct.rows, ct.degree, ct.level, stream)?;
+        check(unsafe {
+            ffi::fhe_bfv_inner_sum_dev(ptrs.as_ptr(), exponents.as_ptr(), keys.len(), ct.buf.as_ptr(), out.buf.as_mut_ptr(),
+                                       ct.batch, stream.as_ptr())
+        })?;
+        Ok(out)
+    }
+    /// `EvaluationKey::expands` on a device-resident batch (`fhe_bfv_expand_dev`): `keys[l]` is the Galois key of
+    /// element `(N >> l) + 1`.  The result has `size * ct.batch` ciphertexts laid out `[size][batch]`.
+    pub fn expand_dev(keys: &[Arc<HipKsk>], size: usize, ct: &DeviceCiphertexts, stream: &Stream) -> Result<DeviceCiphertexts> {
+        if size == 0 || size > ct.degree {
+            return Err(HipError { status: status::INVALID_EXPANSION_SIZE, message: format!("expand_dev: size {size}, degree {}", ct.degree) });
+        }
+        let device = match keys.first() {
+            Some(k) => {
+                k.check_resident("expand_dev", ct, 2)?;
+                k.ct_ctx.device()
+            }
+            None if size == 1 => default_device(),
+            None => return Err(HipError { status: status::EXPANSION_UNSUPPORTED, message: "expand_dev: no Galois keys".into() }),
+        };
+        let out = DeviceCiphertexts::alloc_on(device, size * ct.batch, 2, ct.rows, ct.degree, ct.level, stream)?;
+        if keys.is_empty() {   // size 1: the expansion is the ciphertext itself
+            check(unsafe {
+                ffi::fhe_buf_copy_async(out.buf.as_mut_ptr() as *mut c_void, ct.buf.as_ptr() as *const c_void, ct.buf.len() * 8, stream.as_ptr())
+            })?;
+            return Ok(out);
+        }
+        let ptrs: Vec<*const ffi::FheKsk> = keys.iter().map(|k| k.as_ptr()).collect();
+        check(unsafe {
+            ffi::fhe_bfv_expand_dev(ptrs.as_ptr(), keys.len(), ct.buf.as_ptr(), out.buf.as_mut_ptr(), size, ct.batch, stream.as_ptr())
+        })?;
+        Ok(out)
+    }
+    /// How the engine evaluates every key switch through this key (`fhe_ksk_set_mode`): [`KsMode`]; `w_budget` bytes of
+    /// transformed digit rows per launch pair of the unfused strategy (0 = default).  Values never change, only speed.
+    pub fn set_mode(&self, mode: KsMode, w_budget: usize) -> Result<()> {
+        check(unsafe { ffi::fhe_ksk_set_mode(self.ptr, mode as c_int, w_budget) })
+    }
+}
+/// Key-switch evaluation strategies (`FHE_KS_*` of the header).
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+#[repr(i32)]
+pub enum KsMode {
+    Auto = 0,
+    Fused = 1,
+    Unfused = 2,
+    UnfusedSub = 3,
 }
 impl Drop for HipKsk {
     fn drop(&mut self) { unsafe { ffi::fhe_ksk_destroy(self.ptr) } }
@@ -608,6 +665,25 @@ impl HipParams {
 impl Drop for HipParams {
     fn drop(&mut self) { unsafe { ffi::fhe_params_destroy(self.ptr) } }
 }
+
+// ------------------------------------------------------------------------------------ engine-wide state
+/// Bounds on the scratch memory the engine retains between calls (`fhe_workspace_set_limit`; 0 = none): bytes per
+/// (device, stream) and in total.  Idle blocks beyond a bound are evicted least-recently-used first; calls that need
+/// more still run.  Scratch of streams that no longer exist is dropped by the engine on its own.
+pub fn workspace_set_limit(per_stream_bytes: usize, total_bytes: usize) -> Result<()> {
+    check(unsafe { ffi::fhe_workspace_set_limit(per_stream_bytes, total_bytes) })
+}
+/// (bytes held, bytes in use, blocks, distinct (device, stream) owners) of the engine's scratch pool.
+pub fn workspace_stats() -> Result<(usize, usize, usize, usize)> {
+    let (mut h, mut u, mut b, mut o) = (0usize, 0usize, 0usize, 0usize);
+    check(unsafe { ffi::fhe_workspace_stats(&mut h, &mut u, &mut b, &mut o) })?;
+    Ok((h, u, b, o))
+}
+/// Frees every idle scratch block, internal stream and pooled event; returns the bytes released.
+pub fn workspace_trim() -> usize { unsafe { ffi::fhe_workspace_trim() } }
+/// Number of HIP devices the engine sees (a host that shards a batch over the GPUs of a node makes one set of handles
+/// per device and drives each from its own thread -- `tests/c_host/c4_sharded.c` is that host in C).
+pub fn device_count() -> i32 { unsafe { ffi::fhe_device_count() as i32 } }
 
 // -------------------------------------------------------------------- device memory, streams, residency
 /// A HIP stream made by the C ABI (`fhe_stream_create`); `_dev` calls on one stream run in order.

@@ -1041,3 +1041,82 @@ def case_option_errors(fhe):
     assert m.set_streams(1).set_chunk(7).options() == dict(chunk=7, streams=1)
     # a host table callback that fails aborts the parameter set with NttOperatorUnavailable
     assert code(lambda: fhe.BfvParameters(16, opar.plaintext, moduli=opar.moduli, tables_fn=lambda q, n: 1 / 0)) == -5
+
+
+def case_workspace_bounds(fhe, make_stream, kill_stream, nstreams=40, nmod=3, n=64, batch=4):
+    """Round 4: the engine's process-global scratch is bounded.
+    (a) Foreign streams -- created and destroyed by the host without telling the engine (`make_stream` / `kill_stream`:
+        raw hipStreamCreate / hipStreamDestroy on the GPU, the emulator's stream table on CPU) -- each run one two-stream
+        multiply (which also creates an internal second stream and its scratch) and vanish: what the engine holds stays
+        within a few streams' footprint, not nstreams of them, and the results stay bit-identical.
+    (b) fhe_stream_destroy gives back the blocks of the stream's internal second stream too.
+    (c) fhe_workspace_set_limit: idle blocks are evicted least-recently-used first; a call larger than the limit still
+        runs; stats report what is held."""
+    import fhe_oracle.bfv as obfv_
+    opar, par = _params(fhe, nmod, n)
+    rng = random.Random(5)
+    sk = obfv_.SecretKey.random(opar, rng)
+    ork = obfv_.RelinearizationKey(sk, rng)
+    c0, c0s, c1, c1s = ksk_arrays(ork.ksk)
+    ctx = par.context_at_level(0)
+    rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1, c0s, c1s))
+    t = opar.plaintext
+    A = [sk.encrypt([rng.randrange(t) for _ in range(n)], rng) for _ in range(batch)]
+    B = [sk.encrypt([rng.randrange(t) for _ in range(n)], rng) for _ in range(batch)]
+    a_h, b_h = np.stack([ct_arr(c) for c in A]), np.stack([ct_arr(c) for c in B])
+    m = fhe.Multiplicator.default(par, rk, 0).set_chunk(1).set_streams(2)      # 4 chunks on two streams
+    om = obfv_.Multiplicator.default(ork)
+    want = np.stack([ct_arr(om.multiply(A[i], B[i])) for i in range(batch)])
+    fhe.workspace_trim()
+    fhe.workspace_set_limit(0, 0)
+    assert fhe.workspace_stats()["held_bytes"] == 0
+
+    def one_call(stream):
+        with stream:
+            a, b = fhe.DeviceArray.from_numpy(a_h), fhe.DeviceArray.from_numpy(b_h)
+            out = m.multiply(a, b)
+            stream.synchronize()
+            got = out.download()
+            for x in (a, b, out):
+                x.free()
+        return got
+
+    # (a) one stream's footprint, then many short-lived foreign streams
+    h0 = make_stream()
+    assert np.array_equal(one_call(fhe.Stream.foreign(h0)), want)
+    one = fhe.workspace_stats()
+    assert one["held_bytes"] > 0 and one["owners"] == 2, one       # the stream and its internal second stream
+    kill_stream(h0)
+    peak = 0
+    for i in range(nstreams):
+        h = make_stream()
+        assert np.array_equal(one_call(fhe.Stream.foreign(h)), want), i
+        kill_stream(h)
+        st = fhe.workspace_stats()
+        peak = max(peak, st["held_bytes"])
+        assert st["in_use_bytes"] == 0
+    assert peak <= 2 * one["held_bytes"], (peak, one)
+    assert fhe.workspace_stats()["owners"] <= 4
+    # (b) an ABI-made stream takes everything it owned with it
+    fhe.workspace_trim()
+    s = fhe.Stream(0)
+    assert np.array_equal(one_call(s), want)
+    assert fhe.workspace_stats()["held_bytes"] > 0
+    s.destroy()
+    assert fhe.workspace_stats() == dict(held_bytes=0, in_use_bytes=0, blocks=0, owners=0), fhe.workspace_stats()
+    # (c) limits: total cap of one stream's footprint -> a second live stream evicts the first one's idle blocks
+    s1, s2 = fhe.Stream(0), fhe.Stream(0)
+    fhe.workspace_set_limit(0, one["held_bytes"])
+    assert np.array_equal(one_call(s1), want)
+    assert np.array_equal(one_call(s2), want)
+    st = fhe.workspace_stats()
+    assert st["held_bytes"] <= one["held_bytes"] and st["in_use_bytes"] == 0, st
+    fhe.workspace_set_limit(1, 0)        # a per-stream cap below any block: nothing is retained, calls still run
+    assert np.array_equal(one_call(s1), want)
+    assert fhe.workspace_stats()["held_bytes"] == 0
+    fhe.workspace_set_limit(0, 0)
+    assert np.array_equal(one_call(s1), want)
+    assert fhe.workspace_stats()["held_bytes"] > 0
+    s1.destroy()
+    s2.destroy()
+    fhe.workspace_trim()

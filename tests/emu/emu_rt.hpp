@@ -16,7 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #define __global__ static
@@ -43,7 +45,7 @@ struct State {
     const std::function<void()> *body = nullptr;
 };
 inline State &st() {
-    static State s;
+    static thread_local State s;   // one fiber scheduler per host thread (a host may drive one "device" per thread)
     return s;
 }
 inline void fiber_entry() {
@@ -128,18 +130,37 @@ struct emuEvent {
     std::chrono::steady_clock::time_point t;
 };
 typedef emuEvent *hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorContextIsDestroyed = 709 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+// FHE_EMU_DEVICES=<n> (read once): the emulator reports n "devices" (all of them this host), each thread has a
+// current one -- enough to walk the engine's per-device bookkeeping (handles, scratch pools, the sharded multiply)
+// in CI without a second GPU
+inline int emu_device_count() {
+    static const int n = [] {
+        const char *e = getenv("FHE_EMU_DEVICES");
+        const int v = e ? atoi(e) : 1;
+        return v >= 1 && v <= 16 ? v : 1;
+    }();
+    return n;
+}
+inline int &emu_current_device() {
+    static thread_local int d = 0;
+    return d;
+}
 inline hipError_t hipGetDeviceCount(int *n) {
-    *n = 1;
+    *n = emu_device_count();
     return hipSuccess;
 }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipSetDevice(int d) {
+    if (d < 0 || d >= emu_device_count()) return hipErrorInvalidValue;
+    emu_current_device() = d;
+    return hipSuccess;
+}
 inline hipError_t hipGetDevice(int *d) {
-    *d = 0;
+    *d = emu_current_device();
     return hipSuccess;
 }
 inline hipError_t hipMalloc(void **p, size_t n) {
@@ -183,19 +204,80 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 enum { hipEventDisableTiming = 2, hipStreamNonBlocking = 1 };
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+// Streams: distinct non-null handles (the emulator runs everything in order) with a liveness table, so that
+// hipStreamQuery on a destroyed handle answers what the HIP runtime answers (an invalid-handle error) and handle
+// values are recycled like real ones.
+struct emuStreams {
+    std::mutex mu;
+    char pool[4096];
+    bool live[4096] = {};
+    int next = 0;
+};
+inline emuStreams &emu_streams() {
+    static emuStreams s;
+    return s;
+}
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
-    static char pool[64];
-    static int next = 0;
-    *s = (hipStream_t)&pool[next++ % 64];  // distinct non-null handles; the emulator runs everything in order
-    return hipSuccess;
+    emuStreams &t = emu_streams();
+    std::lock_guard<std::mutex> g(t.mu);
+    for (int k = 0; k < 4096; k++) {
+        const int i = (t.next + k) % 4096;
+        if (!t.live[i]) {
+            t.live[i] = true;
+            t.next = i + 1;
+            *s = (hipStream_t)&t.pool[i];
+            return hipSuccess;
+        }
+    }
+    return hipErrorInvalidValue;
 }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) {
+    emuStreams &t = emu_streams();
+    std::lock_guard<std::mutex> g(t.mu);
+    const ptrdiff_t i = (char *)s - t.pool;
+    if (i < 0 || i >= 4096 || !t.live[i]) return hipErrorContextIsDestroyed;
+    t.live[i] = false;
+    return hipSuccess;
+}
+inline hipError_t hipStreamQuery(hipStream_t s) {
+    if (!s) return hipSuccess;
+    emuStreams &t = emu_streams();
+    std::lock_guard<std::mutex> g(t.mu);
+    const ptrdiff_t i = (char *)s - t.pool;
+    return (i >= 0 && i < 4096 && t.live[i]) ? hipSuccess : hipErrorContextIsDestroyed;
+}
+// (allocation counters: what the workspace tests read instead of hipMemGetInfo)
+inline std::atomic<long long> &emu_live_bytes() {
+    static std::atomic<long long> v{0};
+    return v;
+}
 inline hipError_t hipMallocAsync(void **p, size_t n, hipStream_t) { return hipMalloc(p, n); }
 inline hipError_t hipFreeAsync(void *p, hipStream_t) { return hipFree(p); }
-typedef int hipMemPool_t;
+typedef void *hipMemPool_t;
 enum { hipMemPoolAttrReleaseThreshold = 4 };
-inline hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t *pool, int) { *pool = 0; return hipSuccess; }
+enum hipMemAllocationType { hipMemAllocationTypePinned = 1 };
+enum hipMemLocationType { hipMemLocationTypeDevice = 1 };
+struct hipMemLocation {
+    hipMemLocationType type;
+    int id;
+};
+struct hipMemPoolProps {
+    hipMemAllocationType allocType;
+    int handleTypes;
+    hipMemLocation location;
+    void *win32SecurityAttributes;
+    size_t maxSize;
+    unsigned char reserved[56];
+};
+inline hipError_t hipMemPoolCreate(hipMemPool_t *pool, const hipMemPoolProps *) {
+    static char pools[16];
+    static int next = 0;
+    *pool = &pools[next++ % 16];
+    return hipSuccess;
+}
+inline hipError_t hipMallocFromPoolAsync(void **p, size_t n, hipMemPool_t, hipStream_t) { return hipMalloc(p, n); }
+inline hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t *pool, int) { *pool = nullptr; return hipSuccess; }
 inline hipError_t hipMemPoolSetAttribute(hipMemPool_t, int, void *) { return hipSuccess; }
 inline hipError_t hipMemPoolTrimTo(hipMemPool_t, size_t) { return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
@@ -211,4 +293,15 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
 template <class F>
 inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) {
     return hipSuccess;
+}
+
+// ---- test hooks (exported by the emulation library only): a "foreign" stream, i.e. one the host creates and destroys
+// without telling the engine, as torch or a Rust host with its own HIP bindings would ----
+extern "C" {
+inline __attribute__((visibility("default"), used)) void *fhe_emu_stream_create() {
+    hipStream_t s = nullptr;
+    (void)hipStreamCreateWithFlags(&s, 0);
+    return s;
+}
+inline __attribute__((visibility("default"), used)) int fhe_emu_stream_destroy(void *s) { return hipStreamDestroy((hipStream_t)s); }
 }

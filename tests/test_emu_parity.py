@@ -263,3 +263,97 @@ def test_multiply_square_shortcut(fhe):
     cases.case_multiply_host_sliced(fhe)
     with fhe.Stream(0):
         cases.case_multiply_square(fhe, "abi", batch=3)
+
+
+# ---- round 4: the unfused key switch (ks_ntt_kernel + ks_mac_kernel), forced through fhe_ksk_set_mode ----
+def _unfused(fhe, mode=None, w_budget=0):
+    return fhe.KeySwitchingKey.forced_mode(fhe.KeySwitchingKey.UNFUSED if mode is None else mode, w_budget)
+
+
+def test_unfused_key_switch_levels_and_digits(fhe):
+    """Every (ciphertext level, key level) pair, long digit loops (more than sixteen terms: the accumulator is folded
+    in between), Galois keys (the caller's Ntt rows stand in for one transform per key modulus), RGSW, inner sum."""
+    with _unfused(fhe):
+        cases.case_key_switch_levels(fhe, False)
+        cases.case_key_switch_many_digits(fhe, False)
+        cases.case_galois(fhe, False)
+        cases.case_galois(fhe, False, nmod=3, n=128)
+        cases.case_rgsw_and_inner_sum(fhe, False)
+        cases.case_expand(fhe, False)
+
+
+def test_unfused_small_w_budget(fhe):
+    """A W budget of a few rows: groups of one key modulus over chunks of one polynomial (every loop of the host
+    side, ragged tails included)."""
+    with _unfused(fhe, w_budget=1):
+        cases.case_key_switch_levels(fhe, False)
+        cases.case_multiply(fhe, False, nmod=3, level=0, chunk=2, batch=5)
+    with _unfused(fhe, w_budget=3 * 5 * 16 * 8):
+        cases.case_key_switch_levels(fhe, False)
+        cases.case_galois(fhe, False)
+
+
+@pytest.mark.parametrize("nmod,level,chunk", [(2, 0, 0), (3, 1, 0), (4, 1, 1)])
+def test_unfused_multiply(fhe, nmod, level, chunk):
+    with _unfused(fhe):
+        cases.case_multiply(fhe, False, nmod=nmod, level=level, chunk=chunk)
+        cases.case_multiply(fhe, False, nmod=2, n=512, batch=2)
+
+
+def test_unfused_decomposition_keys_stay_fused(fhe):
+    with _unfused(fhe):
+        cases.case_key_switch_decomposition(fhe, False)
+
+
+@pytest.mark.parametrize("n,mode", [(8192, 2), (16384, 2), (16384, 3), (32768, 2), (65536, 2)])
+def test_unfused_key_switch_large_rows(fhe, n, mode):
+    """Whole-row tiles up to N = 16384, 8192-point sub-block tiles with the first stages folded into the loader
+    above (and at 16384 in mode UNFUSED_SUB) -- synthetic key and input vs the C oracle, 60- and 62-bit key moduli."""
+    import numpy as np
+    from fhe_oracle import bfv as obfv, coracle
+    from fhe_oracle.rq import Context as OCtx
+    from fhe_oracle.zq import generate_prime
+    import full_size
+    seed = 0xF4E50078
+    for q in (obfv.generate_moduli([60, 60], n), [generate_prime(62, 2 * n, 1 << 62), generate_prime(61, 2 * n, 1 << 61)]):
+        cc = coracle.CCtx(OCtx(q, n))
+        ck = full_size.host_key(cc, seed, len(q))
+        c0 = np.stack([cc.synth_poly(seed, 0, 8 + 2 * i) for i in range(len(q))])
+        c1 = np.stack([cc.synth_poly(seed, 0, 9 + 2 * i) for i in range(len(q))])
+        ctx = fhe.Context(q, n)
+        with _unfused(fhe, mode):
+            ksk = fhe.KeySwitchingKey(ctx, ctx, c0, c1)
+        assert ksk.mode()["mode"] == mode
+        p = np.stack([cc.synth_poly(seed, i, 0) for i in range(2)])
+        g0, g1 = ksk.key_switch(p)
+        for i in range(2):
+            w0, w1 = ck.key_switch(p[i])
+            assert np.array_equal(np.asarray(g0[i]), w0) and np.array_equal(np.asarray(g1[i]), w1)
+        if n > 16384:
+            break   # (one modulus set is enough at the emulator's speed)
+
+
+def test_unfused_random_parameter_shapes(fhe):
+    """24 of the pseudo-random shapes of test_random_parameter_shapes with the unfused strategy forced (mixed modulus
+    widths: all three lift forms; ragged batches: the tails of the XCD-grouped stage-B grid)."""
+    import random
+    import full_size
+    with _unfused(fhe):
+        for idx in range(0, 48, 2):
+            rng = random.Random(0xBEEF + idx)
+            n = 1 << rng.randrange(3, 13)
+            L = rng.randrange(1, 7)
+            sizes = [rng.choice([36, 45, 50, 54, 58, 59, 60, 61, 62]) for _ in range(L)]
+            batch = rng.randrange(1, 12)
+            if L < 2:
+                continue
+            full_size.check_mul_host(fhe, n=n, sizes=sizes, batch=batch, relin=True, cfg=300 + idx, mod_switch=(idx % 4 == 0))
+
+
+def test_workspace_bounds(fhe):
+    import ctypes as C
+    from fhe_rs_amd import _lib
+    L = _lib.lib()
+    L.fhe_emu_stream_create.restype = C.c_void_p
+    L.fhe_emu_stream_destroy.argtypes = [C.c_void_p]
+    cases.case_workspace_bounds(fhe, lambda: L.fhe_emu_stream_create(), lambda h: L.fhe_emu_stream_destroy(h))

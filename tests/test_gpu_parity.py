@@ -507,3 +507,165 @@ def test_release_library_ignores_lab_environment(tmp_path):
             "print('lab-env ok')") % (ROOT, ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "lab-env ok" in r.stdout, r.stdout + r.stderr
+
+
+# ---- round 4: the unfused key switch (ks_ntt_kernel + ks_mac_kernel).  Every case that goes through a key switch is
+# run with each evaluation strategy forced on the handle (fhe_ksk_set_mode), so that whichever one the engine's
+# per-shape choice (FHE_KS_AUTO) lands on has been compared with the oracle at that shape. ----
+KS_MODES = {"fused": 1, "unfused": 2, "unfused_sub": 3}
+
+
+@pytest.mark.parametrize("dev", [False, True])
+def test_unfused_key_switch_small(fhe, dev):
+    with fhe.KeySwitchingKey.forced_mode(2):
+        cases.case_key_switch_levels(fhe, dev)
+        cases.case_key_switch_many_digits(fhe, dev)
+        cases.case_galois(fhe, dev)
+        cases.case_galois(fhe, dev, nmod=3, n=128)
+        cases.case_rgsw_and_inner_sum(fhe, dev)
+        cases.case_expand(fhe, dev)
+        cases.case_key_switch_decomposition(fhe, dev)     # (stays on the fused kernel: base-2^k digits)
+    with fhe.KeySwitchingKey.forced_mode(2, w_budget=1):   # one polynomial x one key modulus per launch pair
+        cases.case_key_switch_levels(fhe, dev)
+        cases.case_multiply(fhe, dev, nmod=3, level=0, chunk=2, batch=5)
+
+
+@pytest.mark.parametrize("mode", ["fused", "unfused"])
+@pytest.mark.parametrize("sizes,n,batch", [([60, 58, 62, 50], 4096, 7), ([61, 45, 36], 2048, 33), ([62] * 6, 1024, 5),
+                                           ([60, 60], 256, 3)])
+def test_multiply_key_switch_modes(fhe, mode, sizes, n, batch):
+    """Mixed modulus widths (the lift takes its one-, two-subtraction and Barrett forms), with modulus switch."""
+    import full_size
+    with fhe.KeySwitchingKey.forced_mode(KS_MODES[mode]):
+        full_size.check_mul(fhe, n=n, sizes=sizes, batch=batch, relin=True, cfg=40 + len(sizes), mod_switch=True)
+
+
+@pytest.mark.parametrize("mode", ["fused", "unfused"])
+def test_config_c2_key_switch_modes(fhe, mode):
+    import full_size
+    with fhe.KeySwitchingKey.forced_mode(KS_MODES[mode]):
+        full_size.check_mul(fhe, n=8192, sizes=[60] * 4, batch=70, relin=True, cfg=2)
+
+
+@pytest.mark.parametrize("mode", ["fused", "unfused", "unfused_sub"])
+def test_config_c3_key_switch_modes(fhe, mode):
+    """configs[2] (relinearise + both rotations, N = 16384, 8 moduli) with every key-switch strategy: batch 6, and
+    batch 96 with a W budget that cuts it into three chunks of polynomials and four groups of key moduli."""
+    import full_size
+    with fhe.KeySwitchingKey.forced_mode(KS_MODES[mode]):
+        full_size.check_relin_rotate(fhe, n=16384, sizes=[60] * 8, batch=6, cfg=3)
+    with fhe.KeySwitchingKey.forced_mode(KS_MODES[mode], w_budget=32 * 8 * 2 * 16384 * 8):
+        full_size.check_relin_rotate(fhe, n=16384, sizes=[60] * 8, batch=96, cfg=3, sample=(0, 1, 31, 32, 33, 63, 64, 95))
+
+
+@pytest.mark.parametrize("mode", ["fused", "unfused"])
+def test_config_c5_key_switch_modes(fhe, mode):
+    """configs[4]: the 15-level chain (4 ciphertexts) and the bench batch 16 at level 0, with each strategy."""
+    import full_size
+    with fhe.KeySwitchingKey.forced_mode(KS_MODES[mode]):
+        full_size.check_chain(fhe, n=32768, sizes=[60] * 16, batch=4, levels=15, cfg=5)
+        full_size.check_mul(fhe, n=32768, sizes=[60] * 16, batch=16, relin=True, cfg=5, sample=(0, 7, 8, 15), mod_switch=True)
+    fhe.workspace_trim()
+
+
+@pytest.mark.parametrize("n,mode", [(8192, 2), (16384, 2), (16384, 3), (32768, 2), (65536, 2)])
+def test_unfused_key_switch_large_rows(fhe, n, mode):
+    """Synthetic key and input vs the C oracle; 60-bit (narrow passes) and 61/62-bit (general passes) key moduli."""
+    from fhe_oracle import bfv as obfv, coracle
+    from fhe_oracle.rq import Context as OCtx
+    from fhe_oracle.zq import generate_prime
+    import full_size
+    import torch
+    seed = 0xF4E50078
+    for q in (obfv.generate_moduli([60, 60, 60], n), [generate_prime(62, 2 * n, 1 << 62), generate_prime(61, 2 * n, 1 << 61)]):
+        cc = coracle.CCtx(OCtx(q, n))
+        ck = full_size.host_key(cc, seed, len(q))
+        c0 = np.stack([cc.synth_poly(seed, 0, 8 + 2 * i) for i in range(len(q))])
+        c1 = np.stack([cc.synth_poly(seed, 0, 9 + 2 * i) for i in range(len(q))])
+        ctx = fhe.Context(q, n)
+        ksk = fhe.KeySwitchingKey(ctx, ctx, c0, c1).set_mode(mode)
+        p = np.stack([cc.synth_poly(seed, i, 0) for i in range(3)])
+        g0, g1 = ksk.key_switch(torch.from_numpy(p.view(np.int64)).cuda())
+        for i in range(3):
+            w0, w1 = ck.key_switch(p[i])
+            assert np.array_equal(full_size.u64(g0[i]), w0) and np.array_equal(full_size.u64(g1[i]), w1)
+
+
+def _raw_hip_streams():
+    """hipStreamCreate / hipStreamDestroy straight from the HIP runtime: streams the engine is never told about."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def make():
+        s = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(s)) == 0
+        return s.value
+
+    def kill(h):
+        assert hip.hipStreamDestroy(C.c_void_p(h)) == 0
+    return make, kill
+
+
+def test_workspace_bounds(fhe):
+    make, kill = _raw_hip_streams()
+    cases.case_workspace_bounds(fhe, make, kill, nstreams=60, n=256)
+
+
+def test_workspace_1000_foreign_streams_c2(fhe):
+    """1,000 short-lived streams of the host's own (never announced to the engine, destroyed behind its
+    back), each doing one C2-shaped two-stream multiply: the device's free memory stays within 2x of one stream's
+    footprint, and every result is bit-identical to the first (which is checked against the C oracle)."""
+    import full_size
+    import torch
+    from fhe_oracle import bfv as obfv, coracle, synth
+    make, kill = _raw_hip_streams()
+    n, sizes, batch = 8192, [60] * 4, 64
+    q = obfv.generate_moduli(sizes, n)
+    t = full_size.plaintext_modulus(n)
+    seed = synth.seed_for_config(2)
+    par = fhe.BfvParameters(n, t, moduli=q)
+    ctx = par.context_at_level(0)
+    c0, c1 = full_size.device_key(ctx, seed, len(q))
+    rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1))
+    m = fhe.Multiplicator.default(par, rk, 0)
+    lhs, rhs = ctx.synth_uniform(seed, 0, 0, 2, batch), ctx.synth_uniform(seed, 0, 2, 2, batch)
+    torch.cuda.synchronize()
+    fhe.workspace_trim()
+    torch.cuda.empty_cache()
+    la, ra = fhe.DeviceArray.from_numpy(full_size.u64(lhs)), fhe.DeviceArray.from_numpy(full_size.u64(rhs))
+    del lhs, rhs
+    torch.cuda.empty_cache()
+    free0, _ = fhe.device_mem_info(0)
+
+    def one(handle):
+        with fhe.Stream.foreign(handle) as st:
+            out = m.multiply(la, ra)
+            st.synchronize()
+            got = out.download()
+            out.free()
+        return got
+    h = make()
+    first = one(h)
+    o = full_size.oracle_level(n, q, t, 0)
+    cm = coracle.CMul(o["cb"], o["cm"], o["cel"], o["cel"], o["cdn"], full_size.host_key(o["cb"], seed, len(q)), False)
+    for i in (0, 31, 63):
+        l = np.stack([o["cb"].synth_poly(seed, i, 0), o["cb"].synth_poly(seed, i, 1)])
+        r = np.stack([o["cb"].synth_poly(seed, i, 2), o["cb"].synth_poly(seed, i, 3)])
+        assert np.array_equal(first[i], cm.multiply(l, r))
+    free1, _ = fhe.device_mem_info(0)
+    footprint = free0 - free1
+    held1 = fhe.workspace_stats()["held_bytes"]
+    assert footprint > 0 and held1 > 0
+    kill(h)
+    worst = 0
+    for it in range(1000):
+        h = make()
+        got = one(h)
+        kill(h)
+        if it % 50 == 0:
+            assert np.array_equal(got, first), it
+            fr, _ = fhe.device_mem_info(0)
+            worst = max(worst, free0 - fr)
+        assert fhe.workspace_stats()["held_bytes"] <= 2 * held1
+    assert worst <= 2 * footprint + (64 << 20), (worst, footprint)
+    fhe.workspace_trim()

@@ -83,6 +83,39 @@ EDITS = [
             return;
         }
 """),
+        ("match R::REPRESENTATION {", "before", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() && R::REPRESENTATION != Representation::NttShoup {
+            // x -> x^i as one gather on the device (fhe_poly_substitute); NttShoup polynomials carry their twins
+            // along and stay on the native path
+            self.ctx
+                .hip_handle()?
+                .substitute(
+                    i.exponent,
+                    self.coefficients.as_slice().unwrap(),
+                    q.coefficients.as_slice_mut().unwrap(),
+                    R::REPRESENTATION == Representation::Ntt,
+                )
+                .map_err(crate::hip_error)?;
+            return Ok(q);
+        }
+""", 0),
+        ("let next_context = self.ctx.next_context.as_ref().unwrap();", "after", """
+        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
+            // divide-and-round by the last modulus, one lane per coefficient column (fhe_poly_switch_down)
+            let mut lower = Array2::<u64>::zeros((self.ctx.q.len() - 1, self.ctx.degree));
+            self.ctx
+                .hip_handle()?
+                .switch_down(self.coefficients.as_slice().unwrap(), lower.as_slice_mut().unwrap())
+                .map_err(crate::hip_error)?;
+            if !self.allow_variable_time_computations {
+                self.coefficients.as_slice_mut().unwrap().zeroize();
+            }
+            self.coefficients = lower;
+            self.ctx = next_context.clone();
+            return Ok(());
+        }
+"""),
     ]),
     ("05-rq-ops", "crates/fhe-math/src/rq/ops.rs", [
         ("impl AddAssign<&Poly<PowerBasis>> for Poly<PowerBasis> {", "before", """/// `hip` backend of the element-wise assignments below: one call on the `[L][N]` buffers, values identical.
@@ -99,10 +132,68 @@ macro_rules! hip_elementwise {
 }
 
 """),
-        # (the first AddAssign, Poly<PowerBasis>; the macro serves the other element-wise assignments the same way)
-        ('debug_assert_eq!(self.ctx, p.ctx, "Incompatible contexts");\n\n        self.allow_variable_time_computations &= p.allow_variable_time_computations;\n        if self.allow_variable_time_computations {\n            izip!(\n                self.coefficients.outer_iter_mut(),\n                p.coefficients.outer_iter(),\n                self.ctx.q.iter()\n            )\n            .for_each(|(mut v1, v2, qi)| unsafe {\n                qi.add_vec_vt(v1.as_slice_mut().unwrap(), v2.as_slice().unwrap())', "after_third", """        #[cfg(feature = "hip")]
+        # `self.allow_variable_time_computations &= p...;` occurs once per assignment impl, in source order:
+        # AddAssign<PowerBasis> :15, SubAssign<PowerBasis> :60, AddAssign<Ntt> :97, SubAssign<Ntt> :142,
+        # MulAssign<&Poly<Ntt>> :182, MulAssign<&Poly<NttShoup>> :212 (SURVEY 8b: M/rq/ops.rs:10-418)
+        ("self.allow_variable_time_computations &= p.allow_variable_time_computations;", "after", """        #[cfg(feature = "hip")]
         hip_elementwise!(self, p, add_assign);
-"""),
+""", 0),
+        ("self.allow_variable_time_computations &= p.allow_variable_time_computations;", "after", """        #[cfg(feature = "hip")]
+        hip_elementwise!(self, p, sub_assign);
+""", 1),
+        ("self.allow_variable_time_computations &= p.allow_variable_time_computations;", "after", """        #[cfg(feature = "hip")]
+        hip_elementwise!(self, p, add_assign);
+""", 2),
+        ("self.allow_variable_time_computations &= p.allow_variable_time_computations;", "after", """        #[cfg(feature = "hip")]
+        hip_elementwise!(self, p, sub_assign);
+""", 3),
+        ("self.allow_variable_time_computations &= p.allow_variable_time_computations;", "after", """        #[cfg(feature = "hip")]
+        hip_elementwise!(self, p, mul_assign);
+""", 4),
+        ("self.allow_variable_time_computations &= p.allow_variable_time_computations;", "after", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
+            // (a lazy left operand is fine: the Shoup product takes any 64-bit value and returns a canonical one)
+            let h = self.ctx.hip_handle().expect("fhe_hip: device context");
+            h.mul_shoup_assign(
+                self.coefficients.as_slice_mut().unwrap(),
+                p.coefficients.as_slice().unwrap(),
+                p.coefficients_shoup.as_ref().unwrap().as_slice().unwrap(),
+            )
+            .expect("fhe_hip: mul_shoup_assign");
+            self.has_lazy_coefficients = false;
+            return;
+        }
+""", 5),
+        # `assert!(!self.has_lazy_coefficients);` opens the four Neg impls: &Poly<Ntt> :358, &Poly<PowerBasis> :375
+        # (they negate a clone, `out`), Poly<Ntt> :392, Poly<PowerBasis> :408 (they negate `self`)
+        ("let mut out = self.clone();", "after", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
+            let h = out.ctx.hip_handle().expect("fhe_hip: device context").clone();
+            h.neg_assign(out.coefficients.as_slice_mut().unwrap()).expect("fhe_hip: neg_assign");
+            return out;
+        }
+""", 0),
+        ("let mut out = self.clone();", "after", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
+            let h = out.ctx.hip_handle().expect("fhe_hip: device context").clone();
+            h.neg_assign(out.coefficients.as_slice_mut().unwrap()).expect("fhe_hip: neg_assign");
+            return out;
+        }
+""", 1),
+        ("assert!(!self.has_lazy_coefficients);", "after", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
+            let h = self.ctx.hip_handle().expect("fhe_hip: device context").clone();
+            h.neg_assign(self.coefficients.as_slice_mut().unwrap()).expect("fhe_hip: neg_assign");
+            return self;
+        }
+""", 2),
+        ("assert!(!self.has_lazy_coefficients);", "after", """        #[cfg(feature = "hip")]
+        if fhe_math_hip::enabled() {
+            let h = self.ctx.hip_handle().expect("fhe_hip: device context").clone();
+            h.neg_assign(self.coefficients.as_slice_mut().unwrap()).expect("fhe_hip: neg_assign");
+            return self;
+        }
+""", 3),
     ]),
     ("06-rq-scaler", "crates/fhe-math/src/rq/scaler.rs", [
         ("scaler: RnsScaler,", "after", """    /// Device twin (constants of `scaler` uploaded on first use).
@@ -261,6 +352,21 @@ pub(crate) fn hip_error(e: fhe_math_hip::HipError) -> Error {
             .map_err(crate::hip_error)
     }
 
+    /// [`Ciphertext::switch_to_level`] on a device-resident batch over `par` (all of it at `d.level`): one inverse /
+    /// forward transform pair and `target_level - d.level` divide-and-round steps on the GPU, stream-ordered; the
+    /// same level checks and errors as the host method.
+    #[cfg(feature = "hip")]
+    pub fn switch_to_level_dev(par: &Arc<BfvParameters>, d: &fhe_math_hip::DeviceCiphertexts, target_level: usize,
+                               stream: &fhe_math_hip::Stream) -> Result<fhe_math_hip::DeviceCiphertexts> {
+        if target_level < d.level || target_level > par.max_level() {
+            return Err(Error::InvalidLevel { level: target_level, min_level: d.level, max_level: par.max_level() });
+        }
+        par.context_at_level(d.level)?
+            .hip_handle()?
+            .ciphertexts_switch_to_level_dev(target_level - d.level, d, stream)
+            .map_err(crate::hip_error)
+    }
+
     /// Downloads a device-resident batch (waits for `stream`) into ciphertexts over `par`.
     #[cfg(feature = "hip")]
     pub fn from_device(par: &Arc<BfvParameters>, d: &fhe_math_hip::DeviceCiphertexts, stream: &fhe_math_hip::Stream) -> Result<Vec<Ciphertext>> {
@@ -279,6 +385,157 @@ pub(crate) fn hip_error(e: fhe_math_hip::HipError) -> Error {
             *self = Ciphertext::from_ntt_coefficients(&self.par, &out, self.c.len(), self.level + 1)?;
             return Ok(());
         }
+"""),
+    ]),
+    ("14-bfv-relinearization-key", "crates/fhe/src/bfv/keys/relinearization_key.rs", [
+        ("/// Relinearize using polynomials.", "before", """    /// [`RelinearizationKey::relinearizes`] on a device-resident batch of three-part ciphertexts
+    /// (`Ciphertext::to_device`, `Multiplicator::multiply_dev` without a key): stream-ordered, nothing crosses PCIe;
+    /// the two-part result stays on the GPU.  Same checks, same errors, same values as `relinearizes`.
+    #[cfg(feature = "hip")]
+    pub fn relinearizes_dev(&self, ct: &fhe_math_hip::DeviceCiphertexts, stream: &fhe_math_hip::Stream) -> Result<fhe_math_hip::DeviceCiphertexts> {
+        if ct.parts != 3 {
+            return Err(crate::CiphertextError::InvalidPolynomialCount {
+                operation: crate::CiphertextOperation::Relinearization,
+                actual: ct.parts,
+                expected: 3,
+            }
+            .into());
+        }
+        if ct.level != self.ksk.ciphertext_level {
+            return Err(Error::InvalidLevel {
+                level: ct.level,
+                min_level: self.ksk.ciphertext_level,
+                max_level: self.ksk.ciphertext_level,
+            });
+        }
+        self.ksk.hip_handle()?.relinearize_dev(ct, stream).map_err(crate::hip_error)
+    }
+
+"""),
+    ]),
+    ("15-bfv-galois-key", "crates/fhe/src/bfv/keys/galois_key.rs", [
+        ("/// Relinearize a [`Ciphertext`] writing the result into `out`.", "before", """    /// [`GaloisKey::relinearize`] on a device-resident batch of two-part ciphertexts: substitution, key switch and
+    /// the level fix-up in one stream-ordered call (`fhe_bfv_galois_dev`); the result stays on the GPU.
+    #[cfg(feature = "hip")]
+    pub fn relinearize_dev(&self, ct: &fhe_math_hip::DeviceCiphertexts, stream: &fhe_math_hip::Stream) -> Result<fhe_math_hip::DeviceCiphertexts> {
+        if ct.parts != 2 {
+            return Err(crate::CiphertextError::InvalidPolynomialCount {
+                operation: crate::CiphertextOperation::Galois,
+                actual: ct.parts,
+                expected: 2,
+            }
+            .into());
+        }
+        if ct.level != self.ksk.ciphertext_level {
+            return Err(Error::InvalidLevel {
+                level: ct.level,
+                min_level: self.ksk.ciphertext_level,
+                max_level: self.ksk.ciphertext_level,
+            });
+        }
+        self.ksk.hip_handle()?.galois_dev(self.element.exponent, ct, stream).map_err(crate::hip_error)
+    }
+
+"""),
+    ]),
+    ("16-bfv-evaluation-key", "crates/fhe/src/bfv/keys/evaluation_key.rs", [
+        ("fn validate_ciphertext(&self, ct: &Ciphertext) -> Result<()> {", "before", """    #[cfg(feature = "hip")]
+    fn validate_device_ciphertexts(&self, ct: &fhe_math_hip::DeviceCiphertexts) -> Result<()> {
+        if ct.parts != 2 {
+            return Err(crate::CiphertextError::InvalidPolynomialCount {
+                operation: crate::CiphertextOperation::EvaluationKey,
+                actual: ct.parts,
+                expected: 2,
+            }
+            .into());
+        }
+        if ct.level != self.ciphertext_level {
+            return Err(Error::InvalidLevel {
+                level: ct.level,
+                min_level: self.ciphertext_level,
+                max_level: self.ciphertext_level,
+            });
+        }
+        Ok(())
+    }
+
+    #[cfg(feature = "hip")]
+    fn galois_key_for(&self, element: usize) -> Result<&GaloisKey> {
+        self.gk.get(&element).ok_or_else(|| {
+            crate::EvaluationKeyError::Missing { component: crate::EvaluationKeyComponent::GaloisKey { element } }.into()
+        })
+    }
+
+    /// [`EvaluationKey::rotates_rows`] on a device-resident batch (the exponent lookup stays here; the Galois key
+    /// switch runs on the GPU, stream-ordered, and its result stays there).
+    #[cfg(feature = "hip")]
+    pub fn rotates_rows_dev(&self, ct: &fhe_math_hip::DeviceCiphertexts, stream: &fhe_math_hip::Stream) -> Result<fhe_math_hip::DeviceCiphertexts> {
+        self.validate_device_ciphertexts(ct)?;
+        if !self.supports_row_rotation() {
+            return Err(crate::EvaluationKeyError::Unsupported { operation: crate::EvaluationOperation::RowRotation }.into());
+        }
+        self.galois_key_for(self.par.degree() * 2 - 1)?.relinearize_dev(ct, stream)
+    }
+
+    /// [`EvaluationKey::rotates_columns_by`] on a device-resident batch.
+    #[cfg(feature = "hip")]
+    pub fn rotates_columns_by_dev(&self, ct: &fhe_math_hip::DeviceCiphertexts, i: usize, stream: &fhe_math_hip::Stream) -> Result<fhe_math_hip::DeviceCiphertexts> {
+        self.validate_device_ciphertexts(ct)?;
+        if !self.supports_column_rotation_by(i) {
+            return Err(crate::EvaluationKeyError::Unsupported { operation: crate::EvaluationOperation::ColumnRotation { step: i } }.into());
+        }
+        let exponent = *self.rot_to_gk_exponent.get(&i).ok_or_else(|| crate::EvaluationKeyError::InvalidRotationStep {
+            step: i,
+            min: 1,
+            max: self.par.degree() / 2 - 1,
+        })?;
+        self.galois_key_for(exponent)?.relinearize_dev(ct, stream)
+    }
+
+    /// [`EvaluationKey::computes_inner_sum`] on a device-resident batch: the reference's sequence of Galois keys
+    /// (3^(2^j) mod 2N for j = 0 .. log2(N/2) - 1, then 2N - 1) handed to one engine call (`fhe_bfv_inner_sum_dev`).
+    #[cfg(feature = "hip")]
+    pub fn computes_inner_sum_dev(&self, ct: &fhe_math_hip::DeviceCiphertexts, stream: &fhe_math_hip::Stream) -> Result<fhe_math_hip::DeviceCiphertexts> {
+        self.validate_device_ciphertexts(ct)?;
+        if !self.supports_inner_sum() {
+            return Err(crate::EvaluationKeyError::Unsupported { operation: crate::EvaluationOperation::InnerSum }.into());
+        }
+        let mut elements = Vec::new();
+        let mut i = 1;
+        while i < self.par.degree() / 2 {
+            elements.push(*self.rot_to_gk_exponent.get(&i).ok_or(crate::EvaluationKeyError::Missing {
+                component: crate::EvaluationKeyComponent::GaloisExponent { step: i },
+            })?);
+            i *= 2
+        }
+        elements.push(self.par.degree() * 2 - 1);
+        let mut keys = Vec::with_capacity(elements.len());
+        for e in elements.iter() {
+            keys.push(self.galois_key_for(*e)?.ksk.hip_handle()?.clone());
+        }
+        fhe_math_hip::HipKsk::inner_sum_dev(&keys, &elements, ct, stream).map_err(crate::hip_error)
+    }
+
+    /// [`EvaluationKey::expands`] on a device-resident batch.  The result holds `size * ct.batch` ciphertexts laid out
+    /// `[size][batch]` (output `k` of input `b` is ciphertext `k * ct.batch + b`); the expansion monomials are derived
+    /// on the device from the context's tables.
+    #[cfg(feature = "hip")]
+    pub fn expands_dev(&self, ct: &fhe_math_hip::DeviceCiphertexts, size: usize, stream: &fhe_math_hip::Stream) -> Result<fhe_math_hip::DeviceCiphertexts> {
+        self.validate_device_ciphertexts(ct)?;
+        if size == 0 || size > self.par.degree() {
+            return Err(crate::EvaluationKeyError::InvalidExpansionSize { size, degree: self.par.degree() }.into());
+        }
+        let level = size.next_power_of_two().ilog2() as usize;
+        if !self.supports_expansion(level) {
+            return Err(crate::EvaluationKeyError::Unsupported { operation: crate::EvaluationOperation::Expansion { level } }.into());
+        }
+        let mut keys = Vec::with_capacity(level);
+        for l in 0..level {
+            keys.push(self.galois_key_for((self.par.degree() >> l) + 1)?.ksk.hip_handle()?.clone());
+        }
+        fhe_math_hip::HipKsk::expand_dev(&keys, size, ct, stream).map_err(crate::hip_error)
+    }
+
 """),
     ]),
     ("08-bfv-key-switch", "crates/fhe/src/bfv/keys/key_switching_key.rs", [
@@ -417,17 +674,21 @@ pub(crate) fn hip_error(e: fhe_math_hip::HipError) -> Error {
 
 def apply(text, edits, path):
     lines = text.split("\n")
-    for anchor, where, ins in edits:
-        first = anchor.split("\n")[0].strip()
+    for edit in edits:
+        anchor, where, ins = edit[:3]
+        occ = edit[3] if len(edit) > 3 else None     # which match of an anchor that occurs several times (0-based,
+        first = anchor.split("\n")[0].strip()        # counted in the file as the EARLIER edits of this list left it)
         idx = [i for i, l in enumerate(lines) if l.strip() == first]
         if "\n" in anchor:   # multi-line anchor: the following lines must match too
             rest = [a.strip() for a in anchor.split("\n")[1:]]
             idx = [i for i in idx if [l.strip() for l in lines[i + 1:i + 1 + len(rest)]] == rest]
         if not idx:
             raise SystemExit(f"{path}: anchor not found: {first!r}")
-        if len(idx) > 1 and "\n" not in anchor:
+        if len(idx) > 1 and "\n" not in anchor and occ is None:
             raise SystemExit(f"{path}: anchor is ambiguous ({len(idx)} matches): {first!r}")
-        i = idx[0]
+        if occ is not None and occ >= len(idx):
+            raise SystemExit(f"{path}: anchor has {len(idx)} matches, occurrence {occ} asked for: {first!r}")
+        i = idx[occ or 0]
         new = ins.rstrip("\n").split("\n")
         if where == "after":
             lines[i + 1:i + 1] = new

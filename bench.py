@@ -450,6 +450,163 @@ def other_configs(fhe, torch, reps=3):
     return out
 
 
+def next_rows(fhe, torch, par, timeit):
+    """SURVEY.md 8(f) -- the callers and data formats either side of the path -- on the C2 parameter set, same process
+    (informational, never `value`).  IDs follow the reference's benches: crates/fhe/benches/bfv_optimized_ops.rs
+    (`dot_product/opt`), benches/bfv.rs (`inner_sum`, `expand_*`, `mul_and_relin_2` :257-286, `decrypt`),
+    benches/bfv_rgsw.rs (external product), fhe-math/benches/rq.rs (serialisation).  Every entry carries the
+    stage-model bytes it is priced with (R = 8N bytes per residue row) and its fraction of 8 TB/s."""
+    import numpy as np
+    out = {}
+    n, ctx = par.degree, par.context_at_level(0)
+    L = ctx.nmoduli
+    R = 8 * n
+
+    def entry(ms, units, rows_per_unit, unit="ops_per_s", note=None, workload=None):
+        gbs = units * rows_per_unit * R / ms / 1e6
+        d = {unit: round(units / ms * 1e3, 1), "ms": round(ms, 3), "stage_model_bytes_per_unit": int(rows_per_unit * R),
+             "stage_model_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        if workload:
+            d["workload"] = workload
+        if note:
+            d["note"] = note
+        return d
+
+    ksk = key_for(fhe, ctx, SEED + 0x100)
+    # -- PIR server loop: dot_product_scalar, 256 query ciphertexts shared by 32 database rows (tools/bench_kernels.py)
+    count, rowsdb = 256, 32
+    q = ctx.synth_uniform(SEED, 0, 0, 2, count)
+    db = ctx.synth_uniform(SEED, 1000, 0, count, rowsdb).reshape(rowsdb, count, L, n)
+    ms = timeit(lambda: ctx.dot_product_scalar(q, db))
+    out["pir/dot_product_scalar"] = entry(ms, rowsdb * count, (rowsdb * count * L + count * 2 * L + rowsdb * 2 * L) / (rowsdb * count),
+                                          unit="ct_pt_mac_per_s", workload=f"{count} query cts (shared) x {rowsdb} db rows",
+                                          note="unique bytes: the db rows once, the queries once, the outputs")
+    del q, db
+    # -- ct x pt, one plaintext per ciphertext
+    b = 1024
+    ct = ctx.synth_uniform(SEED, 0, 0, 2, b)
+    pt = ctx.synth_uniform(SEED, 0, 2, 1, b).reshape(b, L, n)
+    ms = timeit(lambda: ctx.mul_plain(ct, pt))
+    out["pir/mul_plain"] = entry(ms, b, 2 * L + L + 2 * L, workload=f"batch {b}, one plaintext per ciphertext")
+    del pt
+    # -- wire format (fhe-math rq/convert.rs): PowerBasis polys <-> bit-packed payload (60 of 64 bits per coefficient)
+    polys = ct.view(b * 2, L, n)
+    packed_rows = L * 60 / 64
+    ms = timeit(lambda: ctx.serialize(polys))
+    out["wire/serialize"] = entry(ms, b * 2, L + packed_rows, unit="polys_per_s", workload=f"{b * 2} polys")
+    blob = ctx.serialize(polys)
+    ms = timeit(lambda: ctx.deserialize(blob))
+    out["wire/deserialize"] = entry(ms, b * 2, L + packed_rows, unit="polys_per_s")
+    ms = timeit(lambda: ctx.deserialize(blob, to_ntt=True))
+    out["wire/deserialize_into_ntt"] = entry(ms, b * 2, L + packed_rows + 2 * L, unit="polys_per_s")
+    del blob
+    # -- seeded c1 (Poly::random_from_seed): SHA-256 + ChaCha8 + rejection sampling per polynomial; compute-bound
+    seeds = torch.arange(b * 2 * 32, dtype=torch.int64, device=ct.device).to(torch.uint8).reshape(b * 2, 32)
+    ms = timeit(lambda: ctx.random_from_seed(seeds))
+    out["wire/seed_expand"] = entry(ms, b * 2, L, unit="polys_per_s", note="bytes = the polynomial written; the kernel is ChaCha / SHA bound, not HBM bound")
+    del seeds, polys
+    # -- decrypt (phase, inverse NTT, ciphertext->plaintext scaler, final reduction)
+    s_ntt = ctx.synth_uniform(SEED, 77, 0, 1, 1)[0, 0].contiguous()
+    pc = par.plaintext_context().nmoduli
+    ms = timeit(lambda: par.decrypt(s_ntt, ct, 0))
+    out["decrypt"] = entry(ms, b, (2 * L + L) + 2 * L + (L + pc) + (pc + 1), workload=f"batch {b}, two parts")
+    # -- RGSW external product: two fused key switches per ciphertext
+    rgsw = fhe.RGSWCiphertext(ksk, key_for(fhe, ctx, SEED + 0x101))
+    ms = timeit(lambda: rgsw.external_product(ct))
+    out["rgsw/external_product"] = entry(ms, b, 2 * (2 * L) + 2 * (L * L + 2 * L) + 2 * L, workload=f"batch {b}")
+    del rgsw
+    # -- inner sum: log2(N/2) column rotations + one row rotation, each a Galois key switch + add
+    seq, i = [], 1
+    while i < n // 2:
+        seq.append(pow(3, i, 2 * n))
+        i *= 2
+    seq.append(2 * n - 1)
+    gal_rows = 2 * (2 * L) + 2 * L + (L * L + 4 * L)         # substitute (2 polys r+w), inverse NTT, fused key switch + addend
+    ek = fhe.EvaluationKey(n, [fhe.GaloisKey(ksk, e) for e in seq])
+    bs = 256
+    cs = ct[:bs].contiguous()
+    ms = timeit(lambda: ek.computes_inner_sum(cs))
+    out["inner_sum"] = entry(ms, bs, len(seq) * (gal_rows + 3 * 2 * L), workload=f"batch {bs}, {len(seq)} Galois key switches each")
+    del ek, cs
+    # -- oblivious expansion of ONE ciphertext to N outputs (13 levels; 8,191 Galois key switches; 4 GiB out)
+    levels = n.bit_length() - 1
+    ek = fhe.EvaluationKey(n, [fhe.GaloisKey(ksk, (n >> l) + 1) for l in range(levels)])
+    one = ct[:1].contiguous()
+    ms = timeit(lambda: ek.expands(one, n))
+    out["pir/expand"] = entry(ms, n - 1, gal_rows + 8 * L, unit="galois_applications_per_s", workload=f"1 ciphertext -> {n} (levels: {levels})",
+                              note=f"{round(ms, 2)} ms per expansion = {round(1e3 / ms, 1)} expansions/s")
+    del ek, one, ct
+    # -- mul_and_relin_2: HPS second strategy (rhs pre-scaled by P/Q, product scaled by t/P; benches/bfv.rs:257-286)
+    qs = par.moduli
+    nm = (sum(int(m).bit_length() for m in qs) + 61) // 62
+    ext, upper = [], (1 << 64) - 1 >> 2
+    while len(ext) < nm:
+        upper = fhe.generate_prime(62, 2 * n, upper)
+        if upper not in qs:
+            ext.append(upper)
+    Q, P = 1, 1
+    for m_ in qs:
+        Q *= int(m_)
+    for m_ in ext:
+        P *= int(m_)
+    mctx = fhe.Context(list(qs) + ext, n)
+    mul2 = fhe.Multiplicator(fhe.Scaler(ctx, mctx, 1, 1), fhe.Scaler(ctx, mctx, P, Q), fhe.Scaler(mctx, ctx, int(par.plaintext), P),
+                             fhe.RelinearizationKey(ksk))
+    a, bb = ctx.synth_uniform(SEED, 0, 0, 2, b), ctx.synth_uniform(SEED, 0, 2, 2, b)
+    K2 = L + nm
+    ms = timeit(lambda: mul2.multiply(a, bb))
+    out["bfv/mul_and_relin_2"] = entry(ms, b, stage_model_rows(L, K2, L), workload=f"batch {b}, basis q ++ P ({K2} rows), rhs factor P/Q, post factor t/P")
+    return out
+
+
+def c5_chain(fhe, torch, batch=16):
+    """BASELINE.json configs[4] as written: the DEEP chain -- multiply + relinearise + modulus switch at every level
+    0 ... 14 of N = 32768, 16 x 60-bit (L_l = 16 ... 2), each level's output feeding the next (a squaring chain on
+    synthetic ciphertexts).  Total time of the 15 levels and every level's own rate."""
+    n, L = 32768, 16
+    t = fhe.generate_prime(20, 2 * n, 1 << 20)
+    par = fhe.BfvParameters(n, t, moduli_sizes=[60] * L)
+    levels = L - 1
+    muls, rows = [], []
+    for lv in range(levels):
+        ctx = par.context_at_level(lv)
+        rk = fhe.RelinearizationKey(key_for(fhe, ctx, 0xF4E50005 + lv))
+        muls.append(fhe.Multiplicator.default(par, rk, lv, mod_switch=True))
+        Ll, Kl = ctx.nmoduli, par.mul_context_at_level(lv).nmoduli
+        rows.append(22 * Kl + 7 * Ll + Ll * Ll + 4 * Ll + 12 * Ll - 6)
+        rows[-1] += 12 * Ll - 6                        # the second operand's own modulus switch (below)
+    c0 = par.context_at_level(0)
+    x0, y0 = c0.synth_uniform(0xF4E50005, 0, 0, 2, batch), c0.synth_uniform(0xF4E50005, 0, 2, 2, batch)
+    ctxs = [par.context_at_level(lv) for lv in range(levels)]
+
+    def chain(evs=None):
+        x, y = x0, y0
+        for i, m in enumerate(muls):
+            xn = m.multiply(x, y)                      # level i -> i + 1 (relinearised, modulus-switched)
+            y = ctxs[i].ciphertext_switch_down(y)      # the other operand follows one level down
+            x = xn
+            if evs is not None:
+                evs[i + 1].record()
+        return x
+    chain()                      # workspace of every level exists
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(levels + 1)]
+    reps, per_level = 3, [0.0] * levels
+    for _ in range(reps):
+        evs[0].record()
+        chain(evs)
+        torch.cuda.synchronize()
+        for i in range(levels):
+            per_level[i] += evs[i].elapsed_time(evs[i + 1]) / reps
+    total = sum(per_level)
+    gbs = batch * sum(rows) * 8 * n / total / 1e6
+    return dict(workload=f"n=32768, 16x60-bit, {levels} levels (L = 16 ... 2), batch {batch}; each level: x <- Multiplicator(x, y) with relinearisation + modulus switch, y <- switch_down(y)",
+                total_ms=round(total, 3), chains_per_s=round(batch / total * 1e3, 1), level_ops_per_s=round(batch * levels / total * 1e3, 1),
+                per_level_ms=[round(v, 3) for v in per_level], per_level_ops_per_s=[round(batch / v * 1e3, 1) for v in per_level],
+                stage_model_bytes_per_chain=int(sum(rows) * 8 * n), stage_model_GBps=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
+                note="two distinct operand batches; per-level time includes the second operand's own modulus switch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -547,18 +704,49 @@ def main():
     def timed(fn, steps):
         return timed_steps(fn, steps, torch.cuda.synchronize, dist, f"cuda:{dev}")
 
-    # setup, not a step: the first call on a stream allocates that stream's workspace (hipMalloc of ~3 GiB)
+    # setup, not a step: the first call on a stream allocates that stream's workspace (~3 GiB from the engine's pool)
     # and loads the kernels' code objects -- one-time state, like the tables and the key above
     step()
     torch.cuda.synchronize()
+    # The CPU-baseline leg runs FIRST (it used to be 9 of the run's 14.6 s at the END, so a sampler that
+    # looks at the GPU every few seconds saw an idle device); its parity spot check happens after the timed region.
+    cpu_leg = None
+    if world == 1 and not args.no_cpu:
+        os.sched_setaffinity(0, all_cpus)   # the CPU baseline gets every host core, not just the GPU's NUMA node
+        cpu_leg = cpu_baseline(n, MODULI_SIZES, t, SEED, args.cpu_seconds)
+        if pin.get("pinned"):
+            pin_to_gpu_numa_node(torch, dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # N > 1: rank 0's rate on the SAME per-GPU batch while every other rank idles at a barrier -- the one-GPU
+    # reference the scaling efficiency of this very run is computed against, and who is who
+    solo_rate, identities = None, None
+    if dist is not None:
+        dist.barrier()
+        if rank == 0:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            solo_rate = batch * args.steps / (time.perf_counter() - t0)
+        dist.barrier()
+        props = torch.cuda.get_device_properties(dev)
+        me = dict(rank=rank, local_rank=local_rank, device=dev, name=props.name,
+                  pci="%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id),
+                  uuid=str(getattr(props, "uuid", "")), numa_node=pin.get("numa_node"), pid=os.getpid())
+        identities = [None] * world
+        dist.all_gather_object(identities, me)
     fhe.prof_reset()
-    fhe.prof_enable(True)   # HIP events around every kernel launch, on the launching stream
-    elapsed = timed(step, args.steps)
+    fhe.prof_enable(True)   # HIP events carried by every kernel launch, on the launching stream
+    # the timed region: K steps between barrier + synchronize, REPEATS times back to back; `value` is the median
+    # repeat, the spread is in the line (value_min / value_max)
+    REPEATS = 3
+    elapsed_all = [timed(step, args.steps) for _ in range(REPEATS)]
     fhe.prof_enable(False)
     prof = fhe.prof_report()
+    elapsed = sorted(elapsed_all)[REPEATS // 2]
+    prof_steps = args.steps * REPEATS    # the per-kernel event sums cover every repeat
     # every rank's own elapsed time for the same K steps (its barrier-to-barrier time is the slowest rank's)
     per_rank = None
     if dist is not None:
@@ -643,7 +831,7 @@ def main():
     }
     dominant = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, 1e-9))
     dname, (dlaunches, dms) = dominant
-    dbytes_total = alg_rows.get(dname, 0) * R * batch * args.steps
+    dbytes_total = alg_rows.get(dname, 0) * R * batch * prof_steps
     achieved = dbytes_total / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
     traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
@@ -657,11 +845,16 @@ def main():
             traffic = None
     per_kernel = {}
     for k, v in sorted(prof.items()):
-        kb = alg_rows.get(k, 0) * R * batch * args.steps
+        kb = alg_rows.get(k, 0) * R * batch * prof_steps
         per_kernel[k] = dict(launches=v[0], ms=round(v[1], 3),
                              frac=round(kb / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[1] > 0 and kb else None)
+    kernel_sum_ms = sum(v[1] for v in prof.values())
     roofline = dict(bound="hbm", kernel=dname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
+                    traffic_observed_this_run=False,
+                    kernel_sum_ms_per_step=round(kernel_sum_ms / prof_steps, 4),
+                    kernel_sum_le_step=bool(kernel_sum_ms / prof_steps <= elapsed / args.steps * 1e3 * 1.001),
+                    timed_steps_behind_kernel_times=prof_steps,
                     launches=dlaunches, avg_launch_ms=round(dms / max(dlaunches, 1), 4), streams=args.streams,
                     algorithmic_bytes_per_launch=int(dbytes_total / max(dlaunches, 1)),
                     whole_op=dict(stage_model_bytes_per_op=stage_model_rows(L, K, L) * R,
@@ -669,13 +862,16 @@ def main():
                                   frac=round(stage_model_rows(L, K, L) * R * value / world / 1e9 / HBM_PEAK_GBS, 4)),
                     kernels=per_kernel)
     if not args.no_extras:
-        roofline["int_issue"] = int_issue_roofline(fhe, dev, prof, n, L, K, batch, args.steps, pipeline_step=step,
+        roofline["int_issue"] = int_issue_roofline(fhe, dev, prof, n, L, K, batch, prof_steps, pipeline_step=step,
                                                    sync=torch.cuda.synchronize)
 
     result = {
         "metric": "BFV ct x ct + relinearize ops/s (n=8192, 4x60-bit moduli)",
         "value": round(value, 1), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "repeats": REPEATS, "value_min": round(ops / max(elapsed_all), 1), "value_max": round(ops / min(elapsed_all), 1),
+        "value_all": [round(ops / e, 1) for e in elapsed_all], "value_is": "median of the repeats",
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload_name(world, batch),
                    "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"batch-sharded x{world}",
@@ -686,10 +882,18 @@ def main():
     result.update(extras)
     if per_rank is not None:
         result["per_rank"] = per_rank
+    if dist is not None:
+        distinct = len({(i["pci"], i["uuid"]) for i in identities})
+        result["multi_gpu"] = dict(
+            rccl_world_size=world if backend == "nccl" else None, dist_backend=backend, ranks=identities,
+            distinct_devices=distinct, one_device_per_rank=bool(distinct == world),
+            solo_rank0_ops_per_s=round(solo_rate, 1), solo_note="rank 0, same per-GPU batch, all other ranks idle at a barrier",
+            efficiency_vs_1gpu_same_batch=round(value / (world * solo_rate), 4),
+            data_path_collectives=0)
 
-    if world == 1 and not args.no_cpu:
-        os.sched_setaffinity(0, all_cpus)   # the CPU baseline gets every host core, not just the GPU's NUMA node
-        cb, cm, (clhs, crhs, last, count, npairs) = cpu_baseline(n, MODULI_SIZES, t, SEED, args.cpu_seconds)
+    if cpu_leg is not None:
+        cb, cm, (clhs, crhs, last, count, npairs) = cpu_leg
+        cb["when"] = "before the GPU legs of this run"
         result["cpu_baseline"] = cb
         result["speedup_vs_cpu_all_cores"] = round(value / cb["value"], 1)
         result["speedup_vs_cpu_single_thread"] = round(value / cb["single_thread_ops_per_s"], 1)
@@ -711,6 +915,12 @@ def main():
         torch.cuda.empty_cache()
         result["other_configs"] = other_configs(fhe, torch)
         result["other_configs"].update(ids)
+        fhe.workspace_trim()
+        torch.cuda.empty_cache()
+        result["other_configs"].update(next_rows(fhe, torch, par, make_timeit(torch)))
+        fhe.workspace_trim()
+        torch.cuda.empty_cache()
+        result["other_configs"]["C5_chain_15_levels"] = c5_chain(fhe, torch)
 
     if dist is not None:
         dist.destroy_process_group()

@@ -1073,15 +1073,19 @@ def workspace_trim():
     return int(_lib.lib().fhe_workspace_trim())
 
 
-def workspace_set_limit(per_stream_bytes=0, total_bytes=0):
-    """Bounds on the scratch the engine retains between calls (fhe_workspace_set_limit; 0 = none)."""
+WORKSPACE_DEFAULT = (1 << 64) - 1
+
+
+def workspace_set_limit(per_stream_bytes=0, total_bytes=WORKSPACE_DEFAULT):
+    """Bounds on the scratch the engine retains between calls (fhe_workspace_set_limit; 0 = none; the default total
+    is a quarter of the device's memory)."""
     check(_lib.lib().fhe_workspace_set_limit(int(per_stream_bytes), int(total_bytes)))
 
 
 def workspace_stats():
-    h, u, b, o = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
-    check(_lib.lib().fhe_workspace_stats(C.byref(h), C.byref(u), C.byref(b), C.byref(o)))
-    return dict(held_bytes=h.value, in_use_bytes=u.value, blocks=b.value, owners=o.value)
+    h, u, b, o, a = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    check(_lib.lib().fhe_workspace_stats(C.byref(h), C.byref(u), C.byref(b), C.byref(o), C.byref(a)))
+    return dict(held_bytes=h.value, in_use_bytes=u.value, blocks=b.value, owners=o.value, internal_streams=a.value)
 
 
 UBENCH_KINDS = {"mad_u64_u32": 0, "mul_lo_u32": 1, "mul_hi_u32": 2, "shoup_lazy": 3, "fwd_butterfly": 4,

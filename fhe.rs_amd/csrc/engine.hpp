@@ -229,29 +229,21 @@ private:
     std::vector<hipMemPool_t> pools;
 };
 
-// Is `s` still a stream?  (A host that makes and destroys its own HIP streams -- torch, hip-rs -- never tells the
-// engine; hipStreamQuery answers hipSuccess / hipErrorNotReady for a live stream and an invalid-handle error for one
-// that is gone.)
-inline bool stream_alive(hipStream_t s) {
-    if (!s) return true;   // the null stream
-    const hipError_t e = hipStreamQuery(s);
-    if (e == hipSuccess || e == hipErrorNotReady) return true;
-    (void)hipGetLastError();   // (clear the sticky error of the failed query)
-    return false;
-}
-
 // Scratch blocks, reused in stream order: a block released by stream S is handed out again only to work enqueued on
 // S, so there is no cross-stream hazard and no allocation per call.  Round 4: bounded.
-//  * Blocks come from the device's private stream-ordered pool (DevPools) and go back to it stream-ordered
-//    (hipFreeAsync on the block's own stream), so growing a stream's block no longer synchronises the device.
-//  * Limits (fhe_workspace_set_limit; 0 = none): `per_stream` and `total` bound the bytes the engine RETAINS -- idle
-//    blocks beyond them are evicted least-recently-used first, on release and before growing.  Blocks in use are never
-//    refused: a call that needs more than the limit still runs, its blocks just are not kept afterwards.
-//  * Before it grows, acquire() drops what belongs to streams that no longer exist (stream_alive): their work is over
-//    or draining, their blocks are freed with hipFree (which waits for the device), and the internal second stream
-//    that shadowed them (AuxStreams) goes with them.  A recycled handle value that inherits an old block is harmless:
-//    everything that ran on the old stream has been waited for by then or is ordered before the new owner's work by
-//    the allocator itself.
+//  * Blocks come from the device's private stream-ordered pool (DevPools).  A stream's own too-small blocks go back to
+//    it in stream order (hipFreeAsync on the acquiring stream, which is alive by construction), so growing a stream's
+//    block no longer synchronises the device.
+//  * Limits (fhe_workspace_set_limit): `per_stream` and `total` bound the bytes the engine RETAINS -- idle blocks
+//    beyond them are evicted least-recently-used first, on release and before growing.  Blocks in use are never
+//    refused: a call that needs more than the limit still runs, its blocks just are not kept afterwards.  Blocks of
+//    OTHER streams are evicted with hipFree (it waits for the device): the engine cannot know whether their stream still
+//    exists -- a host that makes and destroys its own HIP streams never says so, and this runtime's hipStreamQuery
+//    dereferences a destroyed handle (segmentation fault, tools/probe/hip_pool_probe.cpp) -- and hipFree is correct
+//    either way.  That is also what bounds such a host: dead streams' blocks are simply the least recently used.
+//    Default: no per-stream bound, total = a quarter of the device's memory (at least 8 GiB); 0 = unbounded.
+//  * A recycled handle value that inherits an old block is harmless: the block was idle, and whatever ran on the old
+//    stream is ordered before the new owner's work by the device itself (same queue slot) or long finished.
 class Workspace {
 public:
     static Workspace &get() {
@@ -261,12 +253,17 @@ public:
     void *acquire(size_t bytes, hipStream_t s);
     void release(void *p) {
         std::lock_guard<std::mutex> lk(mu);
+        hipStream_t owner = nullptr;
+        int dev = -1;
         for (auto &b : blocks)
             if (b.ptr == p) {
                 b.in_use = false;
                 b.last_use = ++tick;
+                owner = b.stream;
+                dev = b.device;
             }
-        enforce_limits_locked(nullptr, -1, 0);
+        // (the releasing call ran on `owner`, which therefore exists: its blocks may go back in stream order)
+        enforce_limits_locked(owner, dev, 0);
     }
     // A stream is about to be destroyed: its idle blocks can never be handed out again.
     void drop_stream(hipStream_t s) {
@@ -290,6 +287,7 @@ public:
         compact_locked();
         return freed;
     }
+    static constexpr size_t LIMIT_DEFAULT = ~(size_t)0;   // "a quarter of the device's memory, at least 8 GiB"
     void set_limits(size_t per_stream, size_t total) {
         std::lock_guard<std::mutex> lk(mu);
         limit_stream = per_stream;
@@ -299,7 +297,7 @@ public:
     void get_limits(size_t *per_stream, size_t *total) {
         std::lock_guard<std::mutex> lk(mu);
         if (per_stream) *per_stream = limit_stream;
-        if (total) *total = limit_total;
+        if (total) *total = total_limit_locked();
     }
     // bytes held (idle + in use), bytes in use, number of blocks, number of distinct (device, stream) owners
     void stats(size_t *held, size_t *in_use, size_t *nblocks, size_t *nstreams) {
@@ -335,8 +333,18 @@ private:
     std::vector<Block> blocks;
     std::mutex mu;
     uint64_t tick = 0;
-    size_t limit_stream = 0, limit_total = 0;
+    size_t limit_stream = 0, limit_total = LIMIT_DEFAULT;
+    size_t default_total = 0;   // resolved on first use
 
+    size_t total_limit_locked() {
+        if (limit_total != LIMIT_DEFAULT) return limit_total;
+        if (!default_total) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b) total_b = (size_t)32 << 30;
+            default_total = std::max<size_t>((size_t)8 << 30, total_b / 4);
+        }
+        return default_total;
+    }
     void compact_locked() {
         blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const Block &b) { return !b.ptr; }), blocks.end());
     }
@@ -359,17 +367,16 @@ private:
         compact_locked();
     }
     // Evicts idle blocks, least recently used first, until the retained bytes respect the limits; `extra` bytes on
-    // (`dev`, `s`) are about to be added (acquire) and count against both.
+    // (`dev`, `s`) are about to be added (acquire) and count against both.  Only blocks of (`dev`, `s`) -- the stream
+    // the current call runs on -- are returned in stream order; every other owner's go through hipFree.
     void enforce_limits_locked(hipStream_t s, int dev, size_t extra) {
-        if (!limit_stream && !limit_total) return;
+        const size_t lim_total = total_limit_locked();
+        if (!limit_stream && !lim_total) return;
         for (;;) {
-            size_t total = extra, mine = extra;
-            for (auto &b : blocks) {
-                total += b.bytes;
-                if (dev >= 0 && b.device == dev && b.stream == s) mine += b.bytes;
-            }
+            size_t total = extra;
+            for (auto &b : blocks) total += b.bytes;
             Block *victim = nullptr;
-            if (limit_total && total > limit_total) {
+            if (lim_total && total > lim_total) {
                 for (auto &b : blocks)
                     if (!b.in_use && b.ptr && (!victim || b.last_use < victim->last_use)) victim = &b;
             }
@@ -383,13 +390,11 @@ private:
                     if (own > limit_stream && (!victim || b.last_use < victim->last_use)) victim = &b;
                 }
             }
-            (void)mine;
             if (!victim) return;
-            free_block_locked(*victim, stream_alive(victim->stream));
+            free_block_locked(*victim, dev >= 0 && victim->device == dev && victim->stream == s);
             compact_locked();
         }
     }
-    void sweep_stale_locked(int dev);
 };
 // `wipe`: the block held secret-dependent data (decryption intermediates, which the reference keeps in
 // Zeroizing buffers, F/bfv/keys/secret_key.rs:198-226): it is cleared on its stream before it returns to the pool.
@@ -1668,14 +1673,39 @@ public:
         static AuxStreams a;
         return a;
     }
-    // `tag_key`: `user` is not a stream but the address of a static tag (host_sliced's three internal streams): such
-    // keys are never probed with hipStreamQuery
+    // The internal stream that shadows `user` on `device`; the caller holds it until done(device, user).
+    // `tag_key`: `user` is not a stream but the address of a static tag (host_sliced's three internal streams).
+    // At most CAP user streams keep an internal one: beyond that the least recently used idle entry goes (stream
+    // synchronised and destroyed, its scratch blocks freed) -- which is also what eventually collects the entries of
+    // user streams that no longer exist (a host's own streams: the engine is never told, and cannot ask, see Workspace).
     hipStream_t stream_for(int device, hipStream_t user, bool tag_key = false) {
+        std::vector<hipStream_t> victims;
+        hipStream_t out;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            Entry &a = reg[{device, user}];
+            if (!a.aux) FHE_HIP_CHECK(hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking));
+            a.tag_key = tag_key;
+            a.users++;
+            a.last_use = ++tick;
+            out = a.aux;
+            while (reg.size() > CAP) {
+                auto lru = reg.end();
+                for (auto it = reg.begin(); it != reg.end(); ++it)
+                    if (!it->second.tag_key && it->second.users == 0 && (lru == reg.end() || it->second.last_use < lru->second.last_use))
+                        lru = it;
+                if (lru == reg.end()) break;
+                victims.push_back(lru->second.aux);
+                reg.erase(lru);
+            }
+        }
+        retire(victims);
+        return out;
+    }
+    void done(int device, hipStream_t user) {
         std::lock_guard<std::mutex> lk(mu);
-        Entry &a = reg[{device, user}];
-        if (!a.aux) FHE_HIP_CHECK(hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking));
-        a.tag_key = tag_key;
-        return a.aux;
+        auto it = reg.find({device, user});
+        if (it != reg.end() && it->second.users > 0) it->second.users--;
     }
     hipEvent_t take_event() {
         {
@@ -1695,79 +1725,53 @@ public:
         pool.push_back(e);
     }
     // the internal stream that shadows `user` on `device` (device < 0: on any device; all: every internal stream and the
-    // pooled events as well) is synchronised and destroyed; returns the destroyed internal handles, whose scratch
-    // blocks the caller hands back (Workspace::drop_internal_stream) -- ADVICE r03: they used to stay in the pool
-    // under a handle that no longer existed
-    std::vector<hipStream_t> drop(int device, hipStream_t user, bool all) {
-        std::vector<hipStream_t> gone;
-        std::lock_guard<std::mutex> lk(mu);
-        for (auto it = reg.begin(); it != reg.end();) {
-            if (all || ((device < 0 || it->first.first == device) && it->first.second == user)) {
-                if (it->second.aux) {
-                    (void)hipStreamSynchronize(it->second.aux);
-                    (void)hipStreamDestroy(it->second.aux);
-                    gone.push_back(it->second.aux);
+    // pooled events as well) is synchronised and destroyed, and the scratch blocks keyed to it are freed (ADVICE r03:
+    // they used to stay in the pool under a handle that no longer existed)
+    void drop(int device, hipStream_t user, bool all) {
+        std::vector<hipStream_t> victims;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto it = reg.begin(); it != reg.end();) {
+                if (all || ((device < 0 || it->first.first == device) && it->first.second == user)) {
+                    if (it->second.aux) victims.push_back(it->second.aux);
+                    it = reg.erase(it);
+                } else {
+                    ++it;
                 }
-                it = reg.erase(it);
-            } else {
-                ++it;
+            }
+            if (all) {
+                for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+                pool.clear();
             }
         }
-        if (all) {
-            for (hipEvent_t e : pool) (void)hipEventDestroy(e);
-            pool.clear();
-        }
-        return gone;
+        retire(victims);
     }
-    // internal streams whose user stream no longer exists
-    std::vector<hipStream_t> drop_stale(int device) {
-        std::vector<hipStream_t> gone;
+    size_t count() {
         std::lock_guard<std::mutex> lk(mu);
-        for (auto it = reg.begin(); it != reg.end();) {
-            if (it->first.first == device && !it->second.tag_key && !stream_alive(it->first.second)) {
-                if (it->second.aux) {
-                    (void)hipStreamSynchronize(it->second.aux);
-                    (void)hipStreamDestroy(it->second.aux);
-                    gone.push_back(it->second.aux);
-                }
-                it = reg.erase(it);
-            } else {
-                ++it;
-            }
-        }
-        return gone;
+        return reg.size();
     }
-    bool is_internal(hipStream_t s) {
-        std::lock_guard<std::mutex> lk(mu);
-        for (auto &kv : reg)
-            if (kv.second.aux == s) return true;
-        return false;
-    }
+    static constexpr size_t CAP = 32;
 
 private:
     struct Entry {
         hipStream_t aux = nullptr;
         bool tag_key = false;
+        unsigned users = 0;
+        uint64_t last_use = 0;
     };
+    static void retire(const std::vector<hipStream_t> &victims) {
+        for (hipStream_t aux : victims) {
+            (void)hipStreamSynchronize(aux);
+            Workspace::get().drop_internal_stream(aux);   // (its work is over: plain frees)
+            (void)hipStreamDestroy(aux);
+        }
+    }
     std::mutex mu;
     std::map<std::pair<int, hipStream_t>, Entry> reg;
     std::vector<hipEvent_t> pool;
+    uint64_t tick = 0;
 };
 
-// (defined here: they need AuxStreams)
-inline void Workspace::sweep_stale_locked(int dev) {
-    // internal streams of user streams that are gone, then the blocks of those internal streams and of the dead
-    // user streams themselves
-    std::vector<hipStream_t> gone = AuxStreams::get().drop_stale(dev);
-    std::vector<hipStream_t> owners;
-    for (auto &b : blocks)
-        if (b.device == dev && !b.in_use && b.stream && std::find(owners.begin(), owners.end(), b.stream) == owners.end())
-            owners.push_back(b.stream);
-    for (hipStream_t t : owners) {
-        const bool was_internal = std::find(gone.begin(), gone.end(), t) != gone.end();
-        if (was_internal || (!AuxStreams::get().is_internal(t) && !stream_alive(t))) drop_stream_locked(t, false);
-    }
-}
 inline void *Workspace::acquire(size_t bytes, hipStream_t s) {
     int dev = 0;
     FHE_HIP_CHECK(hipGetDevice(&dev));
@@ -1778,12 +1782,11 @@ inline void *Workspace::acquire(size_t bytes, hipStream_t s) {
             best = &b;
     if (!best) {
         // growing.  Idle blocks of this (device, stream) that are too small go back to the pool in stream order (the
-        // allocation below may reuse their memory, ordered behind whatever still reads them), dead streams' blocks
-        // go, the limits are enforced, then the new block is taken from the device's pool on this stream.
+        // allocation below may reuse their memory, ordered behind whatever still reads them), the limits are
+        // enforced, then the new block is taken from the device's pool on this stream.
         for (auto &b : blocks)
             if (!b.in_use && b.device == dev && b.stream == s && b.ptr) free_block_locked(b, true);
         compact_locked();
-        sweep_stale_locked(dev);
         enforce_limits_locked(s, dev, bytes);
         Block nb;
         nb.ptr = DevPools::get().alloc(dev, bytes, s);
@@ -1901,8 +1904,10 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     struct Join {  // the internal stream always rejoins the caller's, also on an error path
         hipStream_t aux = nullptr, to = nullptr;
         hipEvent_t fork = nullptr, join = nullptr;
+        int device = 0;
         ~Join() {
             if (aux && hipEventRecord(join, aux) == hipSuccess) (void)hipStreamWaitEvent(to, join, 0);
+            if (aux) AuxStreams::get().done(device, to);
             // (a wait captures the event's state when it is enqueued: both events may be reused right away)
             if (fork) AuxStreams::get().give_event(fork);
             if (join) AuxStreams::get().give_event(join);
@@ -1930,6 +1935,7 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         join.to = s0;
         join.fork = ax.take_event();
         join.join = ax.take_event();
+        join.device = b.device;
         hipStream_t aux = ax.stream_for(b.device, s0);
         if (dual) lanes[1] = aux;
         if (split_ext) ext_done = ax.take_event();

@@ -360,8 +360,7 @@ fhe_status fhe_stream_destroy(void *stream) {
         FHE_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
         // what the engine keeps per caller stream: its internal second stream and its idle scratch blocks
         // (the internal stream's own blocks too -- a ChunkWs and the split-extension scratch are keyed to it: ADVICE r03)
-        for (hipStream_t aux : AuxStreams::get().drop(-1, as_stream(stream), false))
-            Workspace::get().drop_internal_stream(aux);
+        AuxStreams::get().drop(-1, as_stream(stream), false);
         Workspace::get().drop_stream(as_stream(stream));
         FHE_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
     });
@@ -975,7 +974,7 @@ void fhe_ksk_destroy(fhe_ksk *k_) { delete k_; }
 fhe_status fhe_ksk_set_mode(fhe_ksk *k_, int mode, size_t w_budget) {
     return guard([&] {
         need(k_, "ksk");
-        require(mode >= KS_AUTO && mode <= KS_UNFUSED_SUB, E_ARG, "mode must be one of FHE_KS_AUTO ... FHE_KS_UNFUSED_SUB");
+        require(mode >= KS_AUTO && mode <= KS_UNFUSED_SUB, E_ARG, "mode must be 0 (auto), 1 (fused), 2 (unfused) or 3 (unfused on sub-block tiles)");
         k_->k->mode.store(mode, std::memory_order_relaxed);
         k_->k->w_budget.store(w_budget, std::memory_order_relaxed);
     });
@@ -1710,8 +1709,7 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
     });
 }
 size_t fhe_workspace_trim(void) {
-    for (hipStream_t aux : AuxStreams::get().drop(-1, nullptr, true))   // internal streams and pooled events go too
-        Workspace::get().drop_internal_stream(aux);                      // (recreated on demand)
+    AuxStreams::get().drop(-1, nullptr, true);   // internal streams, their blocks and the pooled events go too
     const size_t freed = Workspace::get().trim();
     DevPools::get().trim();                      // what the private pools kept (scratch blocks, fhe_buf_alloc_async)
     return freed;
@@ -1722,8 +1720,12 @@ fhe_status fhe_workspace_set_limit(size_t per_stream_bytes, size_t total_bytes) 
 fhe_status fhe_workspace_get_limit(size_t *per_stream_bytes, size_t *total_bytes) {
     return guard([&] { Workspace::get().get_limits(per_stream_bytes, total_bytes); });
 }
-fhe_status fhe_workspace_stats(size_t *held_bytes, size_t *in_use_bytes, size_t *blocks, size_t *owners) {
-    return guard([&] { Workspace::get().stats(held_bytes, in_use_bytes, blocks, owners); });
+fhe_status fhe_workspace_stats(size_t *held_bytes, size_t *in_use_bytes, size_t *blocks, size_t *owners,
+                               size_t *internal_streams) {
+    return guard([&] {
+        Workspace::get().stats(held_bytes, in_use_bytes, blocks, owners);
+        if (internal_streams) *internal_streams = AuxStreams::get().count();
+    });
 }
 fhe_status fhe_ubench_int(int device, int which, double min_seconds, double *ops_per_s) {
     return guard([&] {

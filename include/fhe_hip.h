@@ -448,17 +448,25 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
  * streams and a few pooled events between calls; this frees every idle one (call it while no engine call is
  * running) and returns the number of scratch bytes released. */
 size_t fhe_workspace_trim(void);
-/* Bounds on what the engine RETAINS between calls (0 = no bound, the default): `per_stream_bytes` for the scratch
- * blocks keyed to one (device, stream), `total_bytes` over all of them.  Idle blocks beyond a bound are evicted
- * least-recently-used first, when a block is released and before a stream's block grows; blocks in use are never
- * refused (a call that needs more than the bound runs, its blocks are not kept afterwards).  Independently of any
- * bound, scratch that belongs to streams which no longer exist -- a host that creates and destroys its own HIP streams
- * never tells the engine -- is dropped the next time any stream's block has to grow.  Scratch blocks come from the
- * private stream-ordered pool and return to it in stream order: growing does not synchronise the device.
- * fhe_workspace_stats: bytes held (idle + in use), bytes in use, blocks, distinct (device, stream) owners. */
+/* Bounds on what the engine RETAINS between calls: `per_stream_bytes` for the scratch blocks keyed to one
+ * (device, stream), `total_bytes` over all of them; 0 = no bound.  Defaults: no per-stream bound, total = a quarter of
+ * the device's memory (at least 8 GiB) -- pass FHE_WORKSPACE_DEFAULT to ask for it again.  Idle blocks beyond a bound are
+ * evicted least-recently-used first, when a block is released and before a stream's block grows; blocks in use are
+ * never refused (a call that needs more than the bound runs, its blocks are not kept afterwards).
+ * Hosts that create and destroy their OWN HIP streams (torch, hip-rs): the engine is never told that such a stream is
+ * gone and has no safe way to ask (hipStreamQuery on a destroyed handle crashes in this runtime), so what it kept for
+ * it -- scratch blocks, an internal second stream -- stays until it is the least recently used: blocks under the
+ * `total_bytes` bound, internal streams beyond 32 live user streams.  Such a host sets `total_bytes` to a few times
+ * one stream's footprint (tests: 1,000 short-lived streams stay within 2x of one), or calls fhe_workspace_trim.
+ * Scratch blocks come from the library's private stream-ordered pool; a stream's own blocks return to it in stream
+ * order (growing does not synchronise the device), other streams' blocks are evicted with hipFree (which waits).
+ * fhe_workspace_stats: bytes held (idle + in use), bytes in use, blocks, distinct (device, stream) owners, internal
+ * second streams alive. */
+#define FHE_WORKSPACE_DEFAULT ((size_t)-1)
 fhe_status fhe_workspace_set_limit(size_t per_stream_bytes, size_t total_bytes);
 fhe_status fhe_workspace_get_limit(size_t *per_stream_bytes, size_t *total_bytes);
-fhe_status fhe_workspace_stats(size_t *held_bytes, size_t *in_use_bytes, size_t *blocks, size_t *owners);
+fhe_status fhe_workspace_stats(size_t *held_bytes, size_t *in_use_bytes, size_t *blocks, size_t *owners,
+                               size_t *internal_streams);
 /* Integer-issue ceiling ("report both ceilings"): register-resident loops of the instructions /
  * butterflies the NTT-type kernels are made of, chip-wide, no memory traffic, run for at least min_seconds
  * (0 < min_seconds <= 10).  which: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32, 3 lazy Shoup product,

@@ -667,17 +667,19 @@ impl Drop for HipParams {
 }
 
 // ------------------------------------------------------------------------------------ engine-wide state
-/// Bounds on the scratch memory the engine retains between calls (`fhe_workspace_set_limit`; 0 = none): bytes per
-/// (device, stream) and in total.  Idle blocks beyond a bound are evicted least-recently-used first; calls that need
-/// more still run.  Scratch of streams that no longer exist is dropped by the engine on its own.
+/// Bounds on the scratch memory the engine retains between calls (`fhe_workspace_set_limit`; 0 = none, `usize::MAX` =
+/// the default: a quarter of the device's memory in total): bytes per (device, stream) and in total.  Idle blocks beyond
+/// a bound are evicted least-recently-used first; calls that need more still run.  A host that destroys HIP streams of
+/// its own (not [`Stream`]s, whose `Drop` tells the engine) sets `total_bytes` to a few streams' footprint.
 pub fn workspace_set_limit(per_stream_bytes: usize, total_bytes: usize) -> Result<()> {
     check(unsafe { ffi::fhe_workspace_set_limit(per_stream_bytes, total_bytes) })
 }
-/// (bytes held, bytes in use, blocks, distinct (device, stream) owners) of the engine's scratch pool.
-pub fn workspace_stats() -> Result<(usize, usize, usize, usize)> {
-    let (mut h, mut u, mut b, mut o) = (0usize, 0usize, 0usize, 0usize);
-    check(unsafe { ffi::fhe_workspace_stats(&mut h, &mut u, &mut b, &mut o) })?;
-    Ok((h, u, b, o))
+/// (bytes held, bytes in use, blocks, distinct (device, stream) owners, internal second streams) of the engine's
+/// scratch pool.
+pub fn workspace_stats() -> Result<(usize, usize, usize, usize, usize)> {
+    let (mut h, mut u, mut b, mut o, mut a) = (0usize, 0usize, 0usize, 0usize, 0usize);
+    check(unsafe { ffi::fhe_workspace_stats(&mut h, &mut u, &mut b, &mut o, &mut a) })?;
+    Ok((h, u, b, o, a))
 }
 /// Frees every idle scratch block, internal stream and pooled event; returns the bytes released.
 pub fn workspace_trim() -> usize { unsafe { ffi::fhe_workspace_trim() } }

@@ -57,3 +57,44 @@ def test_c_host_reproduces_c2_digest(tmp_path):
     r = subprocess.run(args, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("ALL OK") and r.stdout.count(" ok") == 1 + 2 * len(g["outputs"]), r.stdout
+
+
+# ---- one process, several devices: tests/c_host/c4_sharded.c -- G handles on G devices, G host threads,
+# contiguous batch blocks, no data-path collective
+SHARD_SRC = os.path.join(ROOT, "tests", "c_host", "c4_sharded.c")
+
+
+def test_c_host_sharded_on_two_emulated_devices(tmp_path):
+    """CPU: the emulation build reports FHE_EMU_DEVICES = 2 "devices"; two host threads each drive their own handles,
+    stream and buffers on their device and multiply their block (3 + 2 of 5 pairs, N = 1024); both blocks must equal
+    the slices of the one-call result.  Walks the per-device bookkeeping of the runtime (handles, scratch pool keyed by
+    device, internal streams) under real concurrency."""
+    from helpers import build_emu
+    emu = build_emu()
+    exe = str(tmp_path / "c4_sharded_emu")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-pthread", "-I", INC, SHARD_SRC, "-o", exe, emu,
+                           "-Wl,-rpath," + os.path.dirname(emu)])
+    env = dict(os.environ, FHE_EMU_DEVICES="2")
+    r = subprocess.run([exe, "4108648450", "1032193", "5", "0", "1024"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), r.stdout + r.stderr
+    assert "devices 2 of 2 visible" in r.stdout and "[0, 3)" in r.stdout and "[3, 5)" in r.stdout, r.stdout
+    assert r.stdout.count("identical to the unsharded result") == 2
+
+
+@pytest.mark.gpu
+def test_c_host_sharded_over_all_visible_gpus(tmp_path):
+    """GPU: C4's per-GPU shard size scaled to this box -- every visible device takes its block of 1,024 x G pairs (one
+    device: the program still runs its thread / handle / buffer path, against the one-call result); on the driver's
+    8-GPU node this is the one-process form of the split that bench.py --gpus 8 does with one process per GPU."""
+    import __graft_entry__ as g
+    g.build()
+    exe = str(tmp_path / "c4_sharded")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-pthread", "-I", INC, SHARD_SRC, "-o", exe, "-L", LIBDIR,
+                           "-lfhe_hip", "-Wl,-rpath," + LIBDIR])
+    import torch
+    ndev = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("PYTHON", "TORCH"))}
+    r = subprocess.run([exe, "4108648450", "1032193", str(1024 * ndev), "0"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), r.stdout + r.stderr
+    assert f"devices {ndev} of {ndev} visible" in r.stdout
+    print(r.stdout)

@@ -613,8 +613,9 @@ def test_workspace_bounds(fhe):
 
 def test_workspace_1000_foreign_streams_c2(fhe):
     """1,000 short-lived streams of the host's own (never announced to the engine, destroyed behind its
-    back), each doing one C2-shaped two-stream multiply: the device's free memory stays within 2x of one stream's
-    footprint, and every result is bit-identical to the first (which is checked against the C oracle)."""
+    back), each doing one C2-shaped two-stream multiply, under fhe_workspace_set_limit(total = 2 footprints): the
+    device's free memory stays within 2x of one stream's footprint, the internal second streams stay bounded, and every
+    result is bit-identical to the first (which is checked against the C oracle)."""
     import full_size
     import torch
     from fhe_oracle import bfv as obfv, coracle, synth
@@ -657,6 +658,8 @@ def test_workspace_1000_foreign_streams_c2(fhe):
     held1 = fhe.workspace_stats()["held_bytes"]
     assert footprint > 0 and held1 > 0
     kill(h)
+    # what a host that churns streams of its own does: a retention bound of two streams' footprint
+    fhe.workspace_set_limit(0, 2 * held1)
     worst = 0
     for it in range(1000):
         h = make()
@@ -668,4 +671,6 @@ def test_workspace_1000_foreign_streams_c2(fhe):
             worst = max(worst, free0 - fr)
         assert fhe.workspace_stats()["held_bytes"] <= 2 * held1
     assert worst <= 2 * footprint + (64 << 20), (worst, footprint)
+    assert fhe.workspace_stats()["internal_streams"] <= 32 + 3
     fhe.workspace_trim()
+    fhe.workspace_set_limit()

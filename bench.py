@@ -472,6 +472,23 @@ def next_rows(fhe, torch, par, timeit):
             d["note"] = note
         return d
 
+    # the box's own streaming ceiling: a 2 GiB device-to-device copy, read + write bytes counted (the guide's
+    # "achievable" HBM rate is ~6.3 TB/s; a plain copy on these boxes measures ~5.1 TB/s): the streaming rows below
+    # carry their fraction of THIS number next to the fraction of the nominal 8 TB/s
+    src = torch.empty(1 << 28, dtype=torch.int64, device=f"cuda:{ctx.device}")
+    dst = torch.empty_like(src)
+    copy_ms = timeit(lambda: dst.copy_(src))
+    copy_gbs = 2 * src.numel() * 8 / copy_ms / 1e6
+    out["hbm_copy_ceiling"] = dict(GBps=round(copy_gbs, 1), frac=round(copy_gbs / HBM_PEAK_GBS, 4), ms=round(copy_ms, 3),
+                                   workload="torch D2D copy of 2 GiB, read + write bytes")
+    del src, dst
+    _entry = entry
+
+    def entry(ms, units, rows_per_unit, unit="ops_per_s", note=None, workload=None):   # noqa: F811
+        d = _entry(ms, units, rows_per_unit, unit, note, workload)
+        d["frac_of_measured_copy_ceiling"] = round(d["stage_model_GBps"] / copy_gbs, 4)
+        return d
+
     ksk = key_for(fhe, ctx, SEED + 0x100)
     # -- PIR server loop: dot_product_scalar, 256 query ciphertexts shared by 32 database rows (tools/bench_kernels.py)
     count, rowsdb = 256, 32

@@ -655,6 +655,7 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     k::RowMap inplace = map;
     inplace.src_poly_stride = map.dst_poly_stride;
     inplace.src_row_fixed = -1;
+    inplace.in2 = nullptr;   // (the second half of the transform works in `out`: one array)
     if (!inverse) {
         if (g0 == 2)
             FHE_LAUNCH("ntt_fwd_global", (k::ntt_global_kernel<false, 2>), dim3(gblocks), dim3(gth), 0, s, in, out,
@@ -678,7 +679,7 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
 // Fused tensor + inverse NTT over the extended basis.  Rows that fit LDS (logn <= 14): one kernel.
 // N = 32768 / 65536: the same kernel on 8192-point sub-blocks, then the global inverse stages.
 // (Defined after full_map.)
-inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s);
+inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s, bool reverse = false);
 
 // all rows of [npolys][rows_in_poly][N], modulus = row index
 inline k::RowMap full_map(const Ctx &c, size_t rows_in_poly) {
@@ -688,11 +689,14 @@ inline k::RowMap full_map(const Ctx &c, size_t rows_in_poly) {
     m.mod_offset = 0;
     m.src_row_fixed = -1;
     m.src_poly_stride = m.dst_poly_stride = (u64)rows_in_poly * c.n;
+    m.in2 = nullptr;
+    m.split = 0;
+    m.reverse = 0;
     return m;
 }
 
 inline void launch_tensor_intt_rows(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, uint32_t row_begin,
-                                    uint32_t lrows, bool narrow, hipStream_t s) {
+                                    uint32_t lrows, bool narrow, hipStream_t s, bool reverse) {
     const uint32_t logn = (uint32_t)e.logn, logm = logn <= 14 ? logn : 13;
     const size_t lds = k::lds_words(1u << logm) * sizeof(u64);
     // 8 (row, pair, sub-block) combinations x 3 slots per group
@@ -701,7 +705,7 @@ inline void launch_tensor_intt_rows(const Ctx &e, const k::TensorSrc &ts, u64 *o
     allow_big_lds((k::tensor_intt_kernel<LM, SUB, NRW>), lds);                                                   \
     FHE_LAUNCH("tensor_intt", (k::tensor_intt_kernel<LM, SUB, NRW>), dim3(groups * 24),                          \
                dim3(k::ntt_threads_c(LM)), lds, s, ts, out, e.dmods(), e.ditw(), e.dninv(), (uint32_t)e.L,       \
-               (uint32_t)nb, logn, row_begin, lrows);
+               (uint32_t)nb, logn, row_begin, lrows, reverse ? 1u : 0u);
 #define FHE_TI_CASE(LM)                               \
     case LM:                                          \
         if (narrow) { FHE_TI_LAUNCH(LM, false, true) } \
@@ -721,17 +725,24 @@ inline void launch_tensor_intt_rows(const Ctx &e, const k::TensorSrc &ts, u64 *o
 #undef FHE_TI_LAUNCH
 }
 
-inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s) {
-    // maximal runs of rows of the same kind (moduli below 2^60 or not): one launch each
+inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s, bool reverse) {
+    // maximal runs of rows of the same kind (moduli below 2^60 or not): one launch each (reverse: last run first)
     const bool allow = !FHE_LAB_FLAG("NO_NARROW");
+    struct Run {
+        uint32_t r0, n;
+        bool narrow;
+    };
+    std::vector<Run> runs;
     uint32_t r0 = 0;
     while (r0 < e.L) {
         const bool nr = allow && (e.moduli[r0] >> 60) == 0;
         uint32_t r1 = r0 + 1;
         while (r1 < e.L && (allow && (e.moduli[r1] >> 60) == 0) == nr) r1++;
-        launch_tensor_intt_rows(e, ts, out, nb, r0, r1 - r0, nr, s);
+        runs.push_back(Run{r0, r1 - r0, nr});
         r0 = r1;
     }
+    if (reverse) std::reverse(runs.begin(), runs.end());
+    for (const Run &r : runs) launch_tensor_intt_rows(e, ts, out, nb, r.r0, r.n, r.narrow, s, reverse);
     const uint32_t logn = (uint32_t)e.logn;
     if (logn > 14) {  // the global inverse stages finish every row
         const uint32_t logm = 13;
@@ -777,10 +788,18 @@ inline void wire_serialize(const Ctx &c, const u64 *polys, uint8_t *bytes, size_
     }
     const unsigned groups = (unsigned)(c.n / 8), block = groups < 256 ? 64 : 256;
     const u64 wb = wire_poly_bytes(c);
+    // rows of >= 128 coefficients (and a 16-byte aligned destination: every row then starts on a 16-byte boundary)
+    // take the word-granular kernel; its grid covers the widest row (62 bits)
+    const bool words = c.n >= 128 && ((uintptr_t)bytes & 15) == 0;
     for (size_t p0 = 0; p0 < npolys; p0 += 32768) {  // gridDim.z <= 65535
         const size_t np = std::min<size_t>(32768, npolys - p0);
-        FHE_LAUNCH("wire_pack", k::wire_pack_kernel, dim3(blocks_for(groups, block), (unsigned)c.L, (unsigned)np),
-                   dim3(block), 0, s, polys + p0 * pe, bytes + p0 * wb, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, wb);
+        if (words)
+            FHE_LAUNCH("wire_pack", k::wire_pack_words_kernel,
+                       dim3(blocks_for((c.n >> 7) * 64, 256), (unsigned)c.L, (unsigned)np), dim3(256), 0, s, polys + p0 * pe,
+                       bytes + p0 * wb, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, wb);
+        else
+            FHE_LAUNCH("wire_pack", k::wire_pack_kernel, dim3(blocks_for(groups, block), (unsigned)c.L, (unsigned)np),
+                       dim3(block), 0, s, polys + p0 * pe, bytes + p0 * wb, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, wb);
     }
 }
 inline void wire_deserialize(const Ctx &c, const uint8_t *bytes, u64 *polys, size_t npolys, bool to_ntt, hipStream_t s) {
@@ -788,10 +807,15 @@ inline void wire_deserialize(const Ctx &c, const uint8_t *bytes, u64 *polys, siz
     if (!npolys) return;
     const unsigned groups = (unsigned)(c.n / 8), block = groups < 256 ? 64 : 256;
     const u64 wb = wire_poly_bytes(c), pe = (u64)c.L * c.n;
+    const bool words = c.n >= 128 && ((uintptr_t)bytes & 15) == 0;   // (see wire_serialize)
     for (size_t p0 = 0; p0 < npolys; p0 += 32768) {
         const size_t np = std::min<size_t>(32768, npolys - p0);
-        FHE_LAUNCH("wire_unpack", k::wire_unpack_kernel, dim3(blocks_for(groups, block), (unsigned)c.L, (unsigned)np),
-                   dim3(block), 0, s, bytes + p0 * wb, polys + p0 * pe, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, wb);
+        if (words)
+            FHE_LAUNCH("wire_unpack", k::wire_unpack_words_kernel, dim3(blocks_for(c.n / 2, 256), (unsigned)c.L, (unsigned)np),
+                       dim3(256), 0, s, bytes + p0 * wb, polys + p0 * pe, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, wb);
+        else
+            FHE_LAUNCH("wire_unpack", k::wire_unpack_kernel, dim3(blocks_for(groups, block), (unsigned)c.L, (unsigned)np),
+                       dim3(block), 0, s, bytes + p0 * wb, polys + p0 * pe, c.dmods(), (uint32_t)c.L, (uint32_t)c.logn, wb);
     }
     if (to_ntt) launch_ntt(c, false, polys, polys, full_map(c, c.L), npolys, s);
 }
@@ -939,6 +963,22 @@ inline void scaler_upload(Scaler &s) {
         for (size_t i = 0; i < c.nfrom; i++) sum_q = sum_q + BigUint(s.from->moduli[i] - 1);
         if (sum_q < BigUint::pow2(64)) s.dev.v_fits_64 = 1;
     }
+    // wide_w: can |t| = |sum_i +/- r_i theta_omega_i -/+ v theta_gamma| reach 2^191?  Below that the kernel's fast path
+    // (sign from bit 255, 68 bits of w) IS the reference's `t >> 191 > 0` test and 128-bit w; at or above it the
+    // reference's result is defined by those bit tests and the launch takes the instance that reproduces them
+    // (ADVICE r03).  Bound: r_i <= q_i - 1, v <= sum_i (q_i - 1) + 2 (theta_garner_i / 2^shift < 1).
+    s.dev.wide_w = 0;
+    if (!c.is_one) {
+        BigUint bound(0), vmax(2);
+        for (size_t i = 0; i < c.nfrom; i++) {
+            const u64 limbs[2] = {c.theta_omega_lo[i], c.theta_omega_hi[i]};
+            bound = bound + BigUint::from_limbs(limbs, 2) * BigUint(s.from->moduli[i] - 1);
+            vmax = vmax + BigUint(s.from->moduli[i] - 1);
+        }
+        const u64 gl[2] = {c.theta_gamma_lo, c.theta_gamma_hi};
+        bound = bound + BigUint::from_limbs(gl, 2) * vmax;
+        if (!(bound < BigUint::pow2(191))) s.dev.wide_w = 1;
+    }
     s.dev.fold_mask = fold_mask;
     s.dev.fold_tab = b + o_fold;
     s.dev.theta_gamma_sign = c.theta_gamma_sign ? 1 : 0;
@@ -970,7 +1010,7 @@ inline std::unique_ptr<Scaler> scaler_create(const Ctx &from, const Ctx &to, con
 
 // RnsScaler::scale over `npolys * N` coefficient columns (register-resident residues: NF >= nfrom).
 inline void launch_scale(const Scaler &sc, const u64 *in, u64 in_stride, u64 *out, u64 out_stride, size_t npolys,
-                         hipStream_t s) {
+                         hipStream_t s, bool ascending = false) {
     const Ctx &f = *sc.from, &t = *sc.to;
     const u64 total = (u64)npolys * f.n;
     if (!total) return;
@@ -979,13 +1019,17 @@ inline void launch_scale(const Scaler &sc, const u64 *in, u64 in_stride, u64 *ou
     const char *label = t.L > f.L ? "scale_extend" : "scale_down";
     // PLAIN instances carry no w / v_hi code: factor-one scalers whose v fits one word (every basis extension of BFV)
     const bool plain = sc.dev.is_one && sc.dev.v_fits_64;
+    const uint32_t asc = ascending ? 1u : 0u;
 #define FHE_SCALE_CASE(NF)                                                                                   \
     if (plain)                                                                                               \
         FHE_LAUNCH(label, (k::scale_kernel<NF, true>), grid, block, 0, s, in, out, in_stride, out_stride,    \
-                   sc.dev, t.dmods(), (uint32_t)f.logn, total);                                              \
+                   sc.dev, t.dmods(), (uint32_t)f.logn, total, asc);                                         \
+    else if (sc.dev.wide_w)   /* the reference's bit tests on an out-of-range t, to the letter */             \
+        FHE_LAUNCH(label, (k::scale_kernel<NF, false, true>), grid, block, 0, s, in, out, in_stride,         \
+                   out_stride, sc.dev, t.dmods(), (uint32_t)f.logn, total, asc);                             \
     else                                                                                                     \
         FHE_LAUNCH(label, (k::scale_kernel<NF, false>), grid, block, 0, s, in, out, in_stride, out_stride,   \
-                   sc.dev, t.dmods(), (uint32_t)f.logn, total)
+                   sc.dev, t.dmods(), (uint32_t)f.logn, total, asc)
     switch (scale_kernel_nf(f.L)) {   // (the same NF scaler_upload padded the tables to)
         case 4: FHE_SCALE_CASE(4); break;
         case 9: FHE_SCALE_CASE(9); break;
@@ -1024,6 +1068,35 @@ inline void scale_polys(const Scaler &sc, const u64 *in, u64 *out, size_t npolys
     } else {
         launch_scale(sc, in, in_stride, out, out_stride, npolys, s);
     }
+}
+
+// Scaler::scale of TWO operand arrays (Ntt form, npolys polynomials each, the same scaler) in one pass of three
+// launches: out [2 * npolys][to.L][N] (in0's polynomials first).  What bfv_mul's two operand extensions are when both
+// sides use the same extender (Multiplicator::default): launches twice as large, half as many of them -- each
+// launch's tail (the last, partly filled round of workgroups) is paid once instead of twice.
+inline void scale_polys_pair(const Scaler &sc, const u64 *in0, const u64 *in1, u64 *out, size_t npolys, hipStream_t s,
+                             bool copy_common) {
+    const Ctx &f = *sc.from, &t = *sc.to;
+    f.need_device();
+    if (!npolys) return;
+    const u64 in_stride = (u64)f.L * f.n, out_stride = (u64)t.L * t.n;
+    if (sc.ncommon > 0 && copy_common) {
+        const u64 per = (u64)sc.ncommon * f.n, total = per * npolys;
+        for (int h = 0; h < 2; h++)
+            FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0, s,
+                       h ? in1 : in0, out + (u64)h * npolys * out_stride, in_stride, out_stride, per, total);
+    }
+    if (sc.ncommon >= t.L) return;
+    WsGuard pb(2 * npolys * in_stride * sizeof(u64), s);
+    k::RowMap mi = full_map(f, f.L);
+    mi.in2 = in1;
+    mi.split = (uint32_t)npolys;
+    launch_ntt(f, true, in0, pb.u(), mi, 2 * npolys, s);
+    launch_scale(sc, pb.u(), in_stride, out, out_stride, 2 * npolys, s);
+    k::RowMap m = full_map(t, t.L);
+    m.rows = (uint32_t)(t.L - sc.ncommon);
+    m.row_begin = (uint32_t)sc.ncommon;
+    launch_ntt(t, false, out, out, m, 2 * npolys, s);
 }
 
 // Poly::<PowerBasis>::switch_down (M/rq/mod.rs:433-492) on npolys polynomials.
@@ -1523,7 +1596,7 @@ inline void mul_plain(const Ctx &c, size_t nparts, const u64 *ct, const u64 *pt,
     if (!batch || !nparts) return;
     const u64 pl = (u64)c.L * c.n;
     require(batch <= 65535 && nparts <= 65535, E_ARG, "mul_plain: batch / parts exceed the grid limits");
-    FHE_LAUNCH("mul_plain", k::mul_plain_kernel, dim3(blocks_for(pl, EW_THREADS), (unsigned)nparts, (unsigned)batch),
+    FHE_LAUNCH("mul_plain", k::mul_plain_kernel, dim3(blocks_for(pl / 2, EW_THREADS), 1, (unsigned)batch),
                dim3(EW_THREADS), 0, s, ct, pt, pt_shared ? (u64)0 : pl, out, c.dmods(), (uint32_t)nparts,
                (uint32_t)c.logn, pl);
 }
@@ -1892,11 +1965,11 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     // the extenders copy the shared prefix rows verbatim; when both share all L rows the tensor
     // kernel reads those rows from the inputs directly and the copy is skipped
     const bool skip_copy = m.ext_lhs->ncommon == L && m.ext_rhs->ncommon == L && !FHE_LAB_FLAG("NO_SKIP_COPY");
-    struct ChunkWs {
-        WsGuard extL, extR, ten, d, pre;
+    struct ChunkWs {   // (ext: the extended lhs parts of the chunk, then the extended rhs parts)
+        WsGuard ext, ten, d, pre;
         ChunkWs(size_t chunk, u64 PK, u64 PL, size_t pre_bytes, hipStream_t st)
-            : extL(chunk * 2 * PK * sizeof(u64), st), extR(chunk * 2 * PK * sizeof(u64), st),
-              ten(chunk * 3 * PK * sizeof(u64), st), d(chunk * 3 * PL * sizeof(u64), st), pre(pre_bytes, st) {}
+            : ext(chunk * 4 * PK * sizeof(u64), st), ten(chunk * 3 * PK * sizeof(u64), st),
+              d(chunk * 3 * PL * sizeof(u64), st), pre(pre_bytes, st) {}
     };
     const size_t pre_bytes = m.mod_switch ? chunk * parts * PL * sizeof(u64) : 8;
     const bool dual = plan.dual;
@@ -1921,8 +1994,18 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
     // 259-358): the rhs extension would recompute the lhs one bit for bit, so it is skipped and the tensor kernel
     // reads the one extended operand twice (10 launches -> 7 per chunk; same values by construction).
     const bool square = lhs == rhs && m.ext_lhs == m.ext_rhs;
-    const bool split_ext = !dual && !square && m.streams.load(std::memory_order_relaxed) >= 2 && batch <= chunk &&
-                           FHE_LAB_INT("MUL_SPLIT_EXT", 1) != 0;
+    // Both operands through the same extender (Multiplicator::default; not the second HPS strategy): the two
+    // extensions are ONE pass of three launches over 4 nb polynomials (scale_polys_pair) -- round 4,
+    // profiles/r04_merged_ext_ab.txt.  Otherwise, for a batch that is one chunk, the two extension chains run side by
+    // side on the caller's and the internal stream (round 3's split_ext).
+    const bool merged_ext = !square && m.ext_lhs == m.ext_rhs && FHE_LAB_INT("MUL_MERGED_EXT", FHE_MUL_MERGED_EXT) != 0;
+    // Every kernel of the chain starts on what its producer wrote last (knobs.hpp FHE_MUL_DIRFLAGS): the extension ends
+    // ascending, so the tensor kernel runs descending, the down-scaler ascending, the transform of c0 / c1 descending
+    // and the key switch ascending again.  (Rows larger than LDS keep round 3's order: their transforms are two
+    // kernels each and the global halves run ascending.)
+    const bool dirflags = b.logn <= 14 && FHE_LAB_INT("MUL_DIRFLAGS", FHE_MUL_DIRFLAGS) != 0;
+    const bool split_ext = !dual && !square && !merged_ext && m.streams.load(std::memory_order_relaxed) >= 2 &&
+                           batch <= chunk && FHE_LAB_INT("MUL_SPLIT_EXT", 1) != 0;
     hipEvent_t ext_done = nullptr;
     struct EventBack {
         hipEvent_t &e;
@@ -1951,18 +2034,23 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         const size_t nb = std::min(chunk, batch - b0);
         const hipStream_t s = lanes[dual ? ci & 1 : 0];
         ChunkWs &w = (dual && (ci & 1)) ? *ws1 : ws0;
-        WsGuard &extL = w.extL, &extR = w.extR, &ten = w.ten, &d = w.d, &pre = w.pre;
+        WsGuard &ten = w.ten, &d = w.d, &pre = w.pre;
+        u64 *const extL = w.ext.u(), *const extR = w.ext.u() + nb * 2 * PK;
         const u64 *l = lhs + b0 * 2 * PL, *r = rhs + b0 * 2 * PL;
         // EXTEND (mul.rs:192-195): both parts of every lhs (rhs) ciphertext in one go
-        scale_polys(*m.ext_lhs, l, extL.u(), nb * 2, true, s, !skip_copy);
-        if (square) {
-            // (nothing: extR is never read)
-        } else if (split_ext) {   // (one chunk: the fork above put the internal stream behind the caller's earlier work)
-            scale_polys(*m.ext_rhs, r, extR.u(), nb * 2, true, join.aux, !skip_copy);
-            FHE_HIP_CHECK(hipEventRecord(ext_done, join.aux));
-            FHE_HIP_CHECK(hipStreamWaitEvent(s, ext_done, 0));
+        if (merged_ext) {
+            scale_polys_pair(*m.ext_lhs, l, r, extL, nb * 2, s, !skip_copy);
         } else {
-            scale_polys(*m.ext_rhs, r, extR.u(), nb * 2, true, s, !skip_copy);
+            scale_polys(*m.ext_lhs, l, extL, nb * 2, true, s, !skip_copy);
+            if (square) {
+                // (nothing: extR is never read)
+            } else if (split_ext) {   // (one chunk: the fork above put the internal stream behind the caller's earlier work)
+                scale_polys(*m.ext_rhs, r, extR, nb * 2, true, join.aux, !skip_copy);
+                FHE_HIP_CHECK(hipEventRecord(ext_done, join.aux));
+                FHE_HIP_CHECK(hipStreamWaitEvent(s, ext_done, 0));
+            } else {
+                scale_polys(*m.ext_rhs, r, extR, nb * 2, true, s, !skip_copy);
+            }
         }
         // TENSOR (mul.rs:198-201) + the inverse NTT of the down-scaler (M/rq/scaler.rs:69-79):
         // ten [3][nb][K][N] ends up in PowerBasis.  Rows that fit LDS: one fused kernel;
@@ -1970,14 +2058,14 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         const bool fused_tensor = e.logn <= 16 && !FHE_LAB_FLAG("NO_TENSOR_FUSION");
         if (fused_tensor) {
             require(nb <= 32768, E_ARG, "chunk too large for the fused tensor kernel");  // 3*K*nb blocks in a 1-D grid
-            k::TensorSrc ts{extL.u(), square ? extL.u() : extR.u(), skip_copy ? l : nullptr, skip_copy ? r : nullptr,
+            k::TensorSrc ts{extL, square ? extL : extR, skip_copy ? l : nullptr, skip_copy ? r : nullptr,
                             (uint32_t)L, (uint32_t)L};
-            launch_tensor_intt(e, ts, ten.u(), nb, s);
+            launch_tensor_intt(e, ts, ten.u(), nb, s, dirflags);
         } else {
             for (size_t t0 = 0; t0 < nb; t0 += 32768) {  // grid.y limit
                 const size_t tn = std::min<size_t>(32768, nb - t0);
                 FHE_LAUNCH("tensor", k::tensor_kernel, dim3(blocks_for(PK, EW_THREADS), (unsigned)tn), dim3(EW_THREADS), 0,
-                           s, extL.u() + t0 * 2 * PK, (square ? extL.u() : extR.u()) + t0 * 2 * PK, skip_copy ? l + t0 * 2 * PL : nullptr,
+                           s, extL + t0 * 2 * PK, (square ? extL : extR) + t0 * 2 * PK, skip_copy ? l + t0 * 2 * PL : nullptr,
                            skip_copy ? r + t0 * 2 * PL : nullptr, ten.u() + t0 * PK, e.dmods(), (uint32_t)K, (uint32_t)L,
                            (uint32_t)L, (uint32_t)e.logn, (u64)nb, 0u);
             }
@@ -1985,18 +2073,21 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         if (!fused_tensor) launch_ntt(e, true, ten.u(), ten.u(), full_map(e, K), nb * 3, s);
         u64 *dst = m.mod_switch ? pre.u() : out + b0 * parts * PL;
         // DOWN-SCALE (mul.rs:204-206) to PowerBasis rows of d [3][nb][L][N]
-        launch_scale(*m.down, ten.u(), PK, d.u(), PL, nb * 3, s);
+        // (dirflags: the tensor kernel ran backwards and ended on the first polynomials: the scaler starts there)
+        launch_scale(*m.down, ten.u(), PK, d.u(), PL, nb * 3, s, dirflags && fused_tensor);
+        k::RowMap back = full_map(b, L);
+        back.reverse = (dirflags && fused_tensor) ? 1u : 0u;   // ... and the forward transform where the scaler ended
         if (m.rk) {
             // c0, c1 go back to Ntt; c2 stays in PowerBasis for the key switch (the reference
             // transforms c2 forward and, at mul.rs:212, back again; iNTT(NTT(x)) = x exactly).
             // (Transforming c2 as well and handing it to the key switch as `xhat` was measured at C2: the key
             // switch gains 1.0 ms per 10 steps, the larger forward launch costs 1.6: profiles/r02_mul_xhat_ab.txt.)
-            launch_ntt(b, false, d.u(), d.u(), full_map(b, L), nb * 2, s);
+            launch_ntt(b, false, d.u(), d.u(), back, nb * 2, s);
             // RELINEARIZE (mul.rs:211-227): (c0, c1) += key_switch(c2), written to the output layout
             key_switch_add(*m.rk, d.u() + 2 * nb * PL, PL, d.u(), d.u() + nb * PL, PL, dst, dst + PL, 2 * PL, nb, s);
         } else {
             // no relinearisation: three Ntt parts, slot-major scratch -> [b][3][L][N]
-            launch_ntt(b, false, d.u(), d.u(), full_map(b, L), nb * 3, s);
+            launch_ntt(b, false, d.u(), d.u(), back, nb * 3, s);
             for (size_t slot = 0; slot < 3; slot++) {
                 const u64 total = (u64)nb * PL;
                 FHE_LAUNCH("copy_rows", k::copy_rows_kernel, dim3(blocks_for(total, EW_THREADS)), dim3(EW_THREADS), 0,

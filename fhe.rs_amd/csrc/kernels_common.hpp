@@ -13,6 +13,25 @@ struct u64x2 {
     u64 x, y;
 };
 
+// Streaming accesses: data that ONE lane reads or writes once (a database row of the PIR loop, a ciphertext that is
+// multiplied by a plaintext and never looked at again) is marked non-temporal, so that it does not push the operands
+// other workgroups re-read (shared queries, keys, tables) out of L2 / the Infinity Cache.  (FHE_STREAM_NT, knobs.hpp)
+#if defined(__HIP_DEVICE_COMPILE__) && FHE_STREAM_NT
+typedef u64 u64v2_native __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u64x2 load_stream(const u64x2 *p) {
+    const u64v2_native v = __builtin_nontemporal_load(reinterpret_cast<const u64v2_native *>(p));
+    return u64x2{v.x, v.y};
+}
+__device__ __forceinline__ void store_stream(u64x2 *p, u64x2 v) {
+    u64v2_native w;
+    w.x = v.x, w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<u64v2_native *>(p));
+}
+#else
+__device__ __forceinline__ u64x2 load_stream(const u64x2 *p) { return *p; }
+__device__ __forceinline__ void store_stream(u64x2 *p, u64x2 v) { *p = v; }
+#endif
+
 // FHE_TS(k): phase-timing stamps of one wave, compiled to nothing except in -DFHE_LAB -DFHE_PHASE_TIMING builds
 // (tools/ks_phase_timing.py).
 #if defined(FHE_LAB) && defined(FHE_PHASE_TIMING)
@@ -31,7 +50,20 @@ struct RowMap {
     int32_t mod_offset;  // modulus index of row r is mod_offset + r
     int32_t src_row_fixed;
     u64 src_poly_stride, dst_poly_stride;  // in u64 elements
+    // Two source arrays in one launch (the operand extensions of a multiply: lhs and rhs ciphertexts live in separate
+    // buffers, their transforms go to ONE scratch array): polynomials [split, ...) are read from
+    // in2 + (poly - split) * src_poly_stride.  in2 == nullptr: one source (every other launch).
+    const u64 *in2;
+    uint32_t split;
+    // workgroups walk the launch's tiles from the last one backwards (the producer of `in` ran ascending, so its
+    // most recent output -- what still sits in the Infinity Cache -- is at the end)
+    uint32_t reverse;
 };
+// the source polynomial of workgroup-uniform index `poly`
+__device__ __forceinline__ const u64 *rowmap_src(const RowMap &map, const u64 *in, uint32_t poly) {
+    return (map.in2 != nullptr && poly >= map.split) ? map.in2 + (u64)(poly - map.split) * map.src_poly_stride
+                                                     : in + (u64)poly * map.src_poly_stride;
+}
 
 
 // LDS padding: one extra u64 every 16 keeps the 16-element-strided accesses of the last

@@ -9,7 +9,10 @@ namespace k {
 // ----------------------------------------------------------------- switch_down ----
 // Poly::switch_down (M/rq/mod.rs:433-492), one lane per coefficient:
 // in [npolys][L][N] PowerBasis -> out [npolys][L-1][N].
-__global__ void switch_down_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,
+// `in` and `out` MAY ALIAS with equal strides (switch_down_to_pb walks the levels in one scratch block): hence no
+// __restrict__ on them, and the in-place contract is what the loop below already does -- a lane touches only its own
+// column, reads the last row first, and reads row r before it writes row r.
+__global__ void switch_down_kernel(const u64 *in, u64 *out, u64 in_poly_stride,
                                    u64 out_poly_stride, const DevMod *__restrict__ mods,
                                    const u64x2 *__restrict__ inv_last, uint32_t nmod, uint32_t logn, u64 total) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,11 +154,14 @@ __global__ void __launch_bounds__(256, 8) dot_kernel(const u64 *__restrict__ cts
     Acc192 a0[NP], a1[NP];
 #pragma unroll 4   // (2 -> 4: +2 %; 8: no further gain -- the kernel runs at 4.0 TB/s of fabric reads, PMC FETCH_SIZE)
     for (uint32_t k = 0; k < count; k++) {
-        const u64x2 y = *reinterpret_cast<const u64x2 *>(pp + (u64)k * pl);
+        // (an operand array that is private to this batch element -- stride != 0 -- is read exactly once: streaming)
+        const u64x2 *yp = reinterpret_cast<const u64x2 *>(pp + (u64)k * pl);
+        const u64x2 y = pt_batch_stride ? load_stream(yp) : *yp;
 #pragma unroll
         for (int q = 0; q < NP; q++) {
             if (part0 + q < nparts) {
-                const u64x2 x = *reinterpret_cast<const u64x2 *>(cp + ((u64)k * nparts + q) * pl);
+                const u64x2 *xp = reinterpret_cast<const u64x2 *>(cp + ((u64)k * nparts + q) * pl);
+                const u64x2 x = ct_batch_stride ? load_stream(xp) : *xp;
                 mac192(a0[q], x.x, y.x);
                 mac192(a1[q], x.y, y.y);
             }
@@ -199,15 +205,25 @@ __global__ void tensor_general_kernel(const u64 *__restrict__ a, const u64 *__re
 }
 
 // `Ciphertext * Plaintext` (F/bfv/ops/mod.rs:229-257): out[b][part] = ct[b][part] (.) pt[b].
-__global__ void mul_plain_kernel(const u64 *__restrict__ ct, const u64 *__restrict__ pt, u64 pt_batch_stride,
-                                 u64 *__restrict__ out, const DevMod *__restrict__ mods, uint32_t nparts, uint32_t logn,
-                                 u64 pl) {
-    const u64 off = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (off >= pl) return;
-    const uint32_t part = blockIdx.y, b = blockIdx.z;
+// One lane per 16-byte chunk of the polynomial and ALL parts (the plaintext word is loaded once); the ciphertext and
+// the result are touched once each: streaming accesses.  grid = (ceil(pl / 2 / block), 1, batch).
+// (Round 3's form -- one lane per coefficient and part, 8-byte accesses, the plaintext read once per part -- ran at
+// 0.53 of 8 TB/s; profiles/r04_next_rows_ab.txt.)
+__global__ void __launch_bounds__(256)
+    mul_plain_kernel(const u64 *__restrict__ ct, const u64 *__restrict__ pt, u64 pt_batch_stride, u64 *__restrict__ out,
+                     const DevMod *__restrict__ mods, uint32_t nparts, uint32_t logn, u64 pl) {
+    const u64 pair = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * pair >= pl) return;
+    const u64 off = 2 * pair;
+    const uint32_t b = blockIdx.z;
     const DevMod m = mods[off >> logn];
-    const u64 idx = ((u64)b * nparts + part) * pl + off;
-    out[idx] = mul_mod(ct[idx], pt[(u64)b * pt_batch_stride + off], m);
+    const u64x2 *pp = reinterpret_cast<const u64x2 *>(pt + (u64)b * pt_batch_stride + off);
+    const u64x2 y = pt_batch_stride ? load_stream(pp) : *pp;   // (a plaintext shared by the batch is re-read: cached)
+    for (uint32_t part = 0; part < nparts; part++) {
+        const u64 idx = ((u64)b * nparts + part) * pl + off;
+        const u64x2 x = load_stream(reinterpret_cast<const u64x2 *>(ct + idx));
+        store_stream(reinterpret_cast<u64x2 *>(out + idx), u64x2{mul_mod(x.x, y.x, m), mul_mod(x.y, y.y, m)});
+    }
 }
 
 // SecretKey::try_decrypt (F/bfv/keys/secret_key.rs:205-247).  phase_kernel: out[b] = sum_i
@@ -286,6 +302,64 @@ __global__ void wire_unpack_kernel(const uint8_t *__restrict__ bytes, u64 *__res
         cur >>= nbits;
         have -= nbits;
     }
+}
+
+// The same transcoding for rows of 128 coefficients and more (a row is then a whole number of 16-byte words on both
+// sides), shaped for the memory system instead of after the reference's shift register (round 4: the kernels above
+// wrote / read single bytes at a stride of nbits per lane and ran at 0.06 / 0.11 of the HBM roofline):
+// one lane per 16 bytes of OUTPUT, written (pack) or read-combined (unpack) with full-width coalesced accesses; the
+// other side is read at word granularity -- neighbouring lanes touch neighbouring or the same words, which the vector
+// cache merges, so HBM traffic stays at one pass over both arrays.
+// pack: output word j holds stream bits [64 j, 64 j + 64): coefficient c0 = 64 j / nbits from bit 64 j - c0 nbits on,
+// then the following coefficients shifted up, until 64 bits are there.
+__device__ __forceinline__ u64 wire_pack_word(const u64 *__restrict__ row, uint32_t j, uint32_t nbits, u64 mask, uint32_t n) {
+    const uint32_t bit = 64u * j;
+    uint32_t c = bit / nbits;
+    const uint32_t off = bit - c * nbits;            // bits of coefficient c already consumed by word j - 1
+    u64 w = (row[c] & mask) >> off;
+    uint32_t have = nbits - off;
+    while (have < 64 && ++c < n) {
+        w |= (row[c] & mask) << have;                // (bits beyond 64 fall off: they belong to word j + 1)
+        have += nbits;
+    }
+    return w;
+}
+__global__ void __launch_bounds__(256)
+    wire_pack_words_kernel(const u64 *__restrict__ polys, uint8_t *__restrict__ bytes, const DevMod *__restrict__ mods,
+                           uint32_t nmod, uint32_t logn, u64 poly_bytes) {
+    const uint32_t r = blockIdx.y, poly = blockIdx.z, n = 1u << logn;
+    const uint32_t nbits = wire_bits(mods[r].p);
+    const uint32_t pairs = (n >> 7) * nbits;         // 16-byte words of the packed row: n * nbits / 128
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pairs) return;
+    const u64 mask = ~0ull >> (64 - nbits);
+    const u64 *row = polys + (((u64)poly * nmod + r) << logn);
+    u64x2 o;
+    o.x = wire_pack_word(row, 2 * g, nbits, mask, n);
+    o.y = wire_pack_word(row, 2 * g + 1, nbits, mask, n);
+    reinterpret_cast<u64x2 *>(bytes + (u64)poly * poly_bytes + wire_row_offset(mods, r, logn))[g] = o;
+}
+// unpack: coefficient e is stream bits [e nbits, (e + 1) nbits): at most two 64-bit words of the packed row
+__device__ __forceinline__ u64 wire_unpack_coeff(const u64 *__restrict__ words, uint32_t e, uint32_t nbits, u64 mask) {
+    const u64 bit = (u64)e * nbits;
+    const uint32_t w = (uint32_t)(bit >> 6), off = (uint32_t)(bit & 63);
+    u64 v = words[w] >> off;
+    if (off + nbits > 64) v |= words[w + 1] << (64 - off);     // (only then does the coefficient reach into word w + 1)
+    return v & mask;
+}
+__global__ void __launch_bounds__(256)
+    wire_unpack_words_kernel(const uint8_t *__restrict__ bytes, u64 *__restrict__ polys, const DevMod *__restrict__ mods,
+                             uint32_t nmod, uint32_t logn, u64 poly_bytes) {
+    const uint32_t r = blockIdx.y, poly = blockIdx.z, n = 1u << logn;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * g >= n) return;
+    const uint32_t nbits = wire_bits(mods[r].p);
+    const u64 mask = ~0ull >> (64 - nbits);
+    const u64 *words = reinterpret_cast<const u64 *>(bytes + (u64)poly * poly_bytes + wire_row_offset(mods, r, logn));
+    u64x2 o;
+    o.x = wire_unpack_coeff(words, 2 * g, nbits, mask);
+    o.y = wire_unpack_coeff(words, 2 * g + 1, nbits, mask);
+    reinterpret_cast<u64x2 *>(polys + (((u64)poly * nmod + r) << logn))[g] = o;
 }
 
 // Oblivious expansion (F/bfv/keys/evaluation_key.rs:233-244).  monomial_kernel writes the

@@ -27,15 +27,16 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     const uint32_t tid = threadIdx.x;
     const uint32_t n = 1u << logn;
     const uint32_t nsub = 1u << (logn - LOGM);
-    const uint32_t sub = blockIdx.x & (nsub - 1);
-    const uint32_t rowb = blockIdx.x >> (logn - LOGM);
+    const uint32_t bid = map.reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const uint32_t sub = bid & (nsub - 1);
+    const uint32_t rowb = bid >> (logn - LOGM);
     const uint32_t poly = to_sgpr(rowb / map.rows);
     const uint32_t r = map.row_begin + (rowb - poly * map.rows);
     const uint32_t mi = (uint32_t)(map.mod_offset + (int32_t)r);
     const DevMod md = mods[mi];
     const u64 p = md.p, p2 = md.p2;
     const PM pm = make_pm(md);
-    const u64 *src = in + (u64)poly * map.src_poly_stride +
+    const u64 *src = rowmap_src(map, in, poly) +
                      (u64)(map.src_row_fixed >= 0 ? (uint32_t)map.src_row_fixed : r) * n + (u64)sub * M;
     u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * n + (u64)sub * M;
     const u64x2 *twr = tw + (u64)mi * n;
@@ -96,7 +97,7 @@ template <int LOGM, bool SUB = false, bool NARROW = false>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     tensor_intt_kernel(TensorSrc ts, u64 *__restrict__ out, const DevMod *__restrict__ mods,
                        const u64x2 *__restrict__ itw, const u64x2 *__restrict__ ninv, uint32_t nrows, uint32_t nb,
-                       uint32_t logn_arg, uint32_t row_begin, uint32_t lrows) {
+                       uint32_t logn_arg, uint32_t row_begin, uint32_t lrows, uint32_t reverse) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ntt_threads_c(LOGM);
     constexpr int M = 1 << LOGM;
@@ -108,8 +109,12 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     // own L2.  The three slots of one (row, ciphertext) pair read the same four operand rows, so their
     // ids are 8 apart: same XCD, dispatched back to back, and the re-reads hit that L2 instead of HBM
     // (a (row, pair, slot) 3-D grid put them nb*K blocks apart: 1.8x the algorithmic HBM traffic).
-    const uint32_t t8 = blockIdx.x >> 3, grp = t8 / 3, slot = t8 - 3 * grp;
-    const uint32_t combo = grp * 8 + (blockIdx.x & 7);
+    // `reverse`: the launch walks its groups from the last one backwards (the extension's forward transform, which
+    // wrote the operands, ran ascending).  The grid is a multiple of 8, so (gridDim.x - 1 - id) & 7 = 7 - (id & 7):
+    // workgroups of one hardware XCD still share one residue class, i.e. the three slots of a group stay on one L2.
+    const uint32_t bid = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const uint32_t t8 = bid >> 3, grp = t8 / 3, slot = t8 - 3 * grp;
+    const uint32_t combo = grp * 8 + (bid & 7);
     if (combo >= (lrows * nb) << lsub) return;  // (block-uniform) tail of the rounded-up grid
     const uint32_t sub = combo & ((1u << lsub) - 1), rowb = combo >> lsub;
     const uint32_t b = to_sgpr(rowb / lrows), r = row_begin + (rowb - b * lrows);
@@ -228,7 +233,7 @@ __global__ void ntt_global_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
     const DevMod md = mods[mi];
     const u64 p = md.p;
     const PM pm = make_pm(md);
-    const u64 *src = in + (u64)poly * map.src_poly_stride +
+    const u64 *src = rowmap_src(map, in, poly) +
                      (u64)(map.src_row_fixed >= 0 ? (uint32_t)map.src_row_fixed : r) * n;
     u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * n;
     const u64x2 *twr = tw + (u64)mi * n;

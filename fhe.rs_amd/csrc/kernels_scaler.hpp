@@ -23,6 +23,7 @@ struct ScalerDev {
     const u64 *fold_tab;                                 // [nto][64]  i * 2^(2k_j) mod q_j
     uint32_t theta_gamma_sign, is_one, shift, nfrom, nto, ncommon;
     uint32_t v_fits_64;  // v < 2^64 for every input (factor-one scalers over few moduli): no v_hi term
+    uint32_t wide_w;     // |t| can reach 2^191 (host-side bound, scaler_upload): the launch takes the WIDE_W instance
 };
 
 // Sum of 64x64-bit products on the device: the four 32x32 partial products of a term go straight
@@ -132,18 +133,25 @@ FHE_HD void acc192_resolve(const Acc192 &acc, u128_t &low, u64 &top) {
 // Round 3: everything between the multiply-add blocks (column resolves, the 256-bit shifts, rounding, the small
 // addends of the output sums) is written on 32-bit limbs with add-with-carry chains (zq_dev.hpp): the u128 / U256 C
 // of rounds 1-2 compiled to roughly as many instructions as the multiplies themselves.
-template <int NF, bool PLAIN>
+// WIDE_W: the fast path takes w's sign from bit 255 of t and keeps 68 bits of w -- equal to the
+// reference's `t >> 191 > 0` test and 128-bit w (scaler.rs:303-313) exactly as long as |t| < 2^191, which the host
+// proves from the moduli and thetas for every BFV scaler (the theta_omega of the extension moduli are zero).  A
+// non-unit factor over many wide moduli can leave that range; there the reference's result is defined by its bit
+// tests, not by the mathematics, and this instance reproduces them: sign = any of bits 191 ... 255, w = the low 128
+// bits of (sign ? ~t : t) >> 126, +1 (wrapping) and halved / halved upwards, reduced mod q per target.
+template <int NF, bool PLAIN, bool WIDE_W = false>
 __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs / 8 waves per SIMD measured 3 % faster)
     scale_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 in_poly_stride,
                              u64 out_poly_stride, ScalerDev s, const DevMod *__restrict__ to_mods, uint32_t logn,
-                             u64 total) {
+                             u64 total, uint32_t ascending) {
     u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     // Columns are handed out from the LAST polynomial backwards: the kernel that wrote `in` (an inverse NTT, the
     // fused tensor kernel) went through the polynomials in ascending order, so its most recent output is what
     // still sits in the 256 MiB Infinity Cache; and the forward NTT that follows this kernel (ascending again)
     // starts on what was written here last.  Same-box A/B: -1.2 % per ct x ct step, -3 % on that forward NTT.
-    gid = total - 1 - gid;
+    // (`ascending`: the caller knows that the producer ran backwards -- the multiply's tensor kernel since round 4)
+    if (!ascending) gid = total - 1 - gid;
     const uint32_t n = 1u << logn;
     const uint32_t col = (uint32_t)(gid & (n - 1));
     const u64 poly = gid >> logn;
@@ -174,6 +182,8 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
     }
     u64 wx = 0;            // w's low word, complemented when w is subtracted (see the output sums)
     uint32_t widx = 0;     // index of w's contribution in w_tab: 16 * (w subtracted) + (w >> 64)
+    u64 ww_lo = 0, ww_hi = 0;   // WIDE_W: the reference's 128-bit w
+    bool ww_neg = false;
     if constexpr (!PLAIN) {
         if (!s.is_one) {
             // t = sum_i +/- r_i * theta_omega_i  -/+  v * theta_gamma  (mod 2^256, scaler.rs:278-301).  ONE accumulator:
@@ -212,13 +222,25 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
             }
             // w = ceil(X / 2) with X = (t negative ? ~t : t) >> 126  -- scaler.rs:303-313 writes the negative case as
             // ((!t >> 126) + 1) >> 1, which is the same rounding; |w| < 2^68, so three limbs of X are enough
-            const uint32_t m = (uint32_t)((int32_t)W[7] >> 31);   // all ones: t is negative, w is subtracted
+            if constexpr (WIDE_W) {
+                // scaler.rs:303-313 to the letter (see the template's comment)
+                ww_neg = ((W[5] >> 31) | W[6] | W[7]) != 0;
+                const uint32_t mm = ww_neg ? ~0u : 0u;
+                // X = the low 128 bits of (t ^ mm) >> 126 (`as_u128()`): bit 126 is bit 30 of limb 3; the two top bits
+                // of the shifted value (bits 254, 255 of t ^ mm) would land in bits 128, 129 and are dropped
+                const u128_t X =
+                    ((u128_t)pack64(funnel32(W[6] ^ mm, W[5] ^ mm, 30), funnel32(W[7] ^ mm, W[6] ^ mm, 30)) << 64) |
+                    pack64(funnel32(W[4] ^ mm, W[3] ^ mm, 30), funnel32(W[5] ^ mm, W[4] ^ mm, 30));
+                const u128_t w128 = ww_neg ? (X + 1) >> 1 : (X >> 1) + (X & 1);
+                ww_lo = (u64)w128, ww_hi = (u64)(w128 >> 64);
+            }
+            const uint32_t m = WIDE_W ? 0u : (uint32_t)((int32_t)W[7] >> 31);   // all ones: t is negative, w is subtracted
             uint32_t x0 = funnel32(W[4] ^ m, W[3] ^ m, 30), x1 = funnel32(W[5] ^ m, W[4] ^ m, 30),
                      x2 = funnel32(W[6] ^ m, W[5] ^ m, 30);
             ceil_half3(x0, x1, x2);
             // -w = -(w_hi 2^64 + w_lo) = ~w_lo + (1 - (w_hi + 1) 2^64): the complemented low word goes into the output
             // sums as it is, the rest is a per-target table entry (w_tab, 16 + w_hi)
-            wx = pack64(x0 ^ m, x1 ^ m);
+            wx = WIDE_W ? 0 : pack64(x0 ^ m, x1 ^ m);
             widx = (m & 16) + (x2 & 15);
         }
     }
@@ -252,7 +274,15 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
             // bound on v (scaler_upload: v <= sum_i (q_i - 1) + 1) says v_hi is always zero; +/- w: its high part and
             // the constant of the complement through w_tab, its (complemented) low word straight into the sum
             u64 small = s.v_fits_64 ? 0 : s.vhi_tab[jt * 16 + vh];
-            if (!s.is_one) small += s.w_tab[jt * 32 + widx];   // below 2q
+            if constexpr (WIDE_W) {
+                // +/- (w mod q): any representative of the class gives the same canonical output
+                if (!s.is_one) {
+                    const u64 wr = reduce_u128(ww_hi, ww_lo, q);
+                    small += ww_neg ? (wr ? q.p - wr : 0) : wr;
+                }
+            } else {
+                if (!s.is_one) small += s.w_tab[jt * 32 + widx];   // below 2q
+            }
             uint32_t k = 0;
             const uint32_t e0 = addc32(lo32(wx), lo32(small), k), e1 = addc32(hi32(wx), hi32(small), k), e2 = k;
             k = 0;

@@ -12,7 +12,8 @@
 #if defined(FHE_SENS) || defined(FHE_MAD_CARRY) || defined(FHE_MAD_CROSS) || defined(FHE_APPROX_SHOUP) || defined(FHE_KS_LATE) ||             \
     defined(FHE_KS_TWPF) || defined(FHE_KS_PERSIST14) || defined(FHE_KS_KPF_CHUNKS) || defined(FHE_TENSOR_TW_EARLY) ||  \
     defined(FHE_KS_EXPERIMENTS) || defined(FHE_PHASE_TIMING) || defined(FHE_LDS_PAD) || defined(FHE_NO_WAVE_SYNC) || \
-    defined(FHE_DIAG_NO_SGPR_ASM) || defined(FHE_KS_HALF13) || defined(FHE_KS_SPLIT_XCD)
+    defined(FHE_DIAG_NO_SGPR_ASM) || defined(FHE_KS_HALF13) || defined(FHE_KS_SPLIT_XCD) || defined(FHE_STREAM_NT) || \
+    defined(FHE_MUL_DIRFLAGS) || defined(FHE_MUL_MERGED_EXT)
 #error "kernel-variant macros are lab-only: add -DFHE_LAB (the release build pins every knob, see knobs.hpp)"
 #endif
 #endif
@@ -55,4 +56,19 @@
 // Fused tensor + iNTT: first-pass twiddles requested half-way through the products.
 #ifndef FHE_TENSOR_TW_EARLY
 #define FHE_TENSOR_TW_EARLY 1
+#endif
+// Non-temporal loads / stores on the streaming operands of the element-wise kernels (kernels_common.hpp load_stream).
+#ifndef FHE_STREAM_NT
+#define FHE_STREAM_NT 1
+#endif
+// Multiply pipeline: every kernel starts on what its producer wrote last (tensor+iNTT descending, down-scaler
+// ascending, the forward transform of c0, c1 descending); 0: round 3's order (only the scalers run backwards).
+// Measured (profiles/r04_merged_ext_dirflags_ab.txt, same box, alternating): no change at any batch size -- off.
+#ifndef FHE_MUL_DIRFLAGS
+#define FHE_MUL_DIRFLAGS 0
+#endif
+// Multiply pipeline: the lhs and rhs extensions as one pass of three launches when both use the same extender.
+// Measured (same file): batch 1024 unchanged (power-limited), batch 64 -5 %, batch 16 -12.5 % -- on.
+#ifndef FHE_MUL_MERGED_EXT
+#define FHE_MUL_MERGED_EXT 1
 #endif

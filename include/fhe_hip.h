@@ -131,7 +131,12 @@ fhe_status fhe_ctx_moduli(const fhe_ctx *ctx, uint64_t *out /* [nmoduli] */);
 fhe_status fhe_ctx_get_table(const fhe_ctx *ctx, int which, uint64_t *out);
 
 /* NttOperator::{forward,backward} via Poly::{ntt_forward,ntt_backward} (M/rq/mod.rs:335-354):
- * `polys` is [batch][L][N], transformed in place, canonical outputs. */
+ * `polys` is [batch][L][N], transformed in place, canonical outputs.
+ * The reference also has a lazy forward transform, NttOperator::forward_vt_lazy (M/ntt/native.rs:142-175, outputs in
+ * [0, 2p)); its only caller on the path is the key switch's lift-and-transform (M/rq/mod.rs:563-586), which the
+ * engine performs inside fhe_key_switch and its relatives.  No `lazy` flag is exported on purpose (SURVEY 8b's draft
+ * signature had one): only canonical residues cross this ABI -- a value in [0, 2p) is not a function of the inputs
+ * alone, and bit-exact parity is stated on canonical values. */
 fhe_status fhe_ntt_forward(const fhe_ctx *ctx, uint64_t *polys, size_t batch);
 fhe_status fhe_ntt_backward(const fhe_ctx *ctx, uint64_t *polys, size_t batch);
 fhe_status fhe_ntt_forward_dev(const fhe_ctx *ctx, uint64_t *polys, size_t batch, void *stream);

@@ -1122,3 +1122,31 @@ def case_workspace_bounds(fhe, make_stream, kill_stream, nstreams=40, nmod=3, n=
     s2.destroy()
     fhe.workspace_trim()
     fhe.workspace_set_limit()            # back to the defaults
+
+
+def case_scaler_many_wide_moduli(fhe, dev, n=16, counts=(9, 24, 40), factors=((3, 7), (1, 46116860181065), (5, 1))):
+    """ADVICE r03: non-unit factors over MANY 62-bit source moduli, where the fixed-point sum t of RnsScaler::scale
+    (rns/scaler.rs:278-313) leaves the range in which its sign and w are what the mathematics says: the reference then
+    returns what its bit tests (`t >> 191 > 0`, the low 128 bits of `t >> 126`) give, and so must the engine -- 9
+    moduli stay on the fast instance, 24 and 40 take the one that reproduces those tests (scaler_upload's bound)."""
+    from fhe_oracle.zq import generate_prime
+    x = Xfer(dev)
+    rng = random.Random(31)
+    primes, up = [], 1 << 62
+    while len(primes) < max(counts) + 3:
+        up = generate_prime(62, 2 * n, up)
+        primes.append(up)
+    to_mods = primes[-3:]
+    for cnt in counts:
+        src = primes[:cnt]
+        of, ot = OCtx(src, n), OCtx(to_mods, n)
+        cf, ct = fhe.Context(src, n), fhe.Context(to_mods, n)
+        for num, den in factors:
+            osc = OScaler(of, ot, ScalingFactor(num, den))
+            sc = fhe.Scaler(cf, ct, num, den)
+            polys = [rand_poly(of, POWER_BASIS, rng) for _ in range(3)]
+            polys.append(Poly(of, POWER_BASIS, [[m - 1] * n for m in src]))
+            polys.append(Poly(of, POWER_BASIS, [[(m - 1) if (i + r) % 2 else 0 for i in range(n)] for r, m in enumerate(src)]))
+            got = x.back(sc.scale(x.to(np.stack([arr(p) for p in polys])), ntt=False))
+            for i, p in enumerate(polys):
+                assert np.array_equal(got[i], arr(osc.scale(p))), (cnt, num, den, i)

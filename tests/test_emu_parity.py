@@ -164,8 +164,10 @@ def test_expand(fhe):
     cases.case_expand(fhe, False)
 
 
-def test_wire_format(fhe):
-    cases.case_wire_format(fhe, False)
+@pytest.mark.parametrize("n", [32, 128, 1024])
+def test_wire_format(fhe, n):
+    """n = 32: the byte-granular kernels; n >= 128: the word-granular ones (rows are whole 16-byte words)."""
+    cases.case_wire_format(fhe, False, n=n)
 
 
 def test_tensor_any_parts(fhe):
@@ -357,3 +359,7 @@ def test_workspace_bounds(fhe):
     L.fhe_emu_stream_create.restype = C.c_void_p
     L.fhe_emu_stream_destroy.argtypes = [C.c_void_p]
     cases.case_workspace_bounds(fhe, lambda: L.fhe_emu_stream_create(), lambda h: L.fhe_emu_stream_destroy(h))
+
+
+def test_scaler_many_wide_moduli(fhe):
+    cases.case_scaler_many_wide_moduli(fhe, False)

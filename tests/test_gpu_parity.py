@@ -674,3 +674,8 @@ def test_workspace_1000_foreign_streams_c2(fhe):
     assert fhe.workspace_stats()["internal_streams"] <= 32 + 3
     fhe.workspace_trim()
     fhe.workspace_set_limit()
+
+
+@pytest.mark.parametrize("dev", [False, True])
+def test_scaler_many_wide_moduli(fhe, dev):
+    cases.case_scaler_many_wide_moduli(fhe, dev)

@@ -582,9 +582,10 @@ __global__ void __launch_bounds__(256)
         if (i0) fold(a0x), fold(a0y), fold(a1x), fold(a1y);
 #pragma unroll 4
         for (uint32_t i = i0; i < i1; i++) {
+            // (W is read exactly once, by this lane: a streaming load; the key words are every polynomial's: cached)
             const u64x2 xv = (own && i == j)
                                  ? *reinterpret_cast<const u64x2 *>(xhat + (u64)b * xhat_poly_stride + (u64)j * n + roff)
-                                 : *reinterpret_cast<const u64x2 *>(wp + (u64)i * jg * n);
+                                 : load_stream(reinterpret_cast<const u64x2 *>(wp + (u64)i * jg * n));
             const u64x2 q0 = *reinterpret_cast<const u64x2 *>(kp0 + (u64)i * lk * n);
             const u64x2 q1 = *reinterpret_cast<const u64x2 *>(kp1 + (u64)i * lk * n);
             mac(a0x, xv.x, q0.x);

@@ -32,6 +32,22 @@ __device__ __forceinline__ u64x2 load_stream(const u64x2 *p) { return *p; }
 __device__ __forceinline__ void store_stream(u64x2 *p, u64x2 v) { *p = v; }
 #endif
 
+// (last-use loads of the multiply pipeline, knobs.hpp FHE_PIPE_NT)
+template <bool NT>
+__device__ __forceinline__ u64 load_last(const u64 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ u64x2 load_last2(const u64x2 *p) {
+#if defined(__HIP_DEVICE_COMPILE__) && FHE_STREAM_NT
+    if constexpr (NT) return load_stream(p);
+#endif
+    return *p;
+}
+
 // FHE_TS(k): phase-timing stamps of one wave, compiled to nothing except in -DFHE_LAB -DFHE_PHASE_TIMING builds
 // (tools/ks_phase_timing.py).
 #if defined(FHE_LAB) && defined(FHE_PHASE_TIMING)

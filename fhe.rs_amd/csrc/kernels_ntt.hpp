@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
 
     if constexpr (!INVERSE) {
         // the first pass reads its groups straight from global memory (no tile staging)
-        ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? 1 : 0)>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) { return src[i]; });
+        ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? 1 : 0)>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) { return load_last<(FHE_PIPE_NT & 2) != 0>(src + i); });
         if constexpr (NARROW) {  // < 16p -> canonical
             const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
             lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) {
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         const bool whole = logn == LOGM;  // ninv[2*mi] = {N^-1, shoup}, ninv[2*mi+1] = {z_last * N^-1, shoup}
         // (feeding the first pass straight from global memory, as the forward transform does, was
         // measured for the inverse: no gain -- its groups are runs of consecutive coefficients)
-        tile_to_lds<CH, M, T>(lds, src, tid, [](u64 v) { return v; });
+        tile_to_lds<CH, M, T, (FHE_PIPE_NT & 4) != 0>(lds, src, tid, [](u64 v) { return v; });
         FHE_BARRIER();
         ntt_inv_lds<LOGM, T, 0, 0, NARROW>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1], tw0);
         if (whole)

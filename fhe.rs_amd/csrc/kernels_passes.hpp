@@ -439,13 +439,13 @@ __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ 
 // Thread t owns the 16-byte chunks {c*T + t}, c < CH, of the M-element tile (coalesced 16 B
 // per lane).  CH > 0: all CH loads are issued before the first LDS write (one latency, not
 // CH).  CH == 0: scalar strided loop for tiles smaller than 2*T (tiny test sizes).
-template <int CH, int M, int T, class F>
+template <int CH, int M, int T, bool NT = false, class F>
 __device__ __forceinline__ void tile_to_lds(u64 *lds, const u64 *__restrict__ src, uint32_t tid, F f) {
     if constexpr (CH > 0) {
         const u64x2 *s2 = reinterpret_cast<const u64x2 *>(src);
         u64x2 v[CH];
 #pragma unroll
-        for (int c = 0; c < CH; c++) v[c] = s2[c * T + tid];
+        for (int c = 0; c < CH; c++) v[c] = load_last2<NT>(s2 + c * T + tid);
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const uint32_t i = 2 * (c * T + tid);

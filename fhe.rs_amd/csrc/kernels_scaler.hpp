@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 8 : 1)   // (NF <= 4: 64 VGPRs 
     const u64 *src = in + poly * in_poly_stride + col;
     u64 rests[NF];
 #pragma unroll
-    for (int i = 0; i < NF; i++) rests[i] = (uint32_t)i < s.nfrom ? src[(u64)i * n] : 0;
+    for (int i = 0; i < NF; i++) rests[i] = (uint32_t)i < s.nfrom ? load_last<(FHE_PIPE_NT & 1) != 0>(src + (u64)i * n) : 0;
 
     // (all per-source tables are zero-padded to NF entries by the host, scaler_upload: the term loops run without
     // per-term bounds checks -- a padded term multiplies a zero residue by a zero constant -- so the constants of

@@ -13,7 +13,7 @@
     defined(FHE_KS_TWPF) || defined(FHE_KS_PERSIST14) || defined(FHE_KS_KPF_CHUNKS) || defined(FHE_TENSOR_TW_EARLY) ||  \
     defined(FHE_KS_EXPERIMENTS) || defined(FHE_PHASE_TIMING) || defined(FHE_LDS_PAD) || defined(FHE_NO_WAVE_SYNC) || \
     defined(FHE_DIAG_NO_SGPR_ASM) || defined(FHE_KS_HALF13) || defined(FHE_KS_SPLIT_XCD) || defined(FHE_STREAM_NT) || \
-    defined(FHE_MUL_DIRFLAGS) || defined(FHE_MUL_MERGED_EXT)
+    defined(FHE_MUL_DIRFLAGS) || defined(FHE_MUL_MERGED_EXT) || defined(FHE_PIPE_NT)
 #error "kernel-variant macros are lab-only: add -DFHE_LAB (the release build pins every knob, see knobs.hpp)"
 #endif
 #endif
@@ -71,4 +71,9 @@
 // Measured (same file): batch 1024 unchanged (power-limited), batch 64 -5 %, batch 16 -12.5 % -- on.
 #ifndef FHE_MUL_MERGED_EXT
 #define FHE_MUL_MERGED_EXT 1
+#endif
+// Multiply pipeline: non-temporal LOADS where a kernel reads data for the last time (the scalers' input columns, the
+// forward transforms' rows, the inverse transform's tile): bit 0 scalers, bit 1 forward NTT, bit 2 inverse NTT.
+#ifndef FHE_PIPE_NT
+#define FHE_PIPE_NT 3
 #endif

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The `next_rows` and `C5_chain_15_levels` legs of bench.py on their own (what tools/r04_run3.sh wraps in
+"""The `next_rows` and `C5_chain_15_levels` legs of bench.py on their own (what tools/runs/r04_run3.sh wraps in
 rocprofv3 --kernel-trace --stats for profiles/r04_next_rows_*).  Prints one JSON object."""
 import json
 import os

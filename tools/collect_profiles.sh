@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps $STEPS --warmup 2"
+BENCH="python $ROOT/bench.py --steps $STEPS --warmup 5"
 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $BENCH --no-cpu --no-extras > $OUT/stats_bench.json 2> $OUT/stats.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o run -- $BENCH --no-cpu --no-extras > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.log

@@ -652,6 +652,11 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     }
     const uint32_t logm = 13, g0 = logn - logm, m = 1u << logm;
     const unsigned gth = 256, gblocks = rows_total * (m / gth);
+    // every modulus of the launch below 2^60: the LDS halves take the bound-tracked narrow passes here too (round 4;
+    // rounds 1-3 ran rows larger than LDS on the general passes whatever the moduli)
+    bool narrow = !FHE_LAB_FLAG("NO_NARROW") && !FHE_LAB_FLAG("NO_NARROW_SUB");
+    for (uint32_t r = 0; r < map.rows; r++)
+        narrow = narrow && (c.root->moduli[(size_t)((int32_t)(map.row_begin + r) + map.mod_offset)] >> 60) == 0;
     k::RowMap inplace = map;
     inplace.src_poly_stride = map.dst_poly_stride;
     inplace.src_row_fixed = -1;
@@ -663,10 +668,20 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
         else
             FHE_LAUNCH("ntt_fwd_global", (k::ntt_global_kernel<false, 3>), dim3(gblocks), dim3(gth), 0, s, in, out,
                        map, c.dmods(), c.dtw(), c.dninv(), logn);
-        launch_ntt_lds<false>("ntt_fwd", logm, rows_total << g0, s, out, out, inplace, c.dmods(), c.dtw(), c.dninv(),
-                              logn);
+        if (narrow) {   // (the global stages above leave values below 4p: FWD_B0 = 4)
+            const size_t lds = k::lds_words(1u << 13) * sizeof(u64);
+            allow_big_lds((k::ntt_kernel<false, 13, true, 4>), lds);
+            FHE_LAUNCH("ntt_fwd", (k::ntt_kernel<false, 13, true, 4>), dim3(rows_total << g0), dim3(k::ntt_threads_c(13)), lds,
+                       s, out, out, inplace, c.dmods(), c.dtw(), c.dninv(), logn);
+        } else {
+            launch_ntt_lds<false>("ntt_fwd", logm, rows_total << g0, s, out, out, inplace, c.dmods(), c.dtw(), c.dninv(),
+                                  logn);
+        }
     } else {
-        launch_ntt_lds<true>("ntt_inv", logm, rows_total << g0, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
+        if (narrow)
+            launch_ntt_lds<true, true>("ntt_inv", logm, rows_total << g0, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
+        else
+            launch_ntt_lds<true>("ntt_inv", logm, rows_total << g0, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
         if (g0 == 2)
             FHE_LAUNCH("ntt_inv_global", (k::ntt_global_kernel<true, 2>), dim3(gblocks), dim3(gth), 0, s, out, out,
                        inplace, c.dmods(), c.ditw(), c.dninv(), logn);

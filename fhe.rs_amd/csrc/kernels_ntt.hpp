@@ -16,7 +16,9 @@ namespace k {
 // Register budget 128 VGPRs = 4 waves/SIMD, which is what the LDS footprint allows anyway
 // (N = 8192: 68 KiB/workgroup -> 2 workgroups of 8 waves per CU).
 // NARROW (forward, whole row, every modulus of the launch below 2^60): see fwd_butterfly_narrow.
-template <bool INVERSE, int LOGM, bool NARROW = false>
+// FWD_B0 (forward, NARROW): the loader's values are below FWD_B0 * p -- 1: canonical input (whole rows); 4: this is the
+// LDS half of a row larger than LDS, behind ntt_global_kernel's Harvey stages, which leave values below 4p.
+template <bool INVERSE, int LOGM, bool NARROW = false, int FWD_B0 = 1>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     ntt_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map, const DevMod *__restrict__ mods,
                const u64x2 *__restrict__ tw, const u64x2 *__restrict__ ninv, uint32_t logn) {
@@ -43,7 +45,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
 
     if constexpr (!INVERSE) {
         // the first pass reads its groups straight from global memory (no tile staging)
-        ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? 1 : 0)>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) { return load_last<(FHE_PIPE_NT & 2) != 0>(src + i); });
+        ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? FWD_B0 : 0)>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) { return load_last<(FHE_PIPE_NT & 2) != 0>(src + i); });
         if constexpr (NARROW) {  // < 16p -> canonical
             const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
             lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) {

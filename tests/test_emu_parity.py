@@ -114,13 +114,15 @@ def test_galois_vector_tile_path(fhe):
     cases.case_galois(fhe, False, nmod=3, n=128)
 
 
+@pytest.mark.parametrize("bits", [62, 60])
 @pytest.mark.parametrize("n", [32768, 65536])
-def test_ntt_split_kernels(fhe, n):
-    """N > 16384: global radix stages + LDS kernel on 8192-point sub-blocks (vs the C oracle)."""
+def test_ntt_split_kernels(fhe, n, bits):
+    """N > 16384: global radix stages + LDS kernel on 8192-point sub-blocks (vs the C oracle); 60-bit moduli take the
+    bound-tracked narrow passes in the LDS halves (round 4), whose range checks trap in this build."""
     from fhe_oracle import coracle
     from fhe_oracle.rq import Context as OCtx
     from fhe_oracle.zq import generate_prime
-    mods = [generate_prime(62, 2 * n, 1 << 62)]
+    mods = [generate_prime(bits, 2 * n, 1 << bits)]
     cases.case_ntt(fhe, False, n, moduli=mods, batch=1, coracle_ctx=coracle.CCtx(OCtx(mods, n)))
 
 

@@ -679,3 +679,15 @@ def test_workspace_1000_foreign_streams_c2(fhe):
 @pytest.mark.parametrize("dev", [False, True])
 def test_scaler_many_wide_moduli(fhe, dev):
     cases.case_scaler_many_wide_moduli(fhe, dev)
+
+
+@pytest.mark.parametrize("n", [32768, 65536])
+def test_ntt_split_rows_narrow_moduli(fhe, n):
+    """Rows larger than LDS over moduli below 2^60 only: the LDS halves of both transforms take the narrow passes
+    (forward: input below 4p behind the global stages) -- two 60-bit primes and a 50-bit one, vs the C oracle."""
+    from fhe_oracle import coracle
+    from fhe_oracle.rq import Context as OCtx
+    from fhe_oracle.zq import generate_prime
+    p0 = generate_prime(60, 2 * n, 1 << 60)
+    mods = [p0, generate_prime(60, 2 * n, p0), generate_prime(50, 2 * n, 1 << 50)]
+    cases.case_ntt(fhe, True, n, moduli=mods, batch=5, coracle_ctx=coracle.CCtx(OCtx(mods, n)))

@@ -89,6 +89,7 @@ RUST_STD = {  # methods / functions of std, ndarray and itertools the inserted c
     "ptr_eq", "get_or_try_init", "reset", "is_none", "new", "with_capacity", "extend_from_slice", "push",
     "zeros", "zeroize", "ok_or_else", "get", "next_power_of_two", "ilog2", "is_empty", "cloned",
 }
+USER_LOCAL_FNS = {"hip", "rotated_products"}   # functions the example files define themselves
 
 
 def _added_lines():
@@ -297,9 +298,15 @@ def test_patches_reach_only_visible_items():
 
 
 def _integration_examples():
+    """User code: the Rust blocks of INTEGRATION.md that are examples, and the files under rust/examples/."""
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     blocks = re.findall(r"```rust\n(.*?)```", text, flags=re.S)
-    return [b for b in blocks if "let " in b]      # (the extern-block excerpt is not an example)
+    out = [b for b in blocks if "let " in b]      # (the extern-block excerpt is not an example)
+    exdir = os.path.join(ROOT, "rust", "examples")
+    for f in sorted(os.listdir(exdir)) if os.path.isdir(exdir) else []:
+        if f.endswith(".rs"):
+            out.append(open(os.path.join(exdir, f)).read())
+    return out
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
@@ -319,7 +326,7 @@ def test_examples_use_only_public_items():
         for name in flds - LOCAL_NAMES:
             assert name in fields and _visible(fields[name], None, None), f"example reaches `.{name}`: not a public field"
         for name in calls | set(re.findall(r"::([a-z_][a-z0-9_]*)\(", code)):
-            if name in RUST_STD and name not in methods:
+            if (name in RUST_STD and name not in methods) or name in USER_LOCAL_FNS:
                 continue
             assert name in methods, f"example calls `{name}()`, which nobody defines"
             assert _visible(methods[name], None, None), f"example calls `{name}()`: not public ({methods[name][:3]})"

@@ -730,7 +730,10 @@ impl DeviceBuffer {
         Ok(Self { ptr: out as *mut u64, len })
     }
     /// Gives the block back behind the work already enqueued on `stream` (`fhe_buf_free_async`) instead of waiting for
-    /// the device as `drop` does.
+    /// the device as `drop` does.  `stream` must be the stream of the buffer's LAST USE (every operation that read or
+    /// wrote it was enqueued there, or is ordered before it by the caller's own events): a free that is ordered on
+    /// another stream can hand the memory out again while the last reader still runs.  When in doubt,
+    /// drop the buffer: `Drop` waits for the device.
     pub fn release_on(self, stream: &Stream) -> Result<()> {
         let p = self.ptr as *mut c_void;
         std::mem::forget(self);

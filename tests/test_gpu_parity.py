@@ -325,6 +325,13 @@ def test_bench_two_ranks_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256 and line["value"] > 0
+    # round 4: the line says who ran where and what one GPU does alone on the same per-GPU batch
+    mg = line["multi_gpu"]
+    assert len(mg["ranks"]) == 2 and {r["rank"] for r in mg["ranks"]} == {0, 1} and mg["data_path_collectives"] == 0
+    assert mg["solo_rank0_ops_per_s"] > 0 and 0 < mg["efficiency_vs_1gpu_same_batch"] < 1.5
+    assert mg["one_device_per_rank"] == (mg["distinct_devices"] == 2)
+    assert line["repeats"] == 3 and len(line["value_all"]) == 3 and line["value_min"] <= line["value"] <= line["value_max"]
+    assert line["roofline"]["kernel_sum_le_step"] in (True, False) and line["roofline"]["traffic_observed_this_run"] is False
 
 
 def test_max_degree_n65536(fhe):

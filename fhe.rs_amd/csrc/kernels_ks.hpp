@@ -27,7 +27,12 @@ constexpr bool ks_acc1_in_lds_tt(int logn, int tt) { return tt == 0 && ks_acc1_i
 // (TT = 512 at N = 16384, lab: 32 coefficients per thread and a 256-register budget -- two waves per SIMD -- so that
 // both accumulator sets AND a radix-16 pass fit: 4 passes instead of 6, see engine.hpp FHE_LAB_KS14_T512)
 constexpr int ks_min_waves(int logn, int tt) { return (logn == 14 && tt == 512) ? 2 : 4; }
-template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false>
+// G0 = 1 (round 4, N = 32768 as two 16384-point half rows, LOGN = 14): the tile is HALF of a row of 2^(LOGN+1) points and
+// the first Cooley-Tukey stage is folded into the loader -- half `sub` needs x[e] +/- w x[e + 2^LOGN], ONE Shoup product
+// per coefficient (what a regular stage costs per butterfly pair) and two source reads, where ks_fused_split_kernel's
+// 8192-point quarter rows pay three products and four reads for their two folded stages; the remaining LOGN stages run in
+// LDS with twiddle base 2 + sub.  Workgroups are (ciphertext, key modulus, half).
+template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false, int G0 = 0>
 __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT))
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
                     u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
@@ -37,7 +42,11 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                     const u64 *__restrict__ xhat, u64 xhat_poly_stride, uint32_t total) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ks_threads_tt(LOGN, TT);
-    constexpr int N = 1 << LOGN;
+    constexpr int N = 1 << LOGN;             // the tile: the whole row, or (G0 = 1) one half of it
+    constexpr u64 NROW = (u64)N << G0;       // coefficients of a row
+    constexpr int NS = 1 << G0;
+    static_assert(G0 == 0 || (G0 == 1 && !ks_acc1_in_lds_tt(LOGN, TT) && tile_chunks_c(LOGN, ks_threads_tt(LOGN, TT)) >= 2),
+                  "the folded first stage is written for the register-accumulator form (N = 16384 tiles)");
     constexpr int CH = tile_chunks_c(LOGN, T);
     constexpr int NE = CH > 0 ? 2 * CH : 1;  // coefficients owned by a thread
     // GM: radix (log2) of the LDS passes.  8 everywhere but N = 16384, whose 1024 threads hold both accumulator sets in
@@ -62,11 +71,13 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
     uint32_t item = blockIdx.x;
     if (item >= total) return;
     do {
-    const uint32_t b = to_sgpr(item / lk), j = item - b * lk;
+    const uint32_t bj = item >> G0, sub = item & (NS - 1);
+    const uint32_t b = to_sgpr(bj / lk), j = bj - b * lk;
     const DevMod md = mods[j];
     const u64 p = md.p, p2 = md.p2;
     const PM pm = make_pm(md);
-    const u64x2 *twr = tw + (u64)j * N;
+    const u64x2 *twr = tw + (u64)j * NROW;
+    const u64 suboff = (u64)sub * N;          // this half inside a row (0 when the tile is the row)
     // N = 8192: 1024 threads cap a thread at 128 VGPRs, which 2 x 16 accumulators plus a radix-8
     // pass do not fit; the c1 accumulators live in LDS behind the row tile instead (each thread
     // only ever touches its own 16-byte chunks, so no extra barrier).
@@ -95,7 +106,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
     // digit_shift_bits == 0: digit i is residue row i of p (RNS decomposition, :256-268).
     // otherwise: base-2^bits digits of the single row 0 (key_switch_decomposition, :323-362).
     const u64 *const src0 = pin + (u64)b * src_poly_stride;
-    const u64 dstride = digit_shift_bits ? 0 : (u64)N;
+    const u64 dstride = digit_shift_bits ? 0 : NROW;
     const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
     // `xhat` (callers that hold the digit polynomial in Ntt form -- relinearise, Galois, RGSW: [digits][N] per
     // polynomial over the ciphertext moduli, canonical): the RNS digit j reduced mod q_j is row j itself and its
@@ -103,8 +114,8 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
     // one of the L transforms of this workgroup is not computed: its product initialises the accumulators.
     const bool own = xhat != nullptr && digit_shift_bits == 0 && j < ndigits;   // (block-uniform)
     if (own) {
-        const u64 koff = ((u64)j * lk + j) * N;
-        const u64 *xr = xhat + (u64)b * xhat_poly_stride + (u64)j * N;
+        const u64 koff = ((u64)j * lk + j) * NROW + suboff;
+        const u64 *xr = xhat + (u64)b * xhat_poly_stride + (u64)j * NROW + suboff;
         if constexpr (CH > 0) {
             const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
             const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
@@ -169,8 +180,42 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
         } else {
             // (address and mask are recomputed per digit on purpose: hoisted, they cost VGPRs that the
             // N = 16384 variant does not have)
-            const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N);
-            if constexpr (rns_fast) {
+            const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * NROW);
+            if constexpr (G0 == 1) {
+                // stage 0 of the 2N-point transform, only the branch that leads to this half: lo +/- w * hi on the lifted
+                // values (canonical, so lo needs no correction): below 3p.  Four batches of CH / 4 chunks: 2 x CH / 4
+                // loads of 16 bytes in flight next to the two accumulator sets.
+                const u64 mask_i = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+                auto lf = [&](u64 v) -> u64 {
+                    if constexpr (rns_fast) return csub_n(v, p, pm.np);
+                    return lift((v >> sh) & mask_i);
+                };
+                const u64x2 w0 = twr[1];
+                const u64x2 *s2 = reinterpret_cast<const u64x2 *>(src);
+                constexpr int HB = CH >= 4 ? CH / 4 : 1;
+#pragma unroll
+                for (int h = 0; h < CH; h += HB) {
+                    u64x2 lo[HB], hi[HB];
+#pragma unroll
+                    for (int c = 0; c < HB; c++) {
+                        lo[c] = s2[(h + c) * T + tid];
+                        hi[c] = s2[(h + c) * T + tid + N / 2];
+                    }
+#pragma unroll
+                    for (int c = 0; c < HB; c++) {
+                        const uint32_t e = 2 * ((h + c) * T + tid);
+                        const u64 ax = lf(lo[c].x), ay = lf(lo[c].y), bx = lf(hi[c].x), by = lf(hi[c].y);
+                        if (sub) {   // (uniform over the workgroup)
+                            lds[padi(e)] = ax + p2 - mul_shoup_lazy_n<true>(bx, w0.x, w0.y, pm.np);
+                            lds[padi(e + 1)] = ay + p2 - mul_shoup_lazy_n<true>(by, w0.x, w0.y, pm.np);
+                        } else {
+                            lds[padi(e)] = mul_shoup_lazy_add_n<true>(ax, bx, w0.x, w0.y, pm.np);
+                            lds[padi(e + 1)] = mul_shoup_lazy_add_n<true>(ay, by, w0.x, w0.y, pm.np);
+                        }
+                    }
+                    sched_fence();
+                }
+            } else if constexpr (rns_fast) {
                 tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
             } else {
                 const u64 mask_i = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
@@ -187,7 +232,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                 for (int c = 0; c < CH; c++) pre[c] = nx[c * T + tid];
             }
         }
-        const u64 koff = ((u64)i * lk + j) * N;
+        const u64 koff = ((u64)i * lk + j) * NROW + suboff;
         if constexpr (CH > 0) {
             const u64x2 *a0 = reinterpret_cast<const u64x2 *>(k0 + koff), *a0s = reinterpret_cast<const u64x2 *>(k0s + koff);
             const u64x2 *a1 = reinterpret_cast<const u64x2 *>(k1 + koff), *a1s = reinterpret_cast<const u64x2 *>(k1s + koff);
@@ -195,7 +240,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
             // transform, so their L2 latency is spent waiting for the other waves, not after them
             constexpr bool KPF = PREFETCH && CH >= 2;
             // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
-            ntt_fwd_lds<LOGN, T, GM, FHE_KS_TWPF && LOGN == 13, !KPF, (NARROW ? 1 : 0), NoSrc, KS_LATE>(lds, twr, 1, pm, tid);
+            ntt_fwd_lds<LOGN, T, GM, FHE_KS_TWPF && LOGN == 13, !KPF, (NARROW ? (G0 ? 4 : 1) : 0), NoSrc, KS_LATE>(lds, twr, NS + sub, pm, tid);
             // (all four chunks prefetched -- 118 VGPRs, no scratch: no change; three: 2 % slower.  ABBA runs in
             // profiles/r02_ks_kpf_ab.txt: the key words' latency is not what the MAC waits for)
             constexpr int KPFN = KPF ? (FHE_KS_KPF_CHUNKS < CH ? FHE_KS_KPF_CHUNKS : CH) : 0;   // chunks whose key words are prefetched
@@ -256,7 +301,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
     if constexpr (PREFETCH && ITEM_LOOP) {
         const uint32_t nitem = item + gridDim.x;
         if (nitem < total) {   // the next item's first digit row (the same selection as at the top of the loop)
-            const uint32_t nb = nitem / lk, nj = nitem - nb * lk;
+            const uint32_t nb = (nitem >> G0) / lk, nj = (nitem >> G0) - nb * lk;
             const bool nown = xhat != nullptr && digit_shift_bits == 0 && nj < ndigits;
             if (ndigits - (nown ? 1u : 0u) > 0) {
                 const uint32_t nd = (nown && nj == 0) ? 1u : 0u;
@@ -267,8 +312,8 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
             }
         }
     }
-    const u64 ooff = (u64)b * out_poly_stride + (u64)j * N;
-    const u64 aoff = (u64)b * addend_poly_stride + (u64)j * N;
+    const u64 ooff = (u64)b * out_poly_stride + (u64)j * NROW + suboff;
+    const u64 aoff = (u64)b * addend_poly_stride + (u64)j * NROW + suboff;
     if constexpr (CH > 0) {
         u64x2 *o0 = reinterpret_cast<u64x2 *>(out0 + ooff), *o1 = reinterpret_cast<u64x2 *>(out1 + ooff);
         const u64x2 *d0 = reinterpret_cast<const u64x2 *>(addend0 ? addend0 + aoff : nullptr);

@@ -13,7 +13,8 @@
     defined(FHE_KS_TWPF) || defined(FHE_KS_PERSIST14) || defined(FHE_KS_KPF_CHUNKS) || defined(FHE_TENSOR_TW_EARLY) ||  \
     defined(FHE_KS_EXPERIMENTS) || defined(FHE_PHASE_TIMING) || defined(FHE_LDS_PAD) || defined(FHE_NO_WAVE_SYNC) || \
     defined(FHE_DIAG_NO_SGPR_ASM) || defined(FHE_KS_HALF13) || defined(FHE_KS_SPLIT_XCD) || defined(FHE_STREAM_NT) || \
-    defined(FHE_MUL_DIRFLAGS) || defined(FHE_MUL_MERGED_EXT) || defined(FHE_PIPE_NT)
+    defined(FHE_MUL_DIRFLAGS) || defined(FHE_MUL_MERGED_EXT) || defined(FHE_PIPE_NT) || \
+    defined(FHE_KS_HALF15)
 #error "kernel-variant macros are lab-only: add -DFHE_LAB (the release build pins every knob, see knobs.hpp)"
 #endif
 #endif
@@ -78,4 +79,9 @@
 // C2 / 1024, mask 4 (the inverse transform of the inputs, which the tensor kernel reads again) is noise -- 3.
 #ifndef FHE_PIPE_NT
 #define FHE_PIPE_NT 3
+#endif
+// Key switch at N = 32768: 0 ks_fused_split_kernel (8192-point quarter rows, two folded stages); 1 / 2 ks_fused_kernel<14>
+// on 16384-point half rows with ONE folded stage (generic / RNS loader).
+#ifndef FHE_KS_HALF15
+#define FHE_KS_HALF15 0
 #endif

@@ -698,3 +698,12 @@ def test_ntt_split_rows_narrow_moduli(fhe, n):
     p0 = generate_prime(60, 2 * n, 1 << 60)
     mods = [p0, generate_prime(60, 2 * n, p0), generate_prime(50, 2 * n, 1 << 50)]
     cases.case_ntt(fhe, True, n, moduli=mods, batch=5, coracle_ctx=coracle.CCtx(OCtx(mods, n)))
+
+
+@pytest.mark.parametrize("mode", ["fused", "unfused"])
+def test_relin_rotate_rows_larger_than_lds(fhe, mode):
+    """Relinearise and both rotations at N = 32768 (rows larger than LDS): the key switch reads the caller's Ntt rows for
+    one transform per key modulus and adds the substituted c0 on the way out -- the sub-block offsets of those paths."""
+    import full_size
+    with fhe.KeySwitchingKey.forced_mode(KS_MODES[mode]):
+        full_size.check_relin_rotate(fhe, n=32768, sizes=[60, 60, 60, 58], batch=3, cfg=8)

@@ -1456,24 +1456,27 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     // logn - 13 stages folded into its loader (ks_fused_split_kernel).
     bool narrow = !FHE_LAB_FLAG("NO_NARROW");
     for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
-    // N = 32768 as two 16384-point half rows on the N = 16384 kernel (one folded stage, knobs.hpp FHE_KS_HALF15):
-    // 1 the generic loader, 2 the RNS loader
+    // N = 32768 / 65536 as two / four 16384-point parts on the N = 16384 kernel (one / two folded stages, knobs.hpp
+    // FHE_KS_HALF15): 1 the generic loader, 2 the RNS loader where the key's digits are residue rows
     static const int half15 = FHE_LAB_INT("KS_HALF15", FHE_KS_HALF15);
-    if (kc.logn == 15 && half15) {
+    if ((kc.logn == 15 || kc.logn == 16) && half15) {
         const size_t lds_ = k::lds_words(1u << 14) * sizeof(u64);
-        const unsigned grid = (unsigned)(npolys * kc.L * 2);
+        const unsigned grid = (unsigned)((npolys * kc.L) << (kc.logn - 14));
         const bool rns = half15 == 2 && k_.digit_arg() == (1u << 8);
-#define FHE_KS_HALF15_LAUNCH(NW, RNS)                                                                                 \
-    allow_big_lds((k::ks_fused_kernel<14, NW, k::GM_MIXED, 0, RNS, 1>), lds_);                                        \
-    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<14, NW, k::GM_MIXED, 0, RNS, 1>), dim3(grid),                  \
+#define FHE_KS_HALF15_LAUNCH(NW, RNS, G0)                                                                             \
+    allow_big_lds((k::ks_fused_kernel<14, NW, k::GM_MIXED, 0, RNS, G0>), lds_);                                       \
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<14, NW, k::GM_MIXED, 0, RNS, G0>), dim3(grid),                 \
                dim3(k::ks_threads_c(14)), lds_, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, \
                k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat,   \
                xhat_stride, grid)
-        if (narrow) {
-            if (rns) { FHE_KS_HALF15_LAUNCH(true, true); } else { FHE_KS_HALF15_LAUNCH(true, false); }
-        } else {
-            if (rns) { FHE_KS_HALF15_LAUNCH(false, true); } else { FHE_KS_HALF15_LAUNCH(false, false); }
-        }
+#define FHE_KS_HALF15_PICK(G0)                                                                                        \
+    if (narrow) {                                                                                                     \
+        if (rns) { FHE_KS_HALF15_LAUNCH(true, true, G0); } else { FHE_KS_HALF15_LAUNCH(true, false, G0); }            \
+    } else {                                                                                                          \
+        if (rns) { FHE_KS_HALF15_LAUNCH(false, true, G0); } else { FHE_KS_HALF15_LAUNCH(false, false, G0); }          \
+    }
+        if (kc.logn == 15) { FHE_KS_HALF15_PICK(1) } else { FHE_KS_HALF15_PICK(2) }
+#undef FHE_KS_HALF15_PICK
 #undef FHE_KS_HALF15_LAUNCH
         return;
     }

@@ -27,11 +27,13 @@ constexpr bool ks_acc1_in_lds_tt(int logn, int tt) { return tt == 0 && ks_acc1_i
 // (TT = 512 at N = 16384, lab: 32 coefficients per thread and a 256-register budget -- two waves per SIMD -- so that
 // both accumulator sets AND a radix-16 pass fit: 4 passes instead of 6, see engine.hpp FHE_LAB_KS14_T512)
 constexpr int ks_min_waves(int logn, int tt) { return (logn == 14 && tt == 512) ? 2 : 4; }
-// G0 = 1 (round 4, N = 32768 as two 16384-point half rows, LOGN = 14): the tile is HALF of a row of 2^(LOGN+1) points and
-// the first Cooley-Tukey stage is folded into the loader -- half `sub` needs x[e] +/- w x[e + 2^LOGN], ONE Shoup product
-// per coefficient (what a regular stage costs per butterfly pair) and two source reads, where ks_fused_split_kernel's
-// 8192-point quarter rows pay three products and four reads for their two folded stages; the remaining LOGN stages run in
-// LDS with twiddle base 2 + sub.  Workgroups are (ciphertext, key modulus, half).
+// G0 > 0 (round 4; LOGN = 14: N = 32768 as two 16384-point halves, N = 65536 as four quarters): the tile is one of 2^G0
+// parts of a row of 2^(LOGN+G0) points and the first G0 Cooley-Tukey stages are folded into the loader.  G0 = 1: half
+// `sub` needs x[e] +/- w x[e + 2^LOGN] -- ONE Shoup product per coefficient (what a regular stage costs per butterfly
+// pair) and two source reads, where ks_fused_split_kernel's 8192-point quarter rows pay three products and four reads
+// for their two folded stages (C5 relinearise 1.46 -> 1.25 ms, profiles/r04_ks_half15_ab.txt); G0 = 2: three products
+// instead of the seven of eight 8192-point parts.  The remaining LOGN stages run in LDS with twiddle base 2^G0 + sub.
+// Workgroups are (ciphertext, key modulus, part).
 template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false, int G0 = 0>
 __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT))
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
@@ -45,8 +47,8 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
     constexpr int N = 1 << LOGN;             // the tile: the whole row, or (G0 = 1) one half of it
     constexpr u64 NROW = (u64)N << G0;       // coefficients of a row
     constexpr int NS = 1 << G0;
-    static_assert(G0 == 0 || (G0 == 1 && !ks_acc1_in_lds_tt(LOGN, TT) && tile_chunks_c(LOGN, ks_threads_tt(LOGN, TT)) >= 2),
-                  "the folded first stage is written for the register-accumulator form (N = 16384 tiles)");
+    static_assert(G0 == 0 || (G0 <= 2 && !ks_acc1_in_lds_tt(LOGN, TT) && tile_chunks_c(LOGN, ks_threads_tt(LOGN, TT)) >= 2),
+                  "the folded first stages are written for the register-accumulator form (N = 16384 tiles)");
     constexpr int CH = tile_chunks_c(LOGN, T);
     constexpr int NE = CH > 0 ? 2 * CH : 1;  // coefficients owned by a thread
     // GM: radix (log2) of the LDS passes.  8 everywhere but N = 16384, whose 1024 threads hold both accumulator sets in
@@ -212,6 +214,62 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                             lds[padi(e)] = mul_shoup_lazy_add_n<true>(ax, bx, w0.x, w0.y, pm.np);
                             lds[padi(e + 1)] = mul_shoup_lazy_add_n<true>(ay, by, w0.x, w0.y, pm.np);
                         }
+                    }
+                    sched_fence();
+                }
+            } else if constexpr (G0 > 1) {
+                // the first G0 stages of the 2^G0 N-point transform, only the branches that lead to this part of the
+                // row (ks_fused_split_kernel's loader on 16384-point parts; G0 = 2: three Shoup products per
+                // coefficient, values below 4p), one chunk = NS loads of 16 bytes at a time.  (G0 = 1 written out above:
+                // the general form costs that instance 12 bytes of scratch.)
+                const u64 mask_i = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
+                auto lf = [&](u64 v) -> u64 {
+                    if constexpr (rns_fast) return csub_n(v, p, pm.np);
+                    return lift((v >> sh) & mask_i);
+                };
+                const u64x2 *s2 = reinterpret_cast<const u64x2 *>(src);
+                constexpr int HB = 1;
+                u64x2 wst[G0];
+#pragma unroll
+                for (int st = 0; st < G0; st++) wst[st] = twr[(1u << st) + (sub >> (G0 - st))];
+#pragma unroll
+                for (int h = 0; h < CH; h += HB) {
+                    u64x2 v[HB][NS];
+#pragma unroll
+                    for (int c = 0; c < HB; c++)
+#pragma unroll
+                        for (int k = 0; k < NS; k++) v[c][k] = s2[(h + c) * T + tid + (u64)k * (N / 2)];
+#pragma unroll
+                    for (int c = 0; c < HB; c++) {
+#pragma unroll
+                        for (int k = 0; k < NS; k++) v[c][k].x = lf(v[c][k].x), v[c][k].y = lf(v[c][k].y);
+#pragma unroll
+                        for (int st = 0; st < G0; st++) {   // stage st keeps the half of the pairs whose output leads to `sub`
+                            const int half = NS >> (st + 1);
+                            const u64x2 wv = wst[st];
+                            const bool minus = (sub >> (G0 - st - 1)) & 1;   // (uniform over the workgroup)
+                            // (stage 0 works on canonical values: no correction of the first operand there)
+                            if (minus) {
+#pragma unroll
+                                for (int m = 0; m < half; m++) {
+                                    const u64 lx = st ? csub_n(v[c][m].x, p2, pm.np2) : v[c][m].x;
+                                    const u64 ly = st ? csub_n(v[c][m].y, p2, pm.np2) : v[c][m].y;
+                                    v[c][m].x = lx + p2 - mul_shoup_lazy_n<true>(v[c][m + half].x, wv.x, wv.y, pm.np);
+                                    v[c][m].y = ly + p2 - mul_shoup_lazy_n<true>(v[c][m + half].y, wv.x, wv.y, pm.np);
+                                }
+                            } else {
+#pragma unroll
+                                for (int m = 0; m < half; m++) {
+                                    const u64 lx = st ? csub_n(v[c][m].x, p2, pm.np2) : v[c][m].x;
+                                    const u64 ly = st ? csub_n(v[c][m].y, p2, pm.np2) : v[c][m].y;
+                                    v[c][m].x = mul_shoup_lazy_add_n<true>(lx, v[c][m + half].x, wv.x, wv.y, pm.np);
+                                    v[c][m].y = mul_shoup_lazy_add_n<true>(ly, v[c][m + half].y, wv.x, wv.y, pm.np);
+                                }
+                            }
+                        }
+                        const uint32_t e = 2 * ((h + c) * T + tid);
+                        lds[padi(e)] = v[c][0].x;
+                        lds[padi(e + 1)] = v[c][0].y;
                     }
                     sched_fence();
                 }

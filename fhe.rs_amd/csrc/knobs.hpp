@@ -80,8 +80,11 @@
 #ifndef FHE_PIPE_NT
 #define FHE_PIPE_NT 3
 #endif
-// Key switch at N = 32768: 0 ks_fused_split_kernel (8192-point quarter rows, two folded stages); 1 / 2 ks_fused_kernel<14>
-// on 16384-point half rows with ONE folded stage (generic / RNS loader).
+// Key switch at N = 32768 / 65536: 0 ks_fused_split_kernel (8192-point parts: two / three folded stages, 3 / 7 Shoup
+// products per coefficient in the loader); 1 / 2 ks_fused_kernel<14> on 16384-point parts with ONE / two folded stages
+// (1 / 3 products; generic loader / RNS loader for residue-row digits).  Measured at C5 (N = 32768, 16 moduli,
+// profiles/r04_ks_half15_ab.txt, same box, three rounds each): relinearise 1.46 -> 1.29 (1) -> 1.25 ms (2) at batch 16,
+// 5.00 -> 4.40 -> 4.23 ms at batch 64; the level-0 multiply step 3.43 -> 3.29 -> 3.23 ms -- 2.
 #ifndef FHE_KS_HALF15
-#define FHE_KS_HALF15 0
+#define FHE_KS_HALF15 2
 #endif

@@ -593,6 +593,36 @@ def case_key_switch_decomposition(fhe, dev, n=16):
         assert err.code in (-11, -17)
 
 
+def case_key_switch_decomposition_rows(fhe, dev, n, bits):
+    """key_switching_key.rs:323-362 at full row sizes: a single-modulus key level, base-2^(log q / 2) digits taken from ONE
+    residue row (the key switch's shift-and-mask loader, incl. the folded first stages of rows larger than LDS).  Expected
+    value: the digits by numpy, transforms / products / sums by the C oracle."""
+    from fhe_oracle.zq import generate_prime
+    x = Xfer(dev)
+    q = generate_prime(bits, 2 * n, 1 << bits)
+    cc = coracle.CCtx(OCtx([q], n))
+    seed = 0xF4E50099 + bits
+    log_q = (q - 1).bit_length()
+    log_base = log_q // 2
+    nd = -(-log_q // log_base)
+    c0 = np.stack([cc.synth_poly(seed, 0, 8 + 2 * i) for i in range(nd)])     # [nd][1][n]
+    c1 = np.stack([cc.synth_poly(seed, 0, 9 + 2 * i) for i in range(nd)])
+    p = np.stack([cc.synth_poly(seed, i, 0) for i in range(3)])                 # [3][1][n]
+    ctx = fhe.Context([q], n)
+    ksk = fhe.KeySwitchingKey(ctx, ctx, c0, c1, log_base=log_base)
+    g0, g1 = ksk.key_switch(x.to(p))
+    g0, g1 = x.back(g0), x.back(g1)
+    mask = np.uint64((1 << log_base) - 1)
+    for b in range(3):
+        w0 = np.zeros((1, n), dtype=np.uint64)
+        w1 = np.zeros((1, n), dtype=np.uint64)
+        for i in range(nd):
+            d = cc.poly_ntt_forward((p[b] >> np.uint64(i * log_base)) & mask)
+            w0 = cc.poly_add(w0, cc.poly_mul(d, c0[i]))
+            w1 = cc.poly_add(w1, cc.poly_mul(d, c1[i]))
+        assert np.array_equal(g0[b], w0) and np.array_equal(g1[b], w1), (n, bits, b)
+
+
 def case_galois(fhe, dev, nmod=3, n=16):
     """galois_key.rs:63-123, 186-256; evaluation_key.rs:110-170, 278-286."""
     x = Xfer(dev)

@@ -309,17 +309,20 @@ def test_unfused_decomposition_keys_stay_fused(fhe):
         cases.case_key_switch_decomposition(fhe, False)
 
 
-@pytest.mark.parametrize("n,mode", [(8192, 2), (16384, 2), (16384, 3), (32768, 2), (65536, 2)])
-def test_unfused_key_switch_large_rows(fhe, n, mode):
-    """Whole-row tiles up to N = 16384, 8192-point sub-block tiles with the first stages folded into the loader
-    above (and at 16384 in mode UNFUSED_SUB) -- synthetic key and input vs the C oracle, 60- and 62-bit key moduli."""
+@pytest.mark.parametrize("n,mode", [(8192, 2), (16384, 2), (16384, 3), (32768, 2), (65536, 2), (16384, 1), (32768, 1), (65536, 1)])
+def test_key_switch_strategies_large_rows(fhe, n, mode):
+    """Unfused: whole-row tiles up to N = 16384, 8192-point sub-block tiles with the first stages folded into the loader
+    above (and at 16384 in mode UNFUSED_SUB).  Fused (mode 1): whole rows up to 16384, 16384-point parts with one / two
+    folded stages above.  Synthetic key and input vs the C oracle; 60-bit moduli (narrow passes, residue-row loader),
+    62 + 61 bits (general passes, generic loader), 62 + 62 bits (general passes, residue-row loader)."""
     import numpy as np
     from fhe_oracle import bfv as obfv, coracle
     from fhe_oracle.rq import Context as OCtx
     from fhe_oracle.zq import generate_prime
     import full_size
     seed = 0xF4E50078
-    for q in (obfv.generate_moduli([60, 60], n), [generate_prime(62, 2 * n, 1 << 62), generate_prime(61, 2 * n, 1 << 61)]):
+    p62 = generate_prime(62, 2 * n, 1 << 62)
+    for q in (obfv.generate_moduli([60, 60], n), [p62, generate_prime(61, 2 * n, 1 << 61)], [p62, generate_prime(62, 2 * n, p62)]):
         cc = coracle.CCtx(OCtx(q, n))
         ck = full_size.host_key(cc, seed, len(q))
         c0 = np.stack([cc.synth_poly(seed, 0, 8 + 2 * i) for i in range(len(q))])
@@ -333,8 +336,8 @@ def test_unfused_key_switch_large_rows(fhe, n, mode):
         for i in range(2):
             w0, w1 = ck.key_switch(p[i])
             assert np.array_equal(np.asarray(g0[i]), w0) and np.array_equal(np.asarray(g1[i]), w1)
-        if n > 16384:
-            break   # (one modulus set is enough at the emulator's speed)
+        if n > 16384 and mode != 1:
+            break   # (one modulus set is enough at the emulator's speed; the fused form has a loader per kind of set)
 
 
 def test_unfused_random_parameter_shapes(fhe):
@@ -365,3 +368,11 @@ def test_workspace_bounds(fhe):
 
 def test_scaler_many_wide_moduli(fhe):
     cases.case_scaler_many_wide_moduli(fhe, False)
+
+
+@pytest.mark.parametrize("n,bits", [(16384, 60), (32768, 60), (32768, 62), (65536, 60), (65536, 62)])
+def test_key_switch_decomposition_rows(fhe, n, bits):
+    """Single-modulus key levels (base-2^k digits of one residue row) on whole rows and on the 16384-point parts of rows
+    larger than LDS, narrow (60-bit) and general (62-bit) passes."""
+    cases.case_key_switch_decomposition_rows(fhe, False, n, bits)
+

@@ -575,16 +575,20 @@ def test_config_c5_key_switch_modes(fhe, mode):
     fhe.workspace_trim()
 
 
-@pytest.mark.parametrize("n,mode", [(8192, 2), (16384, 2), (16384, 3), (32768, 2), (65536, 2)])
-def test_unfused_key_switch_large_rows(fhe, n, mode):
-    """Synthetic key and input vs the C oracle; 60-bit (narrow passes) and 61/62-bit (general passes) key moduli."""
+@pytest.mark.parametrize("n,mode", [(8192, 2), (16384, 2), (16384, 3), (32768, 2), (65536, 2), (16384, 1), (32768, 1), (65536, 1)])
+def test_key_switch_strategies_large_rows(fhe, n, mode):
+    """Every key-switch strategy (2 / 3 unfused, 1 fused: 16384-point parts with one / two folded stages above N = 16384)
+    on synthetic keys and inputs vs the C oracle: 60-bit moduli (narrow passes, residue-row loader), 62 + 61 bits (general
+    passes, generic loader), 62 + 62 bits (general passes, residue-row loader), 60 + 58 + 60 bits (narrow, generic)."""
     from fhe_oracle import bfv as obfv, coracle
     from fhe_oracle.rq import Context as OCtx
     from fhe_oracle.zq import generate_prime
     import full_size
     import torch
     seed = 0xF4E50078
-    for q in (obfv.generate_moduli([60, 60, 60], n), [generate_prime(62, 2 * n, 1 << 62), generate_prime(61, 2 * n, 1 << 61)]):
+    p62 = generate_prime(62, 2 * n, 1 << 62)
+    for q in (obfv.generate_moduli([60, 60, 60], n), [p62, generate_prime(61, 2 * n, 1 << 61)], [p62, generate_prime(62, 2 * n, p62)],
+              obfv.generate_moduli([60, 58, 60], n)):
         cc = coracle.CCtx(OCtx(q, n))
         ck = full_size.host_key(cc, seed, len(q))
         c0 = np.stack([cc.synth_poly(seed, 0, 8 + 2 * i) for i in range(len(q))])
@@ -707,3 +711,11 @@ def test_relin_rotate_rows_larger_than_lds(fhe, mode):
     import full_size
     with fhe.KeySwitchingKey.forced_mode(KS_MODES[mode]):
         full_size.check_relin_rotate(fhe, n=32768, sizes=[60, 60, 60, 58], batch=3, cfg=8)
+
+
+@pytest.mark.parametrize("n,bits", [(16384, 60), (32768, 60), (32768, 62), (65536, 60), (65536, 62)])
+def test_key_switch_decomposition_rows(fhe, n, bits):
+    """Single-modulus key levels (base-2^k digits of one residue row) on whole rows and on the 16384-point parts of rows
+    larger than LDS, narrow (60-bit) and general (62-bit) passes."""
+    cases.case_key_switch_decomposition_rows(fhe, True, n, bits)
+

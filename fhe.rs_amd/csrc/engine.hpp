@@ -1452,8 +1452,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
 #undef FHE_KS_CASE
         return;
     }
-    // Rows larger than LDS (N >= 32768): one workgroup per 8192-point sub-block, the first
-    // logn - 13 stages folded into its loader (ks_fused_split_kernel).
+    // Rows larger than LDS (N >= 32768): one workgroup per part of a row, the first stages folded into its loader.
     bool narrow = !FHE_LAB_FLAG("NO_NARROW");
     for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
     // N = 32768 / 65536 as two / four 16384-point parts on the N = 16384 kernel (one / two folded stages, knobs.hpp
@@ -1480,6 +1479,9 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
 #undef FHE_KS_HALF15_LAUNCH
         return;
     }
+#if defined(FHE_LAB) || FHE_KS_HALF15 == 0
+    // rounds 1-3 (release builds: compiled only when the knob selects it): 8192-point sub-blocks, logn - 13 folded stages
+    // (ks_fused_split_kernel)
 #define FHE_KS_SPLIT_LAUNCH_M(G0, LM, NW)                                                                          \
     do {                                                                                                           \
         const size_t lds_ = (k::lds_words(1u << LM) + ((size_t)1 << LM)) * sizeof(u64);                            \
@@ -1523,6 +1525,9 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
 #undef FHE_KS_SPLIT_CASE
 #undef FHE_KS_SPLIT_LAUNCH
 #undef FHE_KS_SPLIT_LAUNCH_M
+#else
+    throw StatusError(E_ARG, "unsupported key-switch row size");
+#endif
 }
 
 // Poly::<PowerBasis>::switch_down_to (M/rq/mod.rs:498-507): `iters` applications of switch_down.

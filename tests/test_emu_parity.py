@@ -221,8 +221,8 @@ def test_errors(fhe):
 def test_key_switch_large_rows(fhe, n):
     """N = 8192: the fused key switch keeps its c1 accumulators in LDS behind the row tile and
     prefetches the next digit; N = 16384: both accumulator sets in registers; N >= 32768: one
-    workgroup per 8192-point sub-block with the first stages folded into the loader
-    (ks_fused_split_kernel).  Synthetic key and input vs the C oracle."""
+    workgroup per 16384-point part of a row with the first one / two stages folded into the loader
+    (ks_fused_kernel<14, ..., G0>).  Synthetic key and input vs the C oracle."""
     import numpy as np
     from fhe_oracle import bfv as obfv, coracle
     from fhe_oracle.rq import Context as OCtx

@@ -648,11 +648,12 @@ class KeySwitchingKey:
         if getattr(self, "_h", None) is not None and _lib._lib is not None:
             _lib._lib.fhe_ksk_destroy(self._h)
 
-    AUTO, FUSED, UNFUSED, UNFUSED_SUB = 0, 1, 2, 3
+    AUTO, FUSED, UNFUSED, UNFUSED_SUB, FUSED_SUB = 0, 1, 2, 3, 4
 
     def set_mode(self, mode, w_budget=0):
         """How every key switch through this handle is evaluated (fhe_ksk_set_mode): AUTO, FUSED, UNFUSED (batched
-        digit transforms + streaming lazy MAC), UNFUSED_SUB; `w_budget` bytes of transformed rows per launch pair."""
+        digit transforms + streaming lazy MAC), UNFUSED_SUB, FUSED_SUB (N >= 32768 on 8192-point sub-blocks);
+        `w_budget` bytes of transformed rows per launch pair."""
         check(_lib.lib().fhe_ksk_set_mode(self._h, int(mode), int(w_budget)))
         return self
 

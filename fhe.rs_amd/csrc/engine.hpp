@@ -1155,14 +1155,16 @@ struct Ksk {
     uint32_t digit_arg() const { return (uint32_t)log_base | (lift_mode() << 8); }
     DevBuf<u64> c0, c0s, c1, c1s;  // [ndigits][Lk][N]
     // Execution options of this handle (fhe_ksk_set_mode; read once per call, like Mul's):
-    //   mode      KS_AUTO: the engine picks per shape (ks_use_unfused); KS_FUSED: ks_fused_kernel / ks_fused_split_kernel;
+    //   mode      KS_AUTO: the engine picks per shape and launch (ks_use_unfused, key_switch_polys); KS_FUSED: ks_fused_kernel
+    //             (rows larger than LDS: on 16384-point parts); KS_FUSED_SUB: rows larger than LDS on 8192-point sub-blocks
+    //             (ks_fused_split_kernel), otherwise KS_FUSED;
     //             KS_UNFUSED: batched digit transforms + streaming MAC (RNS digits only; decomposition keys stay fused);
     //             KS_UNFUSED_SUB: the same with 8192-point sub-block tiles at N = 16384 as well
     //   w_budget  bytes of transformed digit rows (W) one stage-A / stage-B launch pair may have in flight; 0 = default
     std::atomic<int> mode{0};
     std::atomic<size_t> w_budget{0};
 };
-enum : int { KS_AUTO = 0, KS_FUSED = 1, KS_UNFUSED = 2, KS_UNFUSED_SUB = 3 };
+enum : int { KS_AUTO = 0, KS_FUSED = 1, KS_UNFUSED = 2, KS_UNFUSED_SUB = 3, KS_FUSED_SUB = 4 };
 
 inline void ksk_validate(const Ctx &ct_ctx, const Ctx &ksk_ctx, size_t ndigits, size_t log_base) {
     require(ct_ctx.n == ksk_ctx.n, E_DEGREE_MISMATCH, "DegreeMismatch");
@@ -1333,7 +1335,7 @@ constexpr size_t KS_W_BUDGET_DEFAULT = (size_t)4 << 30;
 inline bool ks_use_unfused(const Ksk &k_, int mode) {
     if (k_.log_base != 0) return false;                 // base-2^k digits of one row: the fused loader extracts them
     if (mode == KS_UNFUSED || mode == KS_UNFUSED_SUB) return true;
-    if (mode == KS_FUSED) return false;
+    if (mode == KS_FUSED || mode == KS_FUSED_SUB) return false;
     return k_.ksk_ctx->logn >= (size_t)FHE_LAB_INT("KS_UNFUSED_MIN_LOGN", 99);
 }
 template <int LOGM, int G0>
@@ -1456,9 +1458,17 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     bool narrow = !FHE_LAB_FLAG("NO_NARROW");
     for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;
     // N = 32768 / 65536 as two / four 16384-point parts on the N = 16384 kernel (one / two folded stages, knobs.hpp
-    // FHE_KS_HALF15): 1 the generic loader, 2 the RNS loader where the key's digits are residue rows
+    // FHE_KS_HALF15: 1 the generic loader, 2 the RNS loader where the key's digits are residue rows) -- 15 % ahead of the
+    // 8192-point sub-blocks below once a launch fills the device (profiles/r04_ks_half15_ab.txt).  A launch whose
+    // 8192-point sub-blocks all fit the device at once (one workgroup per CU) is a different regime: its time is ONE
+    // workgroup's, and a 16384-point part takes 1.7 x as long as an 8192-point one (N = 65536, 4 moduli, 8 polynomials:
+    // 128 parts 0.158 ms, 256 sub-blocks 0.129 ms, profiles/r04_final3_n65536_ab.jsonl) -- KS_AUTO takes the small tiles
+    // there; KS_FUSED / KS_FUSED_SUB force either form.
     static const int half15 = FHE_LAB_INT("KS_HALF15", FHE_KS_HALF15);
-    if ((kc.logn == 15 || kc.logn == 16) && half15) {
+    const int ks_mode = k_.mode.load(std::memory_order_relaxed);
+    const bool fits_at_once = ((npolys * kc.L) << (kc.logn - 13)) <= (size_t)device_cus(kc.device);
+    const bool parts16k = half15 && ks_mode != KS_FUSED_SUB && (ks_mode == KS_FUSED || !fits_at_once);
+    if ((kc.logn == 15 || kc.logn == 16) && parts16k) {
         const size_t lds_ = k::lds_words(1u << 14) * sizeof(u64);
         const unsigned grid = (unsigned)((npolys * kc.L) << (kc.logn - 14));
         const bool rns = half15 == 2 && k_.digit_arg() == (1u << 8);
@@ -1479,9 +1489,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
 #undef FHE_KS_HALF15_LAUNCH
         return;
     }
-#if defined(FHE_LAB) || FHE_KS_HALF15 == 0
-    // rounds 1-3 (release builds: compiled only when the knob selects it): 8192-point sub-blocks, logn - 13 folded stages
-    // (ks_fused_split_kernel)
+    // 8192-point sub-blocks, logn - 13 folded stages (ks_fused_split_kernel; rounds 1-3: every launch)
 #define FHE_KS_SPLIT_LAUNCH_M(G0, LM, NW)                                                                          \
     do {                                                                                                           \
         const size_t lds_ = (k::lds_words(1u << LM) + ((size_t)1 << LM)) * sizeof(u64);                            \
@@ -1525,9 +1533,6 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
 #undef FHE_KS_SPLIT_CASE
 #undef FHE_KS_SPLIT_LAUNCH
 #undef FHE_KS_SPLIT_LAUNCH_M
-#else
-    throw StatusError(E_ARG, "unsupported key-switch row size");
-#endif
 }
 
 // Poly::<PowerBasis>::switch_down_to (M/rq/mod.rs:498-507): `iters` applications of switch_down.

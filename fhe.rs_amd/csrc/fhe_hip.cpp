@@ -974,7 +974,7 @@ void fhe_ksk_destroy(fhe_ksk *k_) { delete k_; }
 fhe_status fhe_ksk_set_mode(fhe_ksk *k_, int mode, size_t w_budget) {
     return guard([&] {
         need(k_, "ksk");
-        require(mode >= KS_AUTO && mode <= KS_UNFUSED_SUB, E_ARG, "mode must be 0 (auto), 1 (fused), 2 (unfused) or 3 (unfused on sub-block tiles)");
+        require(mode >= KS_AUTO && mode <= KS_FUSED_SUB, E_ARG, "mode must be 0 (auto), 1 (fused), 2 (unfused), 3 (unfused on sub-block tiles) or 4 (fused on sub-block tiles)");
         k_->k->mode.store(mode, std::memory_order_relaxed);
         k_->k->w_budget.store(w_budget, std::memory_order_relaxed);
     });

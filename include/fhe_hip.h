@@ -244,16 +244,21 @@ void fhe_ksk_destroy(fhe_ksk *k);
 /* Execution options of every key switch through this handle (key_switch, relinearise, Galois, RGSW, the relinearise
  * step of fhe_bfv_mul), kept on the handle like fhe_mul's: atomics read once per call; they only choose how the sum
  * of KeySwitchingKey::key_switch (F/bfv/keys/key_switching_key.rs:241-320) is evaluated, never its value.
- *   mode     FHE_KS_AUTO (default): the engine picks per shape; FHE_KS_FUSED: one kernel per (ciphertext, key modulus)
- *            that transforms the digits in LDS and multiplies them into register accumulators (Shoup twins);
+ *   mode     FHE_KS_AUTO (default): the engine picks per shape and launch size; FHE_KS_FUSED: one kernel per
+ *            (ciphertext, key modulus) that transforms the digits in LDS and multiplies them into register
+ *            accumulators (Shoup twins) -- rows larger than LDS (N >= 32768) as 16384-point parts with the first one /
+ *            two stages folded into the loader; FHE_KS_FUSED_SUB: the same on 8192-point sub-blocks for N >= 32768
+ *            (twice the workgroups, each 1.7 x shorter: ahead only while a launch does not fill the device);
  *            FHE_KS_UNFUSED: the digit transforms of a launch as one batched NTT into scratch, then a streaming
  *            multiply-accumulate with lazy 128-bit sums (the pattern of F/bfv/ops/dot_product.rs:54-180) that reads
  *            the key without its twins; FHE_KS_UNFUSED_SUB: the same on 8192-point sub-block tiles at N = 16384 too.
  *            Decomposition keys (log_base != 0) always take the fused kernel.
  *   w_budget bytes of transformed digit rows one launch pair may have in flight (0 = default, 4 GiB).
- * Measured on the MI355X (profiles/r04_ks_unfused_ab.txt) the two strategies tie at N = 32768 and the fused one wins
- * below, so FHE_KS_AUTO currently means FHE_KS_FUSED at every size. */
-enum { FHE_KS_AUTO = 0, FHE_KS_FUSED = 1, FHE_KS_UNFUSED = 2, FHE_KS_UNFUSED_SUB = 3 };
+ * Measured on the MI355X (profiles/r04_ks_unfused_ab.txt, r04_ks_half15_ab.txt, r04_final3_ks_modes_ab_c5.jsonl) the fused
+ * strategy wins at every size (N = 32768: 1.08 vs 1.23 ms per 16 polynomials at 16 moduli), so FHE_KS_AUTO means
+ * FHE_KS_FUSED -- except for launches at N >= 32768 whose 8192-point sub-blocks all fit the device at once
+ * (batch x key moduli x N / 8192 <= compute units), which take FHE_KS_FUSED_SUB. */
+enum { FHE_KS_AUTO = 0, FHE_KS_FUSED = 1, FHE_KS_UNFUSED = 2, FHE_KS_UNFUSED_SUB = 3, FHE_KS_FUSED_SUB = 4 };
 fhe_status fhe_ksk_set_mode(fhe_ksk *k, int mode, size_t w_budget);
 fhe_status fhe_ksk_get_mode(const fhe_ksk *k, int *mode, size_t *w_budget);
 /* KeySwitchingKey::key_switch / key_switch_assign (:241-320): p [batch][L][N] PowerBasis over

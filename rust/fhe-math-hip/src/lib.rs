@@ -524,6 +524,8 @@ pub enum KsMode {
     Fused = 1,
     Unfused = 2,
     UnfusedSub = 3,
+    /// rows larger than LDS (N >= 32768) on 8192-point sub-blocks instead of 16384-point parts
+    FusedSub = 4,
 }
 impl Drop for HipKsk {
     fn drop(&mut self) { unsafe { ffi::fhe_ksk_destroy(self.ptr) } }

@@ -309,7 +309,8 @@ def test_unfused_decomposition_keys_stay_fused(fhe):
         cases.case_key_switch_decomposition(fhe, False)
 
 
-@pytest.mark.parametrize("n,mode", [(8192, 2), (16384, 2), (16384, 3), (32768, 2), (65536, 2), (16384, 1), (32768, 1), (65536, 1)])
+@pytest.mark.parametrize("n,mode", [(8192, 2), (16384, 2), (16384, 3), (32768, 2), (65536, 2), (16384, 1), (32768, 1), (65536, 1),
+                                    (32768, 4), (65536, 4)])
 def test_key_switch_strategies_large_rows(fhe, n, mode):
     """Unfused: whole-row tiles up to N = 16384, 8192-point sub-block tiles with the first stages folded into the loader
     above (and at 16384 in mode UNFUSED_SUB).  Fused (mode 1): whole rows up to 16384, 16384-point parts with one / two
@@ -336,7 +337,7 @@ def test_key_switch_strategies_large_rows(fhe, n, mode):
         for i in range(2):
             w0, w1 = ck.key_switch(p[i])
             assert np.array_equal(np.asarray(g0[i]), w0) and np.array_equal(np.asarray(g1[i]), w1)
-        if n > 16384 and mode != 1:
+        if n > 16384 and mode not in (1, 4):
             break   # (one modulus set is enough at the emulator's speed; the fused form has a loader per kind of set)
 
 
@@ -373,6 +374,8 @@ def test_scaler_many_wide_moduli(fhe):
 @pytest.mark.parametrize("n,bits", [(16384, 60), (32768, 60), (32768, 62), (65536, 60), (65536, 62)])
 def test_key_switch_decomposition_rows(fhe, n, bits):
     """Single-modulus key levels (base-2^k digits of one residue row) on whole rows and on the 16384-point parts of rows
-    larger than LDS, narrow (60-bit) and general (62-bit) passes."""
-    cases.case_key_switch_decomposition_rows(fhe, False, n, bits)
+    larger than LDS (and on their 8192-point sub-blocks: FUSED_SUB), narrow (60-bit) and general (62-bit) passes."""
+    for mode in (1, 4) if n > 16384 else (1,):
+        with fhe.KeySwitchingKey.forced_mode(mode):
+            cases.case_key_switch_decomposition_rows(fhe, False, n, bits)
 

@@ -519,7 +519,7 @@ def test_release_library_ignores_lab_environment(tmp_path):
 # ---- round 4: the unfused key switch (ks_ntt_kernel + ks_mac_kernel).  Every case that goes through a key switch is
 # run with each evaluation strategy forced on the handle (fhe_ksk_set_mode), so that whichever one the engine's
 # per-shape choice (FHE_KS_AUTO) lands on has been compared with the oracle at that shape. ----
-KS_MODES = {"fused": 1, "unfused": 2, "unfused_sub": 3}
+KS_MODES = {"auto": 0, "fused": 1, "unfused": 2, "unfused_sub": 3, "fused_sub": 4}
 
 
 @pytest.mark.parametrize("dev", [False, True])
@@ -565,9 +565,10 @@ def test_config_c3_key_switch_modes(fhe, mode):
         full_size.check_relin_rotate(fhe, n=16384, sizes=[60] * 8, batch=96, cfg=3, sample=(0, 1, 31, 32, 33, 63, 64, 95))
 
 
-@pytest.mark.parametrize("mode", ["fused", "unfused"])
+@pytest.mark.parametrize("mode", ["fused", "fused_sub", "unfused"])
 def test_config_c5_key_switch_modes(fhe, mode):
-    """configs[4]: the 15-level chain (4 ciphertexts) and the bench batch 16 at level 0, with each strategy."""
+    """configs[4]: the 15-level chain (4 ciphertexts) and the bench batch 16 at level 0, with each strategy (FHE_KS_AUTO
+    -- test_config_c5_chain_n32768, test_config_c5_bench_batches_n32768 -- mixes the two fused forms by launch size)."""
     import full_size
     with fhe.KeySwitchingKey.forced_mode(KS_MODES[mode]):
         full_size.check_chain(fhe, n=32768, sizes=[60] * 16, batch=4, levels=15, cfg=5)
@@ -575,7 +576,8 @@ def test_config_c5_key_switch_modes(fhe, mode):
     fhe.workspace_trim()
 
 
-@pytest.mark.parametrize("n,mode", [(8192, 2), (16384, 2), (16384, 3), (32768, 2), (65536, 2), (16384, 1), (32768, 1), (65536, 1)])
+@pytest.mark.parametrize("n,mode", [(8192, 2), (16384, 2), (16384, 3), (32768, 2), (65536, 2), (16384, 1), (32768, 1), (65536, 1),
+                                    (32768, 4), (65536, 4), (32768, 0), (65536, 0)])
 def test_key_switch_strategies_large_rows(fhe, n, mode):
     """Every key-switch strategy (2 / 3 unfused, 1 fused: 16384-point parts with one / two folded stages above N = 16384)
     on synthetic keys and inputs vs the C oracle: 60-bit moduli (narrow passes, residue-row loader), 62 + 61 bits (general
@@ -704,7 +706,7 @@ def test_ntt_split_rows_narrow_moduli(fhe, n):
     cases.case_ntt(fhe, True, n, moduli=mods, batch=5, coracle_ctx=coracle.CCtx(OCtx(mods, n)))
 
 
-@pytest.mark.parametrize("mode", ["fused", "unfused"])
+@pytest.mark.parametrize("mode", ["auto", "fused", "fused_sub", "unfused"])
 def test_relin_rotate_rows_larger_than_lds(fhe, mode):
     """Relinearise and both rotations at N = 32768 (rows larger than LDS): the key switch reads the caller's Ntt rows for
     one transform per key modulus and adds the substituted c0 on the way out -- the sub-block offsets of those paths."""
@@ -715,7 +717,9 @@ def test_relin_rotate_rows_larger_than_lds(fhe, mode):
 
 @pytest.mark.parametrize("n,bits", [(16384, 60), (32768, 60), (32768, 62), (65536, 60), (65536, 62)])
 def test_key_switch_decomposition_rows(fhe, n, bits):
-    """Single-modulus key levels (base-2^k digits of one residue row) on whole rows and on the 16384-point parts of rows
-    larger than LDS, narrow (60-bit) and general (62-bit) passes."""
-    cases.case_key_switch_decomposition_rows(fhe, True, n, bits)
+    """Single-modulus key levels (base-2^k digits of one residue row) on whole rows and on the 16384-point parts / the
+    8192-point sub-blocks of rows larger than LDS, narrow (60-bit) and general (62-bit) passes."""
+    for mode in (1, 4) if n > 16384 else (1,):
+        with fhe.KeySwitchingKey.forced_mode(mode):
+            cases.case_key_switch_decomposition_rows(fhe, True, n, bits)
 

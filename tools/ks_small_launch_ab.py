@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Key switch on rows larger than LDS: 16384-point parts (FHE_KS_FUSED) against 8192-point sub-blocks (FHE_KS_FUSED_SUB)
+and the engine's per-launch choice (FHE_KS_AUTO) over the batch sizes either side of "the launch fills the device".
+Relinearise (one key switch + the add), same process, alternating, `rounds` rounds, 5 calls per timing.
+usage: python tools/ks_small_launch_ab.py [rounds]   -- one JSON line per (shape, batch)"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import fhe_rs_amd as fhe
+
+K = fhe.KeySwitchingKey
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+
+
+def timeit(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return round(e0.elapsed_time(e1) / reps, 4)
+
+
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+for n, L, batches in ((32768, 16, (1, 2, 3, 4, 6, 8, 16)), (32768, 4, (1, 4, 8, 12, 16, 24, 32, 64)), (65536, 4, (1, 4, 8, 12, 16, 32))):
+    ctx = fhe.Context(fhe.generate_moduli([60] * L, n), n)
+    kk = ctx.synth_uniform(5, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, n)
+    ksk = K(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous())
+    rk = fhe.RelinearizationKey(ksk)
+    for batch in batches:
+        ct3 = ctx.synth_uniform(5, 0, 0, 3, batch)
+        ms = {"parts_16384": [], "sub_blocks_8192": [], "auto": []}
+        for _ in range(rounds):
+            for name, mode in (("parts_16384", K.FUSED), ("sub_blocks_8192", K.FUSED_SUB), ("auto", K.AUTO)):
+                ksk.set_mode(mode)
+                ms[name].append(timeit(lambda: rk.relinearizes(ct3)))
+        sub_blocks = batch * L * (n // 8192)
+        print(json.dumps({"n": n, "moduli": L, "batch": batch, "sub_blocks_8192": sub_blocks, "compute_units": cus,
+                          "auto_takes": "sub_blocks_8192" if sub_blocks <= cus else "parts_16384", "ms": ms}), flush=True)

@@ -1330,13 +1330,25 @@ constexpr size_t KS_W_BUDGET_DEFAULT = (size_t)4 << 30;
 //   C2  N =  8192,  4 moduli, 1024 polynomials  0.831 ms   vs 0.553 + 0.420 = 0.973 ms
 // Stage A runs at the NTT kernels' rate (20 M 8192-point tiles/s with the two folded stages, 26 M without), but W
 // -- L * Lk rows per polynomial, 1 GiB at C5 / 16 -- costs stage B what the transforms gained: a tie at N = 32768, a
-// loss below.  KS_AUTO therefore stays on the fused kernels at every size; the unfused path remains selectable per
-// handle (and is parity-tested at every size) for hosts whose shapes differ (many digits, few key moduli).
-inline bool ks_use_unfused(const Ksk &k_, int mode) {
+// loss below (and since the fused kernel takes rows larger than LDS as 16384-point parts, a loss at N = 32768 too: 1.08 vs
+// 1.23 ms, profiles/r04_final3_ks_modes_ab_c5.jsonl).  For launches that FILL the device KS_AUTO therefore stays on the
+// fused kernels at every size.
+// Launches that do not are the opposite regime (profiles/r04_ks_small_batches_all_modes.txt): a fused launch has
+// batch x key moduli workgroups, each walking its digits one after the other, so its time is one workgroup's whatever the
+// batch -- 0.054 ms at C2, 0.22 ms at C3, 0.52 / 0.32 ms at C5 -- while stage A of the unfused form has digits x more
+// tiles and fills the device from a single ciphertext on: C3 batch 1 0.220 -> 0.055 ms, batch 16 0.225 -> 0.155; C5 batch 1
+// 0.32 -> 0.12 ms; C2 batch 1 0.054 -> 0.030, batch 32 0.063 -> 0.054.  The crossover sits between 128 and 256 fused
+// workgroups at every size measured (N = 4096 ... 32768): KS_AUTO takes the unfused form while 2 x workgroups <= compute
+// units (at least three digits, N >= 4096: below that the second launch costs what the parallelism gains).
+inline bool ks_use_unfused(const Ksk &k_, int mode, size_t npolys) {
     if (k_.log_base != 0) return false;                 // base-2^k digits of one row: the fused loader extracts them
     if (mode == KS_UNFUSED || mode == KS_UNFUSED_SUB) return true;
     if (mode == KS_FUSED || mode == KS_FUSED_SUB) return false;
-    return k_.ksk_ctx->logn >= (size_t)FHE_LAB_INT("KS_UNFUSED_MIN_LOGN", 99);
+    const Ctx &kc = *k_.ksk_ctx;
+    if (kc.logn >= (size_t)FHE_LAB_INT("KS_UNFUSED_MIN_LOGN", 99)) return true;
+    if (FHE_LAB_FLAG("NO_KS_SMALL_UNFUSED") || kc.logn < 12 || k_.ndigits < 3) return false;
+    const size_t fused_wg = (npolys * kc.L) << (kc.logn > 14 ? kc.logn - 14 : 0);
+    return 2 * fused_wg <= (size_t)device_cus(kc.device);
 }
 template <int LOGM, int G0>
 inline void launch_ks_ntt(const Ksk &k_, bool narrow, bool rns, unsigned grid, hipStream_t s, const u64 *p, u64 p_stride,
@@ -1432,7 +1444,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     if (!npolys) return;
     {
         const int mode = k_.mode.load(std::memory_order_relaxed);
-        if (ks_use_unfused(k_, mode)) {
+        if (ks_use_unfused(k_, mode, npolys)) {
             key_switch_polys_unfused(k_, mode, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride);
             return;
         }

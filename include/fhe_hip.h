@@ -254,10 +254,15 @@ void fhe_ksk_destroy(fhe_ksk *k);
  *            the key without its twins; FHE_KS_UNFUSED_SUB: the same on 8192-point sub-block tiles at N = 16384 too.
  *            Decomposition keys (log_base != 0) always take the fused kernel.
  *   w_budget bytes of transformed digit rows one launch pair may have in flight (0 = default, 4 GiB).
- * Measured on the MI355X (profiles/r04_ks_unfused_ab.txt, r04_ks_half15_ab.txt, r04_final3_ks_modes_ab_c5.jsonl) the fused
- * strategy wins at every size (N = 32768: 1.08 vs 1.23 ms per 16 polynomials at 16 moduli), so FHE_KS_AUTO means
- * FHE_KS_FUSED -- except for launches at N >= 32768 whose 8192-point sub-blocks all fit the device at once
- * (batch x key moduli x N / 8192 <= compute units), which take FHE_KS_FUSED_SUB. */
+ * What FHE_KS_AUTO does, from measurements on the MI355X (profiles/r04_ks_unfused_ab.txt, r04_ks_half15_ab.txt,
+ * r04_final3_ks_modes_ab_c5.jsonl, r04_ks_small_launch_ab.txt, r04_ks_small_batches_all_modes.txt):
+ *   - a launch that fills the device takes FHE_KS_FUSED at every size (N = 32768, 16 moduli, 16 polynomials: 1.08 vs
+ *     1.23 ms unfused; N = 16384, 8 moduli, 512: 3.5 vs 4.3 ms; N = 8192, 4 moduli, 1024: 0.83 vs 0.97 ms);
+ *   - a launch with few fused workgroups (2 x batch x key moduli [x N / 16384] <= compute units; RNS-digit keys with at
+ *     least three digits, N >= 4096) takes FHE_KS_UNFUSED, whose first stage has digits x more tiles: one ciphertext at
+ *     N = 16384, 8 moduli 0.220 -> 0.055 ms, at N = 32768, 16 moduli 0.32 -> 0.12 ms, at N = 8192, 4 moduli 0.054 -> 0.030;
+ *   - other launches at N >= 32768 whose 8192-point sub-blocks fit the device at once (decomposition keys, fewer than
+ *     three digits) take FHE_KS_FUSED_SUB. */
 enum { FHE_KS_AUTO = 0, FHE_KS_FUSED = 1, FHE_KS_UNFUSED = 2, FHE_KS_UNFUSED_SUB = 3, FHE_KS_FUSED_SUB = 4 };
 fhe_status fhe_ksk_set_mode(fhe_ksk *k, int mode, size_t w_budget);
 fhe_status fhe_ksk_get_mode(const fhe_ksk *k, int *mode, size_t *w_budget);

@@ -2,7 +2,9 @@
 """Key switch on rows larger than LDS: 16384-point parts (FHE_KS_FUSED) against 8192-point sub-blocks (FHE_KS_FUSED_SUB)
 and the engine's per-launch choice (FHE_KS_AUTO) over the batch sizes either side of "the launch fills the device".
 Relinearise (one key switch + the add), same process, alternating, `rounds` rounds, 5 calls per timing.
-usage: python tools/ks_small_launch_ab.py [rounds]   -- one JSON line per (shape, batch)"""
+With `all`: every strategy (also FHE_KS_UNFUSED / _SUB, whose first stage has batch x digits x key moduli tiles and fills
+the device where the fused kernels' batch x key moduli workgroups do not) on the C2 / C3 / C5 shapes at small batches.
+usage: python tools/ks_small_launch_ab.py [rounds] [all]   -- one JSON line per (shape, batch)"""
 import json
 import os
 import sys
@@ -29,6 +31,28 @@ def timeit(fn, reps=5):
 
 
 cus = torch.cuda.get_device_properties(0).multi_processor_count
+if "all" in sys.argv:
+    for n, L, batches in ((8192, 4, (1, 2, 4, 8, 16, 32, 64, 128, 256)), (16384, 8, (1, 2, 4, 8, 16, 32, 64)), (32768, 16, (1, 2, 4, 8, 16)),
+                          (4096, 3, (1, 4, 16, 64, 256))):
+        ctx = fhe.Context(fhe.generate_moduli([60] * L, n), n)
+        kk = ctx.synth_uniform(5, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, n)
+        ksk = K(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous())
+        rk = fhe.RelinearizationKey(ksk)
+        modes = [("fused", K.FUSED), ("unfused", K.UNFUSED), ("auto", K.AUTO)]
+        if n == 16384:
+            modes.insert(2, ("unfused_sub", K.UNFUSED_SUB))
+        if n > 16384:
+            modes.insert(1, ("fused_sub", K.FUSED_SUB))
+        for batch in batches:
+            ct3 = ctx.synth_uniform(5, 0, 0, 3, batch)
+            ms = {name: [] for name, _ in modes}
+            for _ in range(rounds):
+                for name, mode in modes:
+                    ksk.set_mode(mode)
+                    ms[name].append(timeit(lambda: rk.relinearizes(ct3), reps=10))
+            print(json.dumps({"n": n, "moduli": L, "batch": batch, "fused_workgroups": batch * L * max(1, n // 16384),
+                              "compute_units": cus, "ms": ms}), flush=True)
+    sys.exit(0)
 for n, L, batches in ((32768, 16, (1, 2, 3, 4, 6, 8, 16)), (32768, 4, (1, 4, 8, 12, 16, 24, 32, 64)), (65536, 4, (1, 4, 8, 12, 16, 32))):
     ctx = fhe.Context(fhe.generate_moduli([60] * L, n), n)
     kk = ctx.synth_uniform(5, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, n)

@@ -370,7 +370,13 @@ def reference_bench_ids(fhe, torch, par, rk, batch, timeit):
     out["bfv/relinearize"] = entry(timeit(lambda: rk.relinearizes(c3)), 2 * L + L * L + 4 * L)
     out["bfv/mul_then_relinearize"] = entry(timeit(lambda: rk.relinearizes(plain.multiply(a, b))),
                                             22 * K + 9 * L + 2 * L + L * L + 4 * L)
-    del c3, plain
+    # the reference's Criterion IDs time ONE ciphertext per call: the same calls at batch 1 (informational; caller's stream)
+    a1, b1, c31 = a[:1].contiguous(), b[:1].contiguous(), c3[:1].contiguous()
+    m1 = fhe.Multiplicator.default(par, rk, 0)
+    out["single_ciphertext_latency_c2"] = dict(mul_and_relin_ms=round(timeit(lambda: m1.multiply(a1, b1)), 4),
+                                               relinearize_ms=round(timeit(lambda: rk.relinearizes(c31)), 4),
+                                               note="one ciphertext (pair) per call, inputs resident")
+    del c3, plain, a1, b1, c31, m1
     # fhe-math/benches/rns.rs: the reference's 3 -> 4 modulus lists, PowerBasis columns of [batch*2] polynomials
     q3 = [4611686018326724609, 4611686018309947393, 4611686018282684417]
     p4 = [4611686018257518593, 4611686018232352769, 4611686018171535361, 4611686018106523649]
@@ -422,7 +428,12 @@ def other_configs(fhe, torch, reps=3):
         out[name] = dict(workload=f"n=16384, 8x60-bit, batch {batch}", ops_per_s=round(batch / ms * 1e3, 1),
                          ms=round(ms, 3), stage_model_bytes_per_op=rows * R, stage_model_GBps=round(gbs, 1),
                          frac=round(gbs / HBM_PEAK_GBS, 4))
-    del ct3, ct2, rk, gk3, gkr, ksk, ctx
+    # one ciphertext (the reference's own benches are single-ciphertext calls): the launch does not fill the device with
+    # fused workgroups, FHE_KS_AUTO takes the unfused key switch (profiles/r04_ks_small_batches_all_modes.txt)
+    one3, one2 = ct3[:1].contiguous(), ct2[:1].contiguous()
+    lat = {"C3_relinearize_ms": round(timeit(lambda: rk.relinearizes(one3)), 4),
+           "C3_rotate_columns_ms": round(timeit(lambda: gk3.relinearize(one2)), 4)}
+    del ct3, ct2, one3, one2, rk, gk3, gkr, ksk, ctx
     n, L = 32768, 16
     t = fhe.generate_prime(20, 2 * n, 1 << 20)
     q = fhe.generate_moduli([60] * L, n)
@@ -447,6 +458,9 @@ def other_configs(fhe, torch, reps=3):
             workload=f"n=32768, 16x60-bit (K={K}), batch {batch}", ops_per_s=round(batch / ms * 1e3, 1), ms=round(ms, 3),
             stage_model_bytes_per_op=rows * 8 * n, stage_model_GBps=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
         del a, b
+    a, b = ctx.synth_uniform(0xF4E50005, 0, 0, 2, 1), ctx.synth_uniform(0xF4E50005, 0, 2, 2, 1)
+    lat["C5_level0_mul_relin_modswitch_ms"] = round(timeit(lambda: mul.multiply(a, b)), 4)
+    out["single_ciphertext_latency"] = dict(lat, note="one ciphertext (pair) per call, caller's stream, inputs resident")
     return out
 
 

@@ -1211,8 +1211,9 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     constexpr bool ks_persist_size = LOGN == 13 || (FHE_KS_PERSIST14 && LOGN == 14);
 #endif
     if (ks_persist_size && ks_persist > 0) ks_grid = std::min<unsigned>(ks_grid, (unsigned)(device_cus(kc.device) * ks_persist));
-    // RNS instances (N = 4096, 8192): residue-row digits of same-width moduli, see the kernel.  (Not at N = 16384:
-    // that instance sits at 126 of 128 VGPRs and the simpler loader makes the compiler spill 52 B elsewhere.)
+    // RNS instances (N = 4096, 8192): residue-row digits of same-width moduli, see the kernel.  (Not at N = 16384: in
+    // round 3 that instance spilled 52 B; it no longer does, and measured again at C3 in round 4 it changes nothing --
+    // relinearise of 512: 4.09 / 4.18 / 4.18 ms against 4.17 / 4.14 / 4.13, profiles/r04_ks14_rns_ab.jsonl.)
     const bool rns = (LOGN == 12 || LOGN == 13) && k_.digit_arg() == (1u << 8);
 #define FHE_KS_LAUNCH_R(NW, GMV, RNS)                                                                                 \
     allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 0, RNS>), lds);                                                  \

@@ -1508,13 +1508,13 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
         const size_t lds_ = (k::lds_words(1u << LM) + ((size_t)1 << LM)) * sizeof(u64);                            \
         if (k_.digit_arg() == (1u << 8)) {   /* RNS instance: residue-row digits of same-width moduli */          \
             allow_big_lds((k::ks_fused_split_kernel<G0, LM, NW, true>), lds_);                                     \
-            FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0, LM, NW, true>),                           \
+            FHE_LAUNCH("key_switch_fused_sub", (k::ks_fused_split_kernel<G0, LM, NW, true>),                           \
                        dim3((unsigned)((npolys * kc.L) << G0)), dim3((1u << LM) / 8), lds_, s, p, p_stride, o0,    \
                        o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(),         \
                        kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride);         \
         } else {                                                                                                   \
             allow_big_lds((k::ks_fused_split_kernel<G0, LM, NW, false>), lds_);                                    \
-            FHE_LAUNCH("key_switch_fused", (k::ks_fused_split_kernel<G0, LM, NW, false>),                          \
+            FHE_LAUNCH("key_switch_fused_sub", (k::ks_fused_split_kernel<G0, LM, NW, false>),                          \
                        dim3((unsigned)((npolys * kc.L) << G0)), dim3((1u << LM) / 8), lds_, s, p, p_stride, o0,    \
                        o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(),         \
                        kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride);         \

@@ -723,3 +723,42 @@ def test_key_switch_decomposition_rows(fhe, n, bits):
         with fhe.KeySwitchingKey.forced_mode(mode):
             cases.case_key_switch_decomposition_rows(fhe, True, n, bits)
 
+
+def test_key_switch_auto_picks_strategy_by_launch_size(fhe):
+    """What FHE_KS_AUTO does (engine.hpp ks_use_unfused / key_switch_polys; profiles/r04_ks_small_batches_all_modes.txt,
+    r04_ks_small_launch_ab.txt), read back from the library's per-launch profiler: launches with at most half the compute
+    units' worth of fused workgroups run the unfused kernels, larger ones the fused kernel; a key with fewer than three
+    digits stays fused, on 8192-point sub-blocks while those fit the device at once (N >= 32768).  Values are compared
+    with the oracle by every other test of this file; this one pins the choice."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def kernels_of(ctx, L, batch):
+        kk = ctx.synth_uniform(5, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, ctx.degree)
+        rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous()))
+        ct3 = ctx.synth_uniform(5, 0, 0, 3, batch)
+        rk.relinearizes(ct3)
+        torch.cuda.synchronize()
+        fhe.prof_reset()
+        fhe.prof_enable(True)
+        try:
+            rk.relinearizes(ct3)
+            torch.cuda.synchronize()
+            return set(fhe.prof_report())
+        finally:
+            fhe.prof_enable(False)
+            fhe.prof_reset()
+
+    n, L = 8192, 4
+    ctx = fhe.Context(fhe.generate_moduli([60] * L, n), n)
+    small, large = cus // (2 * L), cus // L          # 2 x batch x L <= CUs  /  batch x L = CUs
+    assert {"ks_digit_ntt", "ks_mac"} <= kernels_of(ctx, L, small) and "key_switch_fused" not in kernels_of(ctx, L, small)
+    ks = kernels_of(ctx, L, large)
+    assert "key_switch_fused" in ks and "ks_mac" not in ks
+    n, L = 32768, 2                                  # two digits: never unfused; sub-blocks while they fit at once
+    ctx = fhe.Context(fhe.generate_moduli([60] * L, n), n)
+    ks = kernels_of(ctx, L, cus // (4 * L))          # batch x L x 4 sub-blocks = CUs
+    assert "key_switch_fused_sub" in ks and "ks_mac" not in ks and "key_switch_fused" not in ks
+    ks = kernels_of(ctx, L, cus // (4 * L) + 1)
+    assert "key_switch_fused" in ks and "key_switch_fused_sub" not in ks
+

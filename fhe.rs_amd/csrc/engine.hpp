@@ -1349,7 +1349,11 @@ inline bool ks_use_unfused(const Ksk &k_, int mode, size_t npolys) {
     if (kc.logn >= (size_t)FHE_LAB_INT("KS_UNFUSED_MIN_LOGN", 99)) return true;
     if (FHE_LAB_FLAG("NO_KS_SMALL_UNFUSED") || kc.logn < 12 || k_.ndigits < 3) return false;
     const size_t fused_wg = (npolys * kc.L) << (kc.logn > 14 ? kc.logn - 14 : 0);
-    return 2 * fused_wg <= (size_t)device_cus(kc.device);
+    const size_t cus = (size_t)device_cus(kc.device);
+    // (rows larger than LDS with short digit loops: the 8192-point fused sub-blocks take over earlier -- N = 32768, 4
+    // moduli: 96 parts 0.093 vs 0.092 ms, 128 parts 0.112 vs 0.101; profiles/r04_final5_ks_small_launch_ab.jsonl)
+    if (kc.logn > 14 && k_.ndigits < 8) return 8 * fused_wg < 3 * cus;
+    return 2 * fused_wg <= cus;
 }
 template <int LOGM, int G0>
 inline void launch_ks_ntt(const Ksk &k_, bool narrow, bool rns, unsigned grid, hipStream_t s, const u64 *p, u64 p_stride,

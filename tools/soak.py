@@ -89,7 +89,37 @@ def small(reps):
     sys.exit(1 if bad else 0)
 
 
+def auto_small(reps):
+    """Round 4: launches that FHE_KS_AUTO sends to the unfused kernels (few fused workgroups) -- relinearise and a
+    rotation at the C2 / C3 / C5 shapes with 8 / 4 / 2 ciphertexts, every result against the SAME call with the fused
+    strategy forced on the handle (cross-strategy equality and determinism in one check)."""
+    K = fhe.KeySwitchingKey
+    bad, total, t0 = 0, 0, time.time()
+    for n, L, batch in ((8192, 4, 8), (16384, 8, 4), (32768, 16, 2)):
+        ctx = fhe.Context(fhe.generate_moduli([60] * L, n), n)
+        kk = ctx.synth_uniform(11, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, n)
+        ksk = K(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous())
+        rk, gk = fhe.RelinearizationKey(ksk), fhe.GaloisKey(ksk, 3)
+        ct3 = ctx.synth_uniform(11, 0, 0, 3, batch)
+        ct2 = ct3[:, :2].contiguous()
+        ksk.set_mode(K.FUSED)
+        ref_r, ref_g = rk.relinearizes(ct3), gk.relinearize(ct2)
+        torch.cuda.synchronize()
+        ksk.set_mode(K.AUTO)
+        for _ in range(reps):
+            r, g = rk.relinearizes(ct3), gk.relinearize(ct2)
+            if not (torch.equal(r, ref_r) and torch.equal(g, ref_g)):
+                bad += 1
+            total += 2 * batch
+    torch.cuda.synchronize()
+    print(json.dumps(dict(config="C2 / C3 / C5 shapes at 8 / 4 / 2 ciphertexts, FHE_KS_AUTO (unfused) against the forced fused result",
+                          repetitions=reps, ops=total, mismatches=bad, seconds=round(time.time() - t0, 1))))
+    sys.exit(1 if bad else 0)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "auto_small":
+        auto_small(int(sys.argv[1]))
     if len(sys.argv) > 3 and sys.argv[3] == "c3":
         c3(int(sys.argv[1]))
     if len(sys.argv) > 3 and sys.argv[3] == "small":

@@ -1381,7 +1381,11 @@ inline void key_switch_polys_unfused(const Ksk &k_, int mode, const u64 *p, u64 
     const size_t N = kc.n, nd = k_.ndigits, Lk = kc.L;
     const uint32_t logn = (uint32_t)kc.logn;
     // tile geometry of stage A: whole rows up to 16384 points, 8192-point sub-blocks above (and at 16384 on request)
-    const uint32_t logm = logn > 14 ? 13 : (logn == 14 && mode == KS_UNFUSED_SUB) ? 13 : logn;
+    // (KS_AUTO at N = 16384: sub-block tiles while the whole-row tiles of stage A would leave half the device idle --
+    // one ciphertext at 8 moduli: 64 rows, 0.0527 vs 0.0556 ms; four: 256 rows, 0.0684 vs 0.0668)
+    const bool sub14 = logn == 14 && (mode == KS_UNFUSED_SUB ||
+                                      (mode == KS_AUTO && 2 * npolys * nd * Lk <= (size_t)device_cus(kc.device)));
+    const uint32_t logm = logn > 14 ? 13 : sub14 ? 13 : logn;
     const uint32_t g0 = logn - logm;
     bool narrow = !FHE_LAB_FLAG("NO_NARROW");
     for (u64 q : kc.moduli) narrow = narrow && (q >> 60) == 0;

@@ -22,8 +22,17 @@ def build_emu():
         return os.environ["FHE_EMU_LIB"]
     srcs = [os.path.join(ROOT, "fhe.rs_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "fhe.rs_amd", "csrc"))]
     srcs += [os.path.join(ROOT, "tests", "emu", "emu_rt.hpp"), os.path.join(ROOT, "include", "fhe_hip.h")]
-    if (not os.path.exists(EMU_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs):
-        subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build.sh")], stdout=subprocess.DEVNULL)
+    def stale():
+        return (not os.path.exists(EMU_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs)
+    if stale():
+        # one builder at a time (pytest-xdist workers of a fresh checkout all arrive here at once); build.sh renames
+        # the finished library into place, so a worker that did not build never sees a partial file
+        import fcntl
+        os.makedirs(os.path.dirname(EMU_LIB), exist_ok=True)
+        with open(os.path.join(os.path.dirname(EMU_LIB), ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if stale():
+                subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build.sh")], stdout=subprocess.DEVNULL)
     return EMU_LIB
 
 

@@ -198,10 +198,16 @@ def check_chain(fhe, n, sizes, batch, levels, cfg):
             assert np.array_equal(u64(cur[i]), want[i]), f"level {level} ciphertext {i}"
 
 
-def random_shape(idx):
-    """A deterministic 'random' parameter shape: degree, modulus sizes (mixed widths), batch."""
+def random_shape(idx, big=False):
+    """A deterministic 'random' parameter shape: degree, modulus sizes (mixed widths), batch.  big: rows larger than LDS
+    (N = 32768 / 65536, up to five moduli, up to three ciphertexts) -- the sub-block / part forms of every kernel."""
     import random
     rng = random.Random(0xC0FFEE + idx)
+    if big:
+        n = 1 << rng.randrange(15, 17)
+        L = rng.randrange(1, 6)
+        sizes = [rng.choice([45, 54, 58, 60, 61, 62]) for _ in range(L)]
+        return n, sizes, rng.randrange(1, 4)
     n = 1 << rng.randrange(5, 15)
     L = rng.randrange(1, 7)
     sizes = [rng.choice([36, 45, 50, 54, 58, 60, 61, 62]) for _ in range(L)]
@@ -209,10 +215,10 @@ def random_shape(idx):
     return n, sizes, batch
 
 
-def check_random_shape(fhe, idx):
+def check_random_shape(fhe, idx, big=False):
     """Multiply (+relinearise, +modulus switch when the chain allows), relinearise and rotations on
     a pseudo-random parameter shape, every ciphertext against the C oracle."""
-    n, sizes, batch = random_shape(idx)
+    n, sizes, batch = random_shape(idx, big)
     cfg = 100 + idx
     L = len(sizes)
     check_mul(fhe, n, sizes, batch, relin=L >= 2, cfg=cfg, mod_switch=L >= 2 and idx % 2 == 0)

@@ -2,7 +2,7 @@
 """Random-shape parity sweep on the GPU beyond the 48 shapes of tests/test_gpu_parity.py: every shape's multiply
 (+relinearise / modulus switch), relinearise and rotations against the C oracle (tests/full_size.py).
 Test infrastructure (lives in tests/ because it uses the oracle).
-Usage: python tests/random_sweep_gpu.py [seconds [first_idx [last_idx [ks_mode]]]]"""
+Usage: python tests/random_sweep_gpu.py [seconds [first_idx [last_idx [ks_mode [big]]]]]   (big: N = 32768 / 65536 only)"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
@@ -14,13 +14,14 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 400
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 last = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 ks_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # fhe_ksk_set_mode of every key the sweep makes (0 = auto)
+big = len(sys.argv) > 5 and sys.argv[5] == "big"
 fhe.KeySwitchingKey.default_mode = (ks_mode, 0)
 for idx in range(first, last):
     try:
-        full_size.check_random_shape(fhe, idx)
+        full_size.check_random_shape(fhe, idx, big)
         done += 1
     except Exception as e:
-        fails.append((idx, full_size.random_shape(idx), repr(e)[:200]))
+        fails.append((idx, full_size.random_shape(idx, big), repr(e)[:200]))
         break
     if time.time() - t0 > budget: break
-print(json.dumps({"shapes_checked": done, "first_idx": first, "ks_mode": ks_mode, "failures": fails, "seconds": round(time.time() - t0)}))
+print(json.dumps({"shapes_checked": done, "first_idx": first, "ks_mode": ks_mode, "big": big, "failures": fails, "seconds": round(time.time() - t0)}))

@@ -372,3 +372,23 @@ def test_every_public_wrapper_is_used_or_declared_host_only():
     assert not dead, f"public wrappers nothing calls and nobody declared host-only: {sorted(dead)}"
     stale = {n for n in HOST_ONLY_API if n not in pub_fns and n not in set(re.findall(r"fn ([a-z_][a-z0-9_]*)", lib))}
     assert not stale, f"HOST_ONLY_API names that lib.rs no longer has: {sorted(stale)}"
+
+
+def test_key_switch_modes_agree_across_header_engine_python_and_rust():
+    """FHE_KS_* (include/fhe_hip.h), KS_* (engine.hpp), KeySwitchingKey.* (api.py) and KsMode (rust/fhe-math-hip) are four
+    spellings of one enum that crosses the C ABI as a plain int: same names, same values, and fhe_ksk_set_mode's range
+    check covers exactly them."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rd = lambda *p: open(os.path.join(root, *p)).read()
+    hdr = dict((k, int(v)) for k, v in re.findall(r"FHE_KS_([A-Z_]+) = (\d+)", re.search(r"enum \{ FHE_KS_AUTO[^}]*\}", rd("include", "fhe_hip.h")).group(0)))
+    eng = dict((k, int(v)) for k, v in re.findall(r"KS_([A-Z_]+) = (\d+)", re.search(r"enum : int \{ KS_AUTO[^}]*\}", rd("fhe.rs_amd", "csrc", "engine.hpp")).group(0)))
+    m = re.search(r"^    ((?:[A-Z_]+, )+[A-Z_]+) = ((?:\d+, )+\d+)$", rd("fhe.rs_amd", "api.py"), re.M)
+    py = dict(zip(m.group(1).split(", "), map(int, m.group(2).split(", "))))
+    rs_body = re.search(r"pub enum KsMode \{(.*?)\n\}", rd("rust", "fhe-math-hip", "src", "lib.rs"), re.S).group(1)
+    snake = lambda s: re.sub(r"(?<!^)(?=[A-Z])", "_", s).upper()
+    rs = dict((snake(k), int(v)) for k, v in re.findall(r"^\s*([A-Za-z]+) = (\d+),", rs_body, re.M))
+    assert hdr == eng == py == rs and sorted(hdr.values()) == list(range(len(hdr))), (hdr, eng, py, rs)
+    top = max(hdr, key=hdr.get)
+    assert re.search(r"mode >= KS_AUTO && mode <= KS_%s" % top, rd("fhe.rs_amd", "csrc", "fhe_hip.cpp"))
+

@@ -55,11 +55,12 @@ def host_key(cctx, seed, ndigits):
     return coracle.CKsk(c0, c0s, c1, c1s, cctx, cctx)
 
 
-def check_mul(fhe, n, sizes, batch, relin, cfg, sample=None, mod_switch=False, ct0=0):
+def check_mul(fhe, n, sizes, batch, relin, cfg, sample=None, mod_switch=False, ct0=0, moduli=None):
     """ct0: index of the first ciphertext of this batch in the global synthetic stream (a rank's shard of a
-    sharded batch starts at rank * batch_per_gpu, fhe.rs_amd/shard.py)."""
+    sharded batch starts at rank * batch_per_gpu, fhe.rs_amd/shard.py).  moduli: explicit primes instead of
+    generate_moduli(sizes) (the reference's stock sets, tests/ref_params.py)."""
     import torch
-    q = obfv.generate_moduli(sizes, n)
+    q = list(moduli) if moduli is not None else obfv.generate_moduli(sizes, n)
     t = plaintext_modulus(n)
     seed = synth.seed_for_config(cfg)
     par = fhe.BfvParameters(n, t, moduli=q)

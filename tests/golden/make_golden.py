@@ -20,6 +20,12 @@ Files:
                           64 coefficients of every output row).
   scaler_constants.json   RnsScaler constant blocks (extender, down-scaler, decrypt scaler) of
                           configs C1-C3: SHA-256 + leading values.
+  default128_digest.json  The reference's stock sets (default_parameters_128, parameters.rs:218-251), n = 4096 / log q = 109
+                          and n = 8192 / log q = 218: SHA-256 of the NTT tables of the multiplication basis and of the
+                          C oracle's output ciphertext 0 for every hot-path Criterion ID of benches/bfv.rs (mul, square,
+                          mul_and_relin, relinearize, rotate_rows, rotate_columns, inner_sum, expand_4, mul_and_relin_2)
+                          and the multiply + modulus-switch chain down to one modulus (tests/ref_params.py; the emulated
+                          kernels are checked against the oracle on the way).
   decrypt_n1024.npz/json  N=1024, 2x62-bit: secret-key encryptions, relin key, product
                           ciphertext; the product decrypts to the plaintext product.
 """
@@ -177,6 +183,18 @@ def decrypt_example(n=1024, nmod=2, seed=77):
     return arrays, meta
 
 
+def default128_digest():
+    import ref_params
+    from helpers import load_engine
+    fhe = load_engine("emu")
+    out = {}
+    for n in (4096, 8192):
+        d = {}
+        ref_params.check_all(fhe, False, n, batch=1, digest=d)
+        out[str(n)] = dict(tables=ref_params.table_digest(n), log_q=ref_params.log_q(n), outputs=d)
+    return out
+
+
 def dump(name, obj):
     with open(os.path.join(HERE, name), "w") as f:
         json.dump(obj, f, separators=(",", ":"))
@@ -188,6 +206,7 @@ def main():
     dump("bfv_small_traces.json", {f"L{k}": small_trace(k) for k in (1, 2, 3, 6)})
     dump("scaler_constants.json", scaler_constants())
     dump("c2_digest.json", c2_digest())
+    dump("default128_digest.json", default128_digest())
     arrays, meta = decrypt_example()
     np.savez_compressed(os.path.join(HERE, "decrypt_n1024.npz"), **arrays)
     dump("decrypt_n1024.json", meta)

@@ -379,3 +379,33 @@ def test_key_switch_decomposition_rows(fhe, n, bits):
         with fhe.KeySwitchingKey.forced_mode(mode):
             cases.case_key_switch_decomposition_rows(fhe, False, n, bits)
 
+
+
+# ---- round 5: the reference's own stock parameter sets (BfvParameters::default_parameters_128, parameters.rs:218-251) ----
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192])
+def test_reference_default_parameter_sets(fhe, n):
+    """Every hot-path Criterion ID of crates/fhe/benches/bfv.rs:167-286 -- mul, square, mul_and_relin, relinearize,
+    rotate_rows, rotate_columns, inner_sum, expand_4, mul_and_relin_2 -- plus the leveled multiply + modulus-switch chain
+    down to one modulus, on the explicit primes of default_parameters_128 (27 / 54 / 36-37 / 43-44-bit rows with 62-bit
+    extension rows; K = 10 at n = 8192), one ciphertext per call, against the plain-C oracle."""
+    import ref_params
+    ref_params.check_all(fhe, False, n, batch=1)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_reference_default_parameter_sets_key_switch_modes(fhe, mode):
+    """n = 4096 / log q = 109 and n = 8192 / log q = 218 with each key-switch strategy forced."""
+    import ref_params
+    with fhe.KeySwitchingKey.forced_mode(mode):
+        ref_params.check_mul(fhe, False, 8192, relin=True, batch=1)
+        ref_params.check_relin_rotate(fhe, False, 4096, batch=2)
+        ref_params.check_chain(fhe, False, 4096, batch=1)
+
+
+def test_reference_default_parameter_set_n16384(fhe):
+    """n = 16384 / log q = 438 (nine 48/49-bit rows, K = 18): multiply + relinearise (+ the HPS second strategy) and the
+    key switches; the long rotation chains of this set run on the GPU suite."""
+    import ref_params
+    ref_params.check_mul(fhe, False, 16384, relin=True, batch=1)
+    ref_params.check_relin_rotate(fhe, False, 16384, batch=1)
+    ref_params.check_mul2(fhe, False, 16384, batch=1)

@@ -191,6 +191,23 @@ def test_engine_host_setup_reproduces_scaler_constants():
             assert s.number_common_moduli == g[key]["number_common_moduli"]
 
 
+def _default128(fhe, dev, n, batch):
+    """The reference's stock sets (tests/ref_params.py): the oracle's outputs -- to which the engine's are compared on
+    the way -- hash to the committed digests, whatever the batch size of the run."""
+    import ref_params
+    g = load("default128_digest.json")[str(n)]
+    assert g["tables"] == json.loads(json.dumps(ref_params.table_digest(n))) and g["log_q"] == ref_params.log_q(n)
+    assert g["tables"]["moduli"] == ref_params.DEFAULT_128[n]
+    d = {}
+    ref_params.check_all(fhe, dev, n, batch=batch, digest=d)
+    assert d == g["outputs"]
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_emulated_kernels_reproduce_default128_digest(n):
+    _default128(load_engine("emu"), False, n, 1)
+
+
 # ----------------------------------------------------------------------------- GPU ----
 @pytest.fixture(scope="module")
 def hip():
@@ -231,6 +248,19 @@ def test_hip_reproduces_c2_digest(hip):
         r = full_size.u64(out[i])
         assert sha(r) == e["output_sha256"], f"ciphertext {i}"
         assert np.array_equal(r[:, :, :64], u(e["head"])) and np.array_equal(r[:, :, -64:], u(e["tail"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_hip_reproduces_default128_digest(hip, n):
+    """n = 8192 / log q = 218 (and n = 4096 / log q = 109) of default_parameters_128: every hot-path Criterion ID, `_dev`
+    entry points, batch 3; also the engine's own tables of the multiplication basis against the committed hashes."""
+    g = load("default128_digest.json")[str(n)]
+    par = hip.BfvParameters(n, g["tables"]["plaintext"], moduli=g["tables"]["moduli"])
+    mctx = par.mul_context_at_level(0)
+    assert mctx.moduli == g["tables"]["mul_moduli"]
+    assert sha(mctx.table(0)) == g["tables"]["omegas"] and sha(mctx.table(2)) == g["tables"]["zetas_inv"]
+    _default128(hip, True, n, 3)
 
 
 @pytest.mark.gpu

@@ -762,3 +762,38 @@ def test_key_switch_auto_picks_strategy_by_launch_size(fhe):
     ks = kernels_of(ctx, L, cus // (4 * L) + 1)
     assert "key_switch_fused" in ks and "key_switch_fused_sub" not in ks
 
+
+
+# ---- round 5: the reference's own stock parameter sets (BfvParameters::default_parameters_128, parameters.rs:218-251;
+# what crates/fhe/benches/bfv.rs:27 iterates over) ----
+@pytest.mark.parametrize("dev", [False, True])
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384])
+def test_reference_default_parameter_sets(fhe, n, dev):
+    """Every hot-path Criterion ID of benches/bfv.rs:167-286 (mul, square, mul_and_relin, relinearize, rotate_rows,
+    rotate_columns, inner_sum, expand_4, mul_and_relin_2) and the leveled multiply + modulus-switch chain down to one
+    modulus, on the explicit primes of each stock set, host-pointer and `_dev` entry points, vs the plain-C oracle."""
+    import ref_params
+    ref_params.check_all(fhe, dev, n, batch=3)
+
+
+@pytest.mark.parametrize("mode", ["fused", "unfused"])
+@pytest.mark.parametrize("n", [4096, 8192, 16384])
+def test_reference_default_parameter_sets_key_switch_modes(fhe, n, mode):
+    import ref_params
+    with fhe.KeySwitchingKey.forced_mode(KS_MODES[mode]):
+        ref_params.check_mul(fhe, True, n, relin=True, batch=3)
+        ref_params.check_relin_rotate(fhe, True, n, batch=3)
+        ref_params.check_inner_sum(fhe, True, n)
+        ref_params.check_expand(fhe, True, n, 16)
+        ref_params.check_chain(fhe, True, n, batch=2)
+
+
+@pytest.mark.parametrize("n,batch", [(4096, 1024), (8192, 1024), (16384, 256)])
+def test_reference_default_parameter_sets_bench_batches(fhe, n, batch):
+    """The stock sets at the batches bench.py's `reference_default_128` entries time (device-generated inputs): sampled
+    ciphertexts of multiply + relinearise against the C oracle."""
+    import full_size
+    import ref_params
+    full_size.check_mul(fhe, n=n, sizes=None, moduli=ref_params.DEFAULT_128[n], batch=batch, relin=True, cfg=0x128,
+                        sample=(0, 1, batch // 2 - 1, batch // 2, batch - 1))
+    fhe.workspace_trim()

@@ -590,6 +590,97 @@ def next_rows(fhe, torch, par, timeit):
     return out
 
 
+def reference_default_128(fhe, torch, cpu_ms=None, sets=(4096, 8192, 16384)):
+    """The reference's OWN workload: every hot-path Criterion ID of crates/fhe/benches/bfv.rs:100-286 on the stock sets of
+    BfvParameters::default_parameters_128(20) (parameters.rs:218-251; explicit primes, log q = 109 / 218 / 438), keyed the
+    way Criterion names them ("<id>" under "n=<n>/log(q)=<logq>").  Per ID: (a) `single_ms` -- one ciphertext per call,
+    inputs resident, what `b.iter(|| ...)` times; (b) `batch_ops_per_s` at `batch` ciphertexts per call; and, when the CPU
+    leg ran, `cpu_port_single_thread_ms` -- the plain-C port of the reference algorithm for the same ID on this box's
+    host (one thread, as the reference runs) -- with the two ratios.  Parity of every ID on these sets:
+    tests/ref_params.py (GPU suite) and tests/golden/default128_digest.json."""
+    out = {}
+    for n in sets:
+        q = {4096: [0xffffee001, 0xffffc4001, 0x1ffffe0001],
+             8192: [0x7fffffd8001, 0x7fffffc8001, 0xfffffffc001, 0xffffff6c001, 0xfffffebc001],
+             16384: [0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001, 0x1ffffffee8001,
+                     0x1ffffffea0001, 0x1ffffffe88001, 0x1ffffffe48001]}[n]
+        logq = sum(int(m).bit_length() for m in q)
+        t = fhe.generate_prime(20, 2 * n, (1 << 20) - 1)
+        par = fhe.BfvParameters(n, t, moduli=q)
+        ctx = par.context_at_level(0)
+        L, K = ctx.nmoduli, par.mul_context_at_level(0).nmoduli
+        batch = 1024 if n <= 8192 else 256
+        seed = 0xF4E5D128 + n
+        ksk = key_for(fhe, ctx, seed)
+        rk = fhe.RelinearizationKey(ksk)
+        seq, i = [], 1
+        while i < n // 2:
+            seq.append(pow(3, i, 2 * n))
+            i *= 2
+        seq.append(2 * n - 1)
+        ek = fhe.EvaluationKey(n, [fhe.GaloisKey(ksk, e) for e in set(seq + [3] + [(n >> l) + 1 for l in range(4)])])
+        plain = fhe.Multiplicator.default(par, None, 0)
+        mul = fhe.Multiplicator.default(par, rk, 0)
+        nm = (logq + 61) // 62                                   # benches/bfv.rs:258-266
+        ext, upper = [], (1 << 64) - 1 >> 2
+        while len(ext) < nm:
+            upper = fhe.generate_prime(62, 2 * n, upper)
+            if upper not in q:
+                ext.append(upper)
+        Q, P = 1, 1
+        for m_ in q:
+            Q *= m_
+        for m_ in ext:
+            P *= m_
+        mctx = fhe.Context(q + ext, n)
+        mul2 = fhe.Multiplicator(fhe.Scaler(ctx, mctx, 1, 1), fhe.Scaler(ctx, mctx, P, Q), fhe.Scaler(mctx, ctx, t, P), rk)
+        ids = {}
+        for b, key, reps in ((1, "single_ms", 20), (batch, "batch", 3)):
+            timeit = make_timeit(torch, reps)
+            a, bb = ctx.synth_uniform(seed, 0, 0, 2, b), ctx.synth_uniform(seed, 0, 2, 2, b)
+            c3 = plain.multiply(a, bb)
+            be = min(b, 64)                                     # expansions write 2^i ciphertexts per input
+            ae = a[:be].contiguous()
+            todo = [("add_ct", lambda: ctx.add(a, bb)), ("sub_ct", lambda: ctx.sub(a, bb)), ("neg", lambda: ctx.neg(a)),
+                    ("relinearize", lambda: rk.relinearizes(c3)), ("rotate_rows", lambda: ek.rotates_rows(a)),
+                    ("rotate_columns", lambda: ek.rotates_columns_by(a, 1)), ("inner_sum", lambda: ek.computes_inner_sum(a))]
+            todo += [("expand_%d" % lv, (lambda lv=lv: ek.expands(ae, 1 << lv))) for lv in range(1, 5)]
+            todo += [("mul", lambda: plain.multiply(a, bb)), ("square", lambda: plain.multiply(a, a)),
+                     ("mul_then_relinearize", lambda: rk.relinearizes(plain.multiply(a, bb))),
+                     ("mul_and_relin", lambda: mul.multiply(a, bb)), ("mul_and_relin_2", lambda: mul2.multiply(a, bb))]
+            for name, fn in todo:
+                ms = timeit(fn)
+                d = ids.setdefault(name, {})
+                if b == 1:
+                    d["single_ms"] = round(ms, 4)
+                else:
+                    nb = be if name.startswith("expand_") else b
+                    d["batch"] = nb
+                    d["batch_ops_per_s"] = round(nb / ms * 1e3, 1)
+            # (add / sub / neg are the *Assign forms here: `a` changes, which the timings do not care about)
+            del a, bb, c3, ae
+            fhe.workspace_trim()
+            torch.cuda.empty_cache()
+        if cpu_ms and n in cpu_ms:
+            for name, d in ids.items():
+                c = cpu_ms[n].get(name)
+                if c:
+                    d["cpu_port_single_thread_ms"] = c
+                    d["single_call_speedup_vs_cpu_port_thread"] = round(c / d["single_ms"], 1)
+                    d["batch_speedup_vs_cpu_port_thread"] = round(d["batch_ops_per_s"] * c / 1e3, 1)
+        stage = stage_model_rows(L, K, L) * 8 * n
+        ids["mul_and_relin"]["stage_model_bytes_per_op"] = stage
+        ids["mul_and_relin"]["frac"] = round(stage * ids["mul_and_relin"]["batch_ops_per_s"] / 1e9 / HBM_PEAK_GBS, 4)
+        out[f"n={n}/log(q)={logq}"] = dict(moduli=len(q), mul_basis_rows=K, plaintext=t, ids=ids)
+        del par, ctx, ksk, rk, ek, plain, mul, mul2, mctx
+        fhe.workspace_trim()
+        torch.cuda.empty_cache()
+    out["note"] = ("Criterion group `bfv` of crates/fhe/benches/bfv.rs on default_parameters_128(20); single_ms = one ciphertext per "
+                   "call on the caller's stream with inputs resident (what b.iter times), batch_ops_per_s = the same call on a "
+                   "batch; cpu_port_single_thread_ms = oracle/c/fhe_oracle.c (kind: port), one host thread")
+    return out
+
+
 def c5_chain(fhe, torch, batch=16):
     """BASELINE.json configs[4] as written: the DEEP chain -- multiply + relinearise + modulus switch at every level
     0 ... 14 of N = 32768, 16 x 60-bit (L_l = 16 ... 2), each level's output feeding the next (a squaring chain on
@@ -741,10 +832,15 @@ def main():
     torch.cuda.synchronize()
     # The CPU-baseline leg runs FIRST (it used to be 9 of the run's 14.6 s at the END, so a sampler that
     # looks at the GPU every few seconds saw an idle device); its parity spot check happens after the timed region.
-    cpu_leg = None
+    cpu_leg, cpu_default128 = None, None
     if world == 1 and not args.no_cpu:
         os.sched_setaffinity(0, all_cpus)   # the CPU baseline gets every host core, not just the GPU's NUMA node
         cpu_leg = cpu_baseline(n, MODULI_SIZES, t, SEED, args.cpu_seconds)
+        if not args.no_extras:
+            # the reference's own Criterion IDs on its stock parameter sets, one host thread (part of the CPU leg: the
+            # only other place this file touches oracle/)
+            import ref_params
+            cpu_default128 = {nn: ref_params.cpu_port_ms(nn, 0.1) for nn in (4096, 8192, 16384)}
         if pin.get("pinned"):
             pin_to_gpu_numa_node(torch, dev)
     for _ in range(args.warmup):
@@ -955,6 +1051,9 @@ def main():
         fhe.workspace_trim()
         torch.cuda.empty_cache()
         result["other_configs"]["C5_chain_15_levels"] = c5_chain(fhe, torch)
+        fhe.workspace_trim()
+        torch.cuda.empty_cache()
+        result["other_configs"]["reference_default_128"] = reference_default_128(fhe, torch, cpu_default128)
 
     if dist is not None:
         dist.destroy_process_group()

@@ -316,3 +316,81 @@ def table_digest(n):
     ops = level(n)["mul"].ops
     return dict(moduli=DEFAULT_128[n], mul_moduli=level(n)["mul"].moduli, plaintext=plaintext_modulus(n), psi=[op.psi for op in ops],
                 omegas=sha([op.omegas for op in ops]), zetas_inv=sha([op.zetas_inv for op in ops]))
+
+
+def cpu_port_ms(n, min_s=0.15):
+    """Single-thread time of the plain-C port (oracle/c/fhe_oracle.c: the reference's algorithms and pass structure) for
+    the hot-path Criterion IDs of benches/bfv.rs on one stock set, one ciphertext per call as Criterion times them.
+    bench.py's cpu_baseline leg prints these beside the GPU's numbers.  ms per call."""
+    import time
+    o = level(n)
+    cb = o["cb"]
+    seed = SEED + n
+    out = {}
+
+    def timed(fn):
+        fn()
+        reps, t0 = 0, time.perf_counter()
+        while reps < 2 or time.perf_counter() - t0 < min_s:
+            fn()
+            reps += 1
+        return round((time.perf_counter() - t0) / reps * 1e3, 4)
+
+    a, b = synth_ct(cb, seed, 0, 0, 2), synth_ct(cb, seed, 0, 2, 2)
+    out["add_ct"] = timed(lambda: [cb.poly_add(a[p], b[p]) for p in range(2)])
+    out["sub_ct"] = timed(lambda: [cb.poly_sub(a[p], b[p]) for p in range(2)])
+    out["neg"] = timed(lambda: [cb.poly_neg(a[p]) for p in range(2)])
+    plain = coracle.CMul(o["cb"], o["cm"], o["cel"], o["cel"], o["cdn"], None, False)
+    out["mul"] = timed(lambda: plain.multiply(a, b))
+    out["square"] = timed(lambda: plain.multiply(a, a))
+    if cb.L == 1:
+        return out
+    c0, c1, ck = synth_key(cb, seed, 0)
+    c3 = plain.multiply(a, b)
+
+    def relin(c):
+        k0, k1 = ck.key_switch(cb.poly_ntt_backward(c[2]))
+        return np.stack([cb.poly_add(c[0], k0), cb.poly_add(c[1], k1)])
+    out["relinearize"] = timed(lambda: relin(c3))
+    out["rotate_rows"] = timed(lambda: ck.galois_relinearize(2 * n - 1, a))
+    out["rotate_columns"] = timed(lambda: ck.galois_relinearize(3, a))
+    seq, i = [], 1
+    while i < n // 2:
+        seq.append(pow(3, i, 2 * n))
+        i *= 2
+    seq.append(2 * n - 1)
+
+    def inner():
+        cur = a
+        for e in seq:
+            tmp = ck.galois_relinearize(e, cur)
+            cur = np.stack([cb.poly_add(cur[0], tmp[0]), cb.poly_add(cur[1], tmp[1])])
+        return cur
+    out["inner_sum"] = timed(inner)
+    monos = []
+    for l in range(4):
+        mono = np.zeros((cb.L, n), dtype=np.uint64)
+        mono[:, n - (1 << l)] = np.array(cb.ctx.moduli, dtype=np.uint64) - np.uint64(1)
+        monos.append(cb.poly_ntt_forward(mono))
+
+    def expand(lv):
+        size = 1 << lv
+        res = [None] * size
+        res[0] = a
+        for l in range(lv):
+            e = (n >> l) + 1
+            step = 1 << l
+            for i in range(step):
+                sub = ck.galois_relinearize(e, res[i])
+                res[step | i] = np.stack([cb.poly_mul(cb.poly_sub(res[i][p], sub[p]), monos[l]) for p in range(2)])
+                res[i] = np.stack([cb.poly_add(res[i][p], sub[p]) for p in range(2)])
+        return res
+    for lv in range(1, 5):
+        out["expand_%d" % lv] = timed(lambda: expand(lv))
+    out["mul_then_relinearize"] = timed(lambda: relin(plain.multiply(a, b)))
+    cm = coracle.CMul(o["cb"], o["cm"], o["cel"], o["cel"], o["cdn"], ck, False)
+    out["mul_and_relin"] = timed(lambda: cm.multiply(a, b))
+    s = second_strategy(n)
+    cm2 = coracle.CMul(s["cb"], s["cm"], s["cel"], s["cer"], s["cdn"], ck, False)
+    out["mul_and_relin_2"] = timed(lambda: cm2.multiply(a, b))
+    return out

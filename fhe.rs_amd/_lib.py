@@ -150,6 +150,7 @@ SIGNATURES = {
     "fhe_workspace_set_limit": (i32, [sz, sz]),
     "fhe_workspace_get_limit": (i32, [szp, szp]),
     "fhe_workspace_stats": (i32, [szp, szp, szp, szp, szp]),
+    "fhe_workspace_pool_stats": (i32, [i32, szp, szp, szp, szp]),
     "fhe_prof_enable": (None, [i32]),
     "fhe_prof_reset": (None, []),
     "fhe_prof_count": (sz, []),

@@ -86,6 +86,7 @@ class DeviceArray:
         self.device, self.itemsize = device, itemsize
         self._base = _base
         self._astream = None
+        self._other_stream_use = False    # (set by _note_use: some call used this array on another stream)
         if _ptr is None:
             h = C.c_void_p()
             st = getattr(_tls, "stream", None)
@@ -159,13 +160,21 @@ class DeviceArray:
         check(_lib.lib().fhe_buf_download(out.ctypes.data_as(C.c_void_p), C.c_void_p(self._p), self.nbytes, _stream()))
         return out
 
+    def _note_use(self):
+        """Called for every engine call that takes this array: remembers whether any of them ran on a stream other
+        than the allocating one (an array used inside another `with Stream` block and dropped after
+        returning to its own stream must not be freed in the allocating stream's order)."""
+        root = self._base or self
+        if root._astream is not None and getattr(_tls, "stream", None) is not root._astream:
+            root._other_stream_use = True
+
     def _release(self, L):
         st = getattr(self, "_astream", None)
-        # stream-ordered free only while the allocating stream is still the current one: every use of the array was
-        # then enqueued on it.  Dropped outside its `with Stream` block (where calls go to another stream) the array
-        # takes the synchronous free, which waits for the device (hipFreeAsync on the allocating stream
-        # could hand the block back while another stream still read it).
-        if st is not None and st.handle is not None and getattr(_tls, "stream", None) is st:
+        # stream-ordered free only when EVERY use of the array was enqueued on the allocating stream and that stream is
+        # still the current one.  Otherwise the synchronous free, which waits for the device (ADVICE r03 / r04:
+        # hipFreeAsync on the allocating stream could hand the block back while another stream still read it).
+        if (st is not None and st.handle is not None and getattr(_tls, "stream", None) is st
+                and not getattr(self, "_other_stream_use", False)):
             return L.fhe_buf_free_async(C.c_void_p(self._p), st.handle)
         return L.fhe_buf_free(C.c_void_p(self._p))                        # (hipFree: waits for the device)
 
@@ -206,12 +215,16 @@ def _ptr(a):
 def _dptr(t):
     if not t.is_cuda or not t.is_contiguous() or t.element_size() != 8:
         raise ValueError("device buffers must be contiguous 8-byte CUDA tensors")
+    if isinstance(t, DeviceArray):
+        t._note_use()
     return C.c_void_p(t.data_ptr())
 
 
 def _dptr8(t):
     if not t.is_cuda or not t.is_contiguous() or t.element_size() != 1:
         raise ValueError("wire buffers must be contiguous uint8 CUDA tensors")
+    if isinstance(t, DeviceArray):
+        t._note_use()
     return C.c_void_p(t.data_ptr())
 
 
@@ -623,25 +636,25 @@ class KeySwitchingKey:
                                    _ptr(a1), _ptr(s1) if s1 is not None else None, log_base, C.byref(h)))
         self.ndigits = nd
         self._h = h
-        if KeySwitchingKey.default_mode != (0, 0):     # (tests and A/B tools: every key made inside `forced_mode`)
-            self.set_mode(*KeySwitchingKey.default_mode)
-
-    default_mode = (0, 0)
+        forced = getattr(_tls, "ks_forced_mode", (0, 0))   # (tests and A/B tools: keys made inside `forced_mode`)
+        if forced != (0, 0):
+            self.set_mode(*forced)
 
     @classmethod
     def forced_mode(cls, mode, w_budget=0):
-        """Context manager: keys created inside take `mode` (the parity suites run their key-switch cases once per
-        evaluation strategy this way; the library itself has no process-wide switch)."""
+        """Context manager for TEST code: keys created inside it BY THIS THREAD take `mode` (the parity suites run their
+        key-switch cases once per evaluation strategy this way).  Thread-local, restored on exit; the library itself
+        has no process-wide switch, and product code sets the mode per key (`set_mode`)."""
         import contextlib
 
         @contextlib.contextmanager
         def cm():
-            old = cls.default_mode
-            cls.default_mode = (int(mode), int(w_budget))
+            old = getattr(_tls, "ks_forced_mode", (0, 0))
+            _tls.ks_forced_mode = (int(mode), int(w_budget))
             try:
                 yield
             finally:
-                cls.default_mode = old
+                _tls.ks_forced_mode = old
         return cm()
 
     def __del__(self):
@@ -1087,6 +1100,14 @@ def workspace_stats():
     h, u, b, o, a = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
     check(_lib.lib().fhe_workspace_stats(C.byref(h), C.byref(u), C.byref(b), C.byref(o), C.byref(a)))
     return dict(held_bytes=h.value, in_use_bytes=u.value, blocks=b.value, owners=o.value, internal_streams=a.value)
+
+
+def workspace_pool_stats(device=0):
+    """What the driver says the library's two private pools on `device` hold (fhe_workspace_pool_stats)."""
+    v = [C.c_size_t() for _ in range(4)]
+    check(_lib.lib().fhe_workspace_pool_stats(int(device), *[C.byref(x) for x in v]))
+    return dict(scratch_reserved_bytes=v[0].value, scratch_used_bytes=v[1].value,
+                buffers_reserved_bytes=v[2].value, buffers_used_bytes=v[3].value)
 
 
 UBENCH_KINDS = {"mad_u64_u32": 0, "mul_lo_u32": 1, "mul_hi_u32": 2, "shoup_lazy": 3, "fwd_butterfly": 4,

@@ -186,19 +186,73 @@ struct DevBuf {
     }
 };
 
-// One PRIVATE stream-ordered memory pool per device (hipMemPoolCreate), told to keep what is freed into it: the
-// engine's scratch blocks and the ABI's fhe_buf_alloc_async come from it.  (Round 3 raised the release threshold of the
-// device's DEFAULT pool instead, which changed the behaviour of every other hipMallocAsync user in the process.)
+// Two PRIVATE stream-ordered memory pools per device (hipMemPoolCreate): SCRATCH serves the engine's workspace blocks,
+// BUFFERS the ABI's fhe_buf_alloc_async.  (Round 3 raised the release threshold of the device's DEFAULT pool instead, which
+// changed the behaviour of every other hipMallocAsync user in the process.)
+// Round 5: the scratch pool's release threshold IS the workspace's total limit -- what the engine evicts
+// goes back to the driver (hipMemPoolTrimTo right after an eviction, and the threshold at the next synchronisation for
+// blocks whose stream-ordered free had not retired yet), so fhe_workspace_set_limit bounds the device memory the process
+// holds for scratch, not only the bookkeeping.  The buffers pool keeps what is freed into it (a host that allocates and
+// drops a result per call must not pay the driver for it each time) until fhe_workspace_trim.
 class DevPools {
 public:
+    enum Kind : int { SCRATCH = 0, BUFFERS = 1 };
     static DevPools &get() {
         static DevPools p;
         return p;
     }
-    hipMemPool_t pool(int device) {
+    hipMemPool_t pool(int device, Kind kind) {
         std::lock_guard<std::mutex> g(mu);
-        if ((size_t)device >= pools.size()) pools.resize((size_t)device + 1, nullptr);
-        if (!pools[(size_t)device]) {
+        return pool_locked(device, kind);
+    }
+    void *alloc(int device, size_t bytes, hipStream_t s, Kind kind) {
+        void *p = nullptr;
+        FHE_HIP_CHECK(hipMallocFromPoolAsync(&p, bytes ? bytes : 8, pool(device, kind), s));
+        return p;
+    }
+    // bytes of reserved scratch the pools may keep once it is idle (0 = everything): Workspace's total limit
+    void set_scratch_threshold(int device, size_t bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        if ((size_t)device >= thresholds.size()) thresholds.resize((size_t)device + 1, ~0ull);
+        const uint64_t keep = bytes ? (uint64_t)bytes : ~0ull;
+        if (thresholds[(size_t)device] == keep && (size_t)(2 * device) < pools.size() && pools[(size_t)(2 * device)]) return;
+        thresholds[(size_t)device] = keep;
+        hipMemPool_t mp = pool_locked(device, SCRATCH);
+        uint64_t v = keep;
+        (void)hipMemPoolSetAttribute(mp, hipMemPoolAttrReleaseThreshold, &v);
+    }
+    // hands idle scratch beyond `keep` bytes back to the driver now
+    void trim_scratch_to(int device, size_t keep) {
+        std::lock_guard<std::mutex> g(mu);
+        const size_t i = (size_t)(2 * device + SCRATCH);
+        if (i < pools.size() && pools[i]) (void)hipMemPoolTrimTo(pools[i], keep);
+    }
+    // hands the pools' idle memory back to the driver
+    void trim() {
+        std::lock_guard<std::mutex> g(mu);
+        for (hipMemPool_t mp : pools)
+            if (mp) (void)hipMemPoolTrimTo(mp, 0);
+    }
+    // what the driver says the pools hold: reserved (backed by device memory) and used (handed out) bytes
+    void stats(int device, size_t out[4]) {
+        std::lock_guard<std::mutex> g(mu);
+        for (int k = 0; k < 2; k++) {
+            uint64_t r = 0, u = 0;
+            const size_t i = (size_t)(2 * device + k);
+            if (device >= 0 && i < pools.size() && pools[i]) {
+                (void)hipMemPoolGetAttribute(pools[i], hipMemPoolAttrReservedMemCurrent, &r);
+                (void)hipMemPoolGetAttribute(pools[i], hipMemPoolAttrUsedMemCurrent, &u);
+            }
+            out[2 * k] = (size_t)r;
+            out[2 * k + 1] = (size_t)u;
+        }
+    }
+
+private:
+    hipMemPool_t pool_locked(int device, Kind kind) {
+        const size_t i = (size_t)(2 * device + (int)kind);
+        if (i >= pools.size()) pools.resize(i + 1, nullptr);
+        if (!pools[i]) {
             hipMemPoolProps props;
             std::memset(&props, 0, sizeof(props));
             props.allocType = hipMemAllocationTypePinned;
@@ -207,26 +261,15 @@ public:
             hipMemPool_t mp = nullptr;
             FHE_HIP_CHECK(hipMemPoolCreate(&mp, &props));
             uint64_t keep = ~0ull;
+            if (kind == SCRATCH && (size_t)device < thresholds.size()) keep = thresholds[(size_t)device];
             FHE_HIP_CHECK(hipMemPoolSetAttribute(mp, hipMemPoolAttrReleaseThreshold, &keep));
-            pools[(size_t)device] = mp;
+            pools[i] = mp;
         }
-        return pools[(size_t)device];
+        return pools[i];
     }
-    void *alloc(int device, size_t bytes, hipStream_t s) {
-        void *p = nullptr;
-        FHE_HIP_CHECK(hipMallocFromPoolAsync(&p, bytes ? bytes : 8, pool(device), s));
-        return p;
-    }
-    // hands the pools' idle memory back to the driver
-    void trim() {
-        std::lock_guard<std::mutex> g(mu);
-        for (hipMemPool_t mp : pools)
-            if (mp) (void)hipMemPoolTrimTo(mp, 0);
-    }
-
-private:
     std::mutex mu;
-    std::vector<hipMemPool_t> pools;
+    std::vector<hipMemPool_t> pools;        // [2 * device + kind]
+    std::vector<uint64_t> thresholds;       // scratch release threshold per device
 };
 
 // Scratch blocks, reused in stream order: a block released by stream S is handed out again only to work enqueued on
@@ -242,6 +285,11 @@ private:
 //    dereferences a destroyed handle (segmentation fault, tools/probe/hip_pool_probe.cpp) -- and hipFree is correct
 //    either way.  That is also what bounds such a host: dead streams' blocks are simply the least recently used.
 //    Default: no per-stream bound, total = a quarter of the device's memory (at least 8 GiB); 0 = unbounded.
+//    `total` is PER DEVICE (round 5, ADVICE r04: it used to be one sum over all devices with a default taken from
+//    whichever device was current first, so an in-process multi-GPU host evicted other devices' blocks -- hipSetDevice +
+//    hipFree under the global mutex -- in steady state): each device's blocks are counted and evicted against its own
+//    bound, and the default is a quarter of THAT device's memory.  What is evicted also leaves the scratch pool
+//    (DevPools above): the bound holds for the device memory the process keeps, not just for this table.
 //  * A recycled handle value that inherits an old block is harmless: the block was idle, and whatever ran on the old
 //    stream is ordered before the new owner's work by the device itself (same queue slot) or long finished.
 class Workspace {
@@ -292,12 +340,16 @@ public:
         std::lock_guard<std::mutex> lk(mu);
         limit_stream = per_stream;
         limit_total = total;
+        thresholds_set.clear();   // (every device's scratch pool learns the new bound at its next use)
+        for (auto &b : blocks) sync_threshold_locked(b.device);
         enforce_limits_locked(nullptr, -1, 0);
     }
     void get_limits(size_t *per_stream, size_t *total) {
         std::lock_guard<std::mutex> lk(mu);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
         if (per_stream) *per_stream = limit_stream;
-        if (total) *total = total_limit_locked();
+        if (total) *total = total_limit_locked(dev);
     }
     // bytes held (idle + in use), bytes in use, number of blocks, number of distinct (device, stream) owners
     void stats(size_t *held, size_t *in_use, size_t *nblocks, size_t *nstreams) {
@@ -334,16 +386,26 @@ private:
     std::mutex mu;
     uint64_t tick = 0;
     size_t limit_stream = 0, limit_total = LIMIT_DEFAULT;
-    size_t default_total = 0;   // resolved on first use
+    std::vector<size_t> default_total;   // per device, resolved on first use
+    std::vector<char> thresholds_set;    // per device: the scratch pool has been told the current bound
 
-    size_t total_limit_locked() {
+    size_t total_limit_locked(int dev) {
         if (limit_total != LIMIT_DEFAULT) return limit_total;
-        if (!default_total) {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b) total_b = (size_t)32 << 30;
-            default_total = std::max<size_t>((size_t)8 << 30, total_b / 4);
+        if (dev < 0) dev = 0;
+        if ((size_t)dev >= default_total.size()) default_total.resize((size_t)dev + 1, 0);
+        if (!default_total[(size_t)dev]) {
+            size_t total_b = 0;
+            if (hipDeviceTotalMem(&total_b, dev) != hipSuccess || !total_b) total_b = (size_t)32 << 30;
+            default_total[(size_t)dev] = std::max<size_t>((size_t)8 << 30, total_b / 4);
         }
-        return default_total;
+        return default_total[(size_t)dev];
+    }
+    void sync_threshold_locked(int dev) {
+        if (dev < 0) return;
+        if ((size_t)dev >= thresholds_set.size()) thresholds_set.resize((size_t)dev + 1, 0);
+        if (thresholds_set[(size_t)dev]) return;
+        DevPools::get().set_scratch_threshold(dev, total_limit_locked(dev));
+        thresholds_set[(size_t)dev] = 1;
     }
     void compact_locked() {
         blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const Block &b) { return !b.ptr; }), blocks.end());
@@ -370,15 +432,25 @@ private:
     // (`dev`, `s`) are about to be added (acquire) and count against both.  Only blocks of (`dev`, `s`) -- the stream
     // the current call runs on -- are returned in stream order; every other owner's go through hipFree.
     void enforce_limits_locked(hipStream_t s, int dev, size_t extra) {
-        const size_t lim_total = total_limit_locked();
-        if (!limit_stream && !lim_total) return;
+        if (!limit_stream && limit_total == 0) return;
+        std::vector<int> trimmed;
         for (;;) {
-            size_t total = extra;
-            for (auto &b : blocks) total += b.bytes;
+            // per device: the device whose retained bytes exceed its bound gives up its least recently used idle block
             Block *victim = nullptr;
-            if (lim_total && total > lim_total) {
+            std::vector<int> devs;
+            for (auto &b : blocks)
+                if (std::find(devs.begin(), devs.end(), b.device) == devs.end()) devs.push_back(b.device);
+            if (dev >= 0 && std::find(devs.begin(), devs.end(), dev) == devs.end()) devs.push_back(dev);
+            for (int d : devs) {
+                const size_t lim_total = total_limit_locked(d);
+                if (!lim_total) continue;
+                size_t total = d == dev ? extra : 0;
                 for (auto &b : blocks)
-                    if (!b.in_use && b.ptr && (!victim || b.last_use < victim->last_use)) victim = &b;
+                    if (b.device == d) total += b.bytes;
+                if (total <= lim_total) continue;
+                for (auto &b : blocks)
+                    if (b.device == d && !b.in_use && b.ptr && (!victim || b.last_use < victim->last_use)) victim = &b;
+                if (victim) break;
             }
             if (!victim && limit_stream) {
                 // any (device, stream) owner over its own limit gives up its oldest idle block
@@ -390,9 +462,19 @@ private:
                     if (own > limit_stream && (!victim || b.last_use < victim->last_use)) victim = &b;
                 }
             }
-            if (!victim) return;
+            if (!victim) break;
+            const int vdev = victim->device;
             free_block_locked(*victim, dev >= 0 && victim->device == dev && victim->stream == s);
             compact_locked();
+            if (std::find(trimmed.begin(), trimmed.end(), vdev) == trimmed.end()) trimmed.push_back(vdev);
+        }
+        // what was evicted leaves the scratch pool too (blocks whose stream-ordered free has not retired yet follow at the
+        // next synchronisation: the pool's release threshold is this bound)
+        for (int d : trimmed) {
+            size_t keep = d == dev ? extra : 0;
+            for (auto &b : blocks)
+                if (b.device == d) keep += b.bytes;
+            DevPools::get().trim_scratch_to(d, keep);
         }
     }
 };
@@ -805,7 +887,7 @@ inline void wire_serialize(const Ctx &c, const u64 *polys, uint8_t *bytes, size_
     const u64 wb = wire_poly_bytes(c);
     // rows of >= 128 coefficients (and a 16-byte aligned destination: every row then starts on a 16-byte boundary)
     // take the word-granular kernel; its grid covers the widest row (62 bits)
-    const bool words = c.n >= 128 && ((uintptr_t)bytes & 15) == 0;
+    const bool words = c.n >= 128 && ((uintptr_t)bytes & 15) == 0 && ((uintptr_t)polys & 15) == 0;
     for (size_t p0 = 0; p0 < npolys; p0 += 32768) {  // gridDim.z <= 65535
         const size_t np = std::min<size_t>(32768, npolys - p0);
         if (words)
@@ -822,7 +904,7 @@ inline void wire_deserialize(const Ctx &c, const uint8_t *bytes, u64 *polys, siz
     if (!npolys) return;
     const unsigned groups = (unsigned)(c.n / 8), block = groups < 256 ? 64 : 256;
     const u64 wb = wire_poly_bytes(c), pe = (u64)c.L * c.n;
-    const bool words = c.n >= 128 && ((uintptr_t)bytes & 15) == 0;   // (see wire_serialize)
+    const bool words = c.n >= 128 && ((uintptr_t)bytes & 15) == 0 && ((uintptr_t)polys & 15) == 0;   // (see wire_serialize)
     for (size_t p0 = 0; p0 < npolys; p0 += 32768) {
         const size_t np = std::min<size_t>(32768, npolys - p0);
         if (words)
@@ -1666,6 +1748,9 @@ inline void mul_plain(const Ctx &c, size_t nparts, const u64 *ct, const u64 *pt,
     if (!batch || !nparts) return;
     const u64 pl = (u64)c.L * c.n;
     require(batch <= 65535 && nparts <= 65535, E_ARG, "mul_plain: batch / parts exceed the grid limits");
+    // (the kernel moves 16 bytes per lane: every device allocator hands out 256-byte aligned blocks and rows are whole
+    // multiples of 64 bytes, so only a pointer into the middle of a coefficient pair can fail this)
+    require((((uintptr_t)ct | (uintptr_t)pt | (uintptr_t)out) & 15) == 0, E_ARG, "mul_plain: buffers must be 16-byte aligned");
     FHE_LAUNCH("mul_plain", k::mul_plain_kernel, dim3(blocks_for(pl / 2, EW_THREADS), 1, (unsigned)batch),
                dim3(EW_THREADS), 0, s, ct, pt, pt_shared ? (u64)0 : pl, out, c.dmods(), (uint32_t)nparts,
                (uint32_t)c.logn, pl);
@@ -1826,10 +1911,19 @@ public:
         hipStream_t out;
         {
             std::lock_guard<std::mutex> lk(mu);
-            Entry &a = reg[{device, user}];
-            if (!a.aux) FHE_HIP_CHECK(hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking));
+            const std::pair<int, hipStream_t> key{device, user};
+            Entry &a = reg[key];
+            if (!a.aux) {
+                hipStream_t made = nullptr;
+                const hipError_t err = hipStreamCreateWithFlags(&made, hipStreamNonBlocking);
+                if (err != hipSuccess) {   // (no half-made entry stays behind: a later eviction would retire a NULL stream)
+                    reg.erase(key);
+                    throw StatusError(E_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(err));
+                }
+                a.aux = made;
+            }
             a.tag_key = tag_key;
-            a.users++;
+            if (!tag_key) a.users++;      // (tag keys are never evicted: their holders do not report back)
             a.last_use = ++tick;
             out = a.aux;
             while (reg.size() > CAP) {
@@ -1904,6 +1998,7 @@ private:
     };
     static void retire(const std::vector<hipStream_t> &victims) {
         for (hipStream_t aux : victims) {
+            if (!aux) continue;
             (void)hipStreamSynchronize(aux);
             Workspace::get().drop_internal_stream(aux);   // (its work is over: plain frees)
             (void)hipStreamDestroy(aux);
@@ -1932,7 +2027,8 @@ inline void *Workspace::acquire(size_t bytes, hipStream_t s) {
         compact_locked();
         enforce_limits_locked(s, dev, bytes);
         Block nb;
-        nb.ptr = DevPools::get().alloc(dev, bytes, s);
+        sync_threshold_locked(dev);
+        nb.ptr = DevPools::get().alloc(dev, bytes, s, DevPools::SCRATCH);
         nb.bytes = bytes ? bytes : 8;
         nb.stream = s;
         nb.device = dev;
@@ -2090,11 +2186,11 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
         join.join = ax.take_event();
         join.device = b.device;
         hipStream_t aux = ax.stream_for(b.device, s0);
+        join.aux = aux;   // (from here on ~Join reports the stream back, whatever throws below)
         if (dual) lanes[1] = aux;
         if (split_ext) ext_done = ax.take_event();
         FHE_HIP_CHECK(hipEventRecord(join.fork, s0));
         FHE_HIP_CHECK(hipStreamWaitEvent(aux, join.fork, 0));
-        join.aux = aux;
     }
     ChunkWs ws0(chunk, PK, PL, pre_bytes, lanes[0]);
     std::unique_ptr<ChunkWs> ws1;

@@ -288,7 +288,7 @@ fhe_status fhe_buf_alloc_async(int device, size_t bytes, void *stream, void **ou
         FHE_HIP_CHECK(hipGetDeviceCount(&ndev));
         require(device >= 0 && device < ndev, E_NO_DEVICE, "no such HIP device");
         FHE_HIP_CHECK(hipSetDevice(device));
-        *out = DevPools::get().alloc(device, std::max<size_t>(bytes, 1), as_stream(stream));
+        *out = DevPools::get().alloc(device, std::max<size_t>(bytes, 1), as_stream(stream), DevPools::BUFFERS);
     });
 }
 fhe_status fhe_buf_free_async(void *buf, void *stream) {
@@ -1725,6 +1725,17 @@ fhe_status fhe_workspace_stats(size_t *held_bytes, size_t *in_use_bytes, size_t 
     return guard([&] {
         Workspace::get().stats(held_bytes, in_use_bytes, blocks, owners);
         if (internal_streams) *internal_streams = AuxStreams::get().count();
+    });
+}
+fhe_status fhe_workspace_pool_stats(int device, size_t *scratch_reserved_bytes, size_t *scratch_used_bytes,
+                                    size_t *buffers_reserved_bytes, size_t *buffers_used_bytes) {
+    return guard([&] {
+        size_t v[4] = {0, 0, 0, 0};
+        DevPools::get().stats(device, v);
+        if (scratch_reserved_bytes) *scratch_reserved_bytes = v[0];
+        if (scratch_used_bytes) *scratch_used_bytes = v[1];
+        if (buffers_reserved_bytes) *buffers_reserved_bytes = v[2];
+        if (buffers_used_bytes) *buffers_used_bytes = v[3];
     });
 }
 fhe_status fhe_ubench_int(int device, int which, double min_seconds, double *ops_per_s) {

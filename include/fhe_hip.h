@@ -473,15 +473,22 @@ size_t fhe_workspace_trim(void);
  * it -- scratch blocks, an internal second stream -- stays until it is the least recently used: blocks under the
  * `total_bytes` bound, internal streams beyond 32 live user streams.  Such a host sets `total_bytes` to a few times
  * one stream's footprint (tests: 1,000 short-lived streams stay within 2x of one), or calls fhe_workspace_trim.
- * Scratch blocks come from the library's private stream-ordered pool; a stream's own blocks return to it in stream
- * order (growing does not synchronise the device), other streams' blocks are evicted with hipFree (which waits).
+ * Scratch blocks come from the library's private stream-ordered SCRATCH pool; a stream's own blocks return to it in
+ * stream order (growing does not synchronise the device), other streams' blocks are evicted with hipFree (which waits).
+ * `total_bytes` is PER DEVICE (the default a quarter of that device's memory), and it bounds DEVICE MEMORY, not only the
+ * engine's bookkeeping: the scratch pool's release threshold is the bound and evictions trim the pool, so another
+ * allocator in the process (torch, the host's own hipMalloc) gets the memory back.  fhe_buf_alloc_async has its own pool
+ * (BUFFERS), which keeps what is freed into it until fhe_workspace_trim.
  * fhe_workspace_stats: bytes held (idle + in use), bytes in use, blocks, distinct (device, stream) owners, internal
- * second streams alive. */
+ * second streams alive.  fhe_workspace_pool_stats: what the DRIVER says the two pools of `device` hold -- reserved
+ * (backed by device memory) and used (handed out) bytes of each (hipMemPoolAttrReservedMemCurrent / UsedMemCurrent). */
 #define FHE_WORKSPACE_DEFAULT ((size_t)-1)
 fhe_status fhe_workspace_set_limit(size_t per_stream_bytes, size_t total_bytes);
 fhe_status fhe_workspace_get_limit(size_t *per_stream_bytes, size_t *total_bytes);
 fhe_status fhe_workspace_stats(size_t *held_bytes, size_t *in_use_bytes, size_t *blocks, size_t *owners,
                                size_t *internal_streams);
+fhe_status fhe_workspace_pool_stats(int device, size_t *scratch_reserved_bytes, size_t *scratch_used_bytes,
+                                    size_t *buffers_reserved_bytes, size_t *buffers_used_bytes);
 /* Integer-issue ceiling ("report both ceilings"): register-resident loops of the instructions /
  * butterflies the NTT-type kernels are made of, chip-wide, no memory traffic, run for at least min_seconds
  * (0 < min_seconds <= 10).  which: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32, 3 lazy Shoup product,

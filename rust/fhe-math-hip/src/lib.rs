@@ -683,6 +683,14 @@ pub fn workspace_stats() -> Result<(usize, usize, usize, usize, usize)> {
     check(unsafe { ffi::fhe_workspace_stats(&mut h, &mut u, &mut b, &mut o, &mut a) })?;
     Ok((h, u, b, o, a))
 }
+/// What the driver says the library's two private stream-ordered pools on `device` hold: (scratch reserved, scratch used,
+/// buffers reserved, buffers used) bytes (`fhe_workspace_pool_stats`).  The scratch pool's reserved bytes respect the
+/// `total_bytes` bound of [`workspace_set_limit`] once evicted blocks have retired.
+pub fn workspace_pool_stats(device: i32) -> Result<(usize, usize, usize, usize)> {
+    let (mut sr, mut su, mut br, mut bu) = (0usize, 0usize, 0usize, 0usize);
+    check(unsafe { ffi::fhe_workspace_pool_stats(device as c_int, &mut sr, &mut su, &mut br, &mut bu) })?;
+    Ok((sr, su, br, bu))
+}
 /// Frees every idle scratch block, internal stream and pooled event; returns the bytes released.
 pub fn workspace_trim() -> usize { unsafe { ffi::fhe_workspace_trim() } }
 /// Number of HIP devices the engine sees (a host that shards a batch over the GPUs of a node makes one set of handles

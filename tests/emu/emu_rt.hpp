@@ -255,7 +255,7 @@ inline std::atomic<long long> &emu_live_bytes() {
 inline hipError_t hipMallocAsync(void **p, size_t n, hipStream_t) { return hipMalloc(p, n); }
 inline hipError_t hipFreeAsync(void *p, hipStream_t) { return hipFree(p); }
 typedef void *hipMemPool_t;
-enum { hipMemPoolAttrReleaseThreshold = 4 };
+enum { hipMemPoolAttrReleaseThreshold = 4, hipMemPoolAttrReservedMemCurrent = 5, hipMemPoolAttrUsedMemCurrent = 7 };
 enum hipMemAllocationType { hipMemAllocationTypePinned = 1 };
 enum hipMemLocationType { hipMemLocationTypeDevice = 1 };
 struct hipMemLocation {
@@ -280,6 +280,14 @@ inline hipError_t hipMallocFromPoolAsync(void **p, size_t n, hipMemPool_t, hipSt
 inline hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t *pool, int) { *pool = nullptr; return hipSuccess; }
 inline hipError_t hipMemPoolSetAttribute(hipMemPool_t, int, void *) { return hipSuccess; }
 inline hipError_t hipMemPoolTrimTo(hipMemPool_t, size_t) { return hipSuccess; }
+inline hipError_t hipMemPoolGetAttribute(hipMemPool_t, int, void *v) {   // (no pools here: every free is immediate)
+    *(uint64_t *)v = 0;
+    return hipSuccess;
+}
+inline hipError_t hipDeviceTotalMem(size_t *bytes, int) {
+    *bytes = (size_t)1 << 34;
+    return hipSuccess;
+}
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {

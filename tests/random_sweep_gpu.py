@@ -15,13 +15,13 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 last = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 ks_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # fhe_ksk_set_mode of every key the sweep makes (0 = auto)
 big = len(sys.argv) > 5 and sys.argv[5] == "big"
-fhe.KeySwitchingKey.default_mode = (ks_mode, 0)
-for idx in range(first, last):
-    try:
-        full_size.check_random_shape(fhe, idx, big)
-        done += 1
-    except Exception as e:
-        fails.append((idx, full_size.random_shape(idx, big), repr(e)[:200]))
-        break
-    if time.time() - t0 > budget: break
+with fhe.KeySwitchingKey.forced_mode(ks_mode):     # (thread-local, restored on exit)
+    for idx in range(first, last):
+        try:
+            full_size.check_random_shape(fhe, idx, big)
+            done += 1
+        except Exception as e:
+            fails.append((idx, full_size.random_shape(idx, big), repr(e)[:200]))
+            break
+        if time.time() - t0 > budget: break
 print(json.dumps({"shapes_checked": done, "first_idx": first, "ks_mode": ks_mode, "big": big, "failures": fails, "seconds": round(time.time() - t0)}))

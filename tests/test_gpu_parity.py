@@ -797,3 +797,48 @@ def test_reference_default_parameter_sets_bench_batches(fhe, n, batch):
     full_size.check_mul(fhe, n=n, sizes=None, moduli=ref_params.DEFAULT_128[n], batch=batch, relin=True, cfg=0x128,
                         sample=(0, 1, batch // 2 - 1, batch // 2, batch - 1))
     fhe.workspace_trim()
+
+
+def test_workspace_limit_bounds_device_memory(fhe):
+    """fhe_workspace_set_limit bounds the DEVICE MEMORY the process holds for scratch, not just the engine's
+    table: after one large call under a small `total_bytes`, the scratch pool's reserved bytes (what the driver says,
+    fhe_workspace_pool_stats) come back under the bound once the stream has been synchronised -- torch or any other
+    allocator in the process can have the memory -- and results stay bit-identical to the unbounded run."""
+    import torch
+    import full_size
+    from fhe_oracle import bfv as obfv
+    n, sizes, batch = 8192, [60] * 4, 256
+    q = obfv.generate_moduli(sizes, n)
+    par = fhe.BfvParameters(n, full_size.plaintext_modulus(n), moduli=q)
+    ctx = par.context_at_level(0)
+    c0, c1 = full_size.device_key(ctx, 31, len(q))
+    m = fhe.Multiplicator.default(par, fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1)), 0).set_streams(1)
+    a, b = ctx.synth_uniform(31, 0, 0, 2, batch), ctx.synth_uniform(31, 0, 2, 2, batch)
+    fhe.workspace_trim()
+    fhe.workspace_set_limit(0, 0)                      # unbounded: the pool keeps the call's whole footprint
+    want = m.multiply(a, b)
+    torch.cuda.synchronize()
+    big = fhe.workspace_pool_stats(0)
+    held = fhe.workspace_stats()["held_bytes"]
+    assert held > (256 << 20) and big["scratch_reserved_bytes"] >= held, (big, held)
+    limit = 64 << 20
+    fhe.workspace_set_limit(0, limit)                  # evicts the idle blocks and trims the pool
+    torch.cuda.synchronize()
+    st = fhe.workspace_pool_stats(0)
+    assert fhe.workspace_stats()["held_bytes"] <= limit
+    assert st["scratch_reserved_bytes"] <= limit + (32 << 20), (st, big)
+    got = m.multiply(a, b)                             # a call larger than the bound still runs ...
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    st = fhe.workspace_pool_stats(0)                   # ... and its blocks are not kept afterwards
+    assert fhe.workspace_stats()["held_bytes"] <= limit
+    assert st["scratch_reserved_bytes"] <= limit + (32 << 20), st
+    # the ABI's own buffers live in the other pool and are untouched by the scratch bound
+    with fhe.Stream(0) as s:
+        d = fhe.DeviceArray((1 << 24,))
+        assert fhe.workspace_pool_stats(0)["buffers_used_bytes"] >= (1 << 27)
+        d.free()
+        s.synchronize()
+    s.destroy()
+    fhe.workspace_set_limit()
+    fhe.workspace_trim()

@@ -344,7 +344,7 @@ HOST_ONLY_API = {
     "as_ptr", "as_mut_ptr", "len", "is_empty", "buffer", "from_ctx", "to_ctx", "ct_ctx", "ksk_ctx", "degree", "nmoduli",
     "device", "poly_words", "get", "view",
     # engine-wide state and per-handle execution options (a serving host tunes these; the patched crates never do)
-    "workspace_set_limit", "workspace_stats", "workspace_trim", "device_count", "set_mode", "set_streams", "set_chunk",
+    "workspace_set_limit", "workspace_stats", "workspace_pool_stats", "workspace_trim", "device_count", "set_mode", "set_streams", "set_chunk",
     # device memory / stream plumbing for hosts that manage residency themselves
     "alloc", "release_on", "synchronize", "upload", "download",
     # the parameter-set route to a Multiplicator (a host that builds BfvParameters-level tables on the device)

@@ -824,7 +824,15 @@ inline void launch_tensor_intt_rows(const Ctx &e, const k::TensorSrc &ts, u64 *o
 
 inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, hipStream_t s, bool reverse) {
     // maximal runs of rows of the same kind (moduli below 2^60 or not): one launch each (reverse: last run first)
-    const bool allow = !FHE_LAB_FLAG("NO_NARROW");
+    bool allow = !FHE_LAB_FLAG("NO_NARROW");
+    // A launch that does not fill the device anyway (its workgroups all run at once: a single ciphertext pair, a handful)
+    // takes ONE workgroup's time whatever its passes cost, so two launches -- narrow rows, then general rows -- take twice
+    // that: such a launch runs every row on the general passes (valid for any modulus below 2^62) in one go.
+    // (C2, one pair: tensor_intt 2 x 16.4 us -> 1 x; profiles/r05_latency_breakdown.json)
+    {
+        const uint32_t lsub = e.logn > 14 ? (uint32_t)e.logn - 13 : 0;
+        if ((((size_t)3 * e.L * nb) << lsub) <= (size_t)device_cus(e.device) * 2 / 3 && device_cus(e.device) > 8) allow = false;
+    }
     struct Run {
         uint32_t r0, n;
         bool narrow;

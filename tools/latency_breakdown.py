@@ -61,6 +61,16 @@ def main():
     m5 = fhe.Multiplicator.default(par, fhe.RelinearizationKey(key_for(fhe, ctx, 5)), 0, True)
     a5, b5 = ctx.synth_uniform(5, 0, 0, 2, 1), ctx.synth_uniform(5, 0, 2, 2, 1)
     out["C5_level0_mul_relin_modswitch"] = measure(lambda: m5.multiply(a5, b5))
+    # one workgroup's latency by tile size: 64 rows (a quarter of the CUs) of n points, forward and inverse, 60- and 62-bit
+    lat = {}
+    for n in (512, 1024, 2048, 4096, 8192, 16384):
+        for bits in (60, 62):
+            c = fhe.Context([fhe.generate_prime(bits, 2 * n, 1 << bits)], n)
+            x = c.synth_uniform(7, 0, 0, 1, 64)
+            f = measure(lambda: c.ntt_forward(x), 100)
+            b = measure(lambda: c.ntt_backward(x), 100)
+            lat[f"n={n}/{bits}bit"] = dict(fwd_us=round(f["kernel_sum_ms"] * 1e3, 2), inv_us=round(b["kernel_sum_ms"] * 1e3, 2))
+    out["ntt_workgroup_latency_64_rows"] = lat
     print(json.dumps(out))
 
 

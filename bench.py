@@ -176,12 +176,15 @@ def sclk_under_load(work, max_seconds=6.0):
         return None
 
 
-def int_issue_roofline(fhe, dev, prof, n, L, K, batch, steps, pipeline_step=None, sync=None):
+def int_issue_roofline(fhe, dev, prof, n, L, K, batch, steps, pipeline_step=None, sync=None, par=None, value_per_gpu=None,
+                       stage_bytes=None):
     """"measure it (microbench v_mad_u64_u32 throughput) and report both ceilings".  Runs the library's
-    register-resident loops (the butterflies the kernels are made of, no memory traffic) for ~0.2 s in this process,
-    samples the engine clock while they run, and prices every NTT-type kernel of the timed region against them:
-    frac_of_ceiling = (time its transform butterflies would take at the register-resident rate) / (its HIP-event
-    time).  Tensor products, key-switch MACs, lifts and reductions are real work NOT counted in the numerator."""
+    no-HBM loops -- the butterflies, the tensor products, the key switch's Shoup multiply-accumulate (register resident)
+    and the two scale_kernel instances of the multiply on one L2-resident polynomial -- for ~0.3 s in this process,
+    samples the engine clock while they run, and prices EVERY kernel family of the timed region against them:
+    frac_of_ceiling = (time its arithmetic would take at those rates) / (its HIP-event time).  Round 5: the numerators
+    cover the whole operation (rounds 1-4 counted transform butterflies only), so `whole_op` is the operation's integer
+    ceiling and `binding` says which of the two ceilings -- integer issue or the HBM stage model -- is the lower one."""
     import threading
     clocks, stop = [], threading.Event()
 
@@ -194,7 +197,12 @@ def int_issue_roofline(fhe, dev, prof, n, L, K, batch, steps, pipeline_step=None
     th = threading.Thread(target=sampler, daemon=True)
     th.start()
     rates = {k: fhe.ubench_int(k, 0.03, dev) for k in ("mad_u64_u32", "mul_lo_u32", "mul_hi_u32", "shoup_lazy",
-                                                        "fwd_butterfly", "fwd_butterfly_narrow", "inv_butterfly")}
+                                                        "fwd_butterfly", "fwd_butterfly_narrow", "inv_butterfly",
+                                                        "shoup_mac", "tensor_mul", "tensor_mac2")}
+    col_ext = col_down = None
+    if par is not None:
+        col_ext = fhe.ubench_scaler(par.extender(0), 0.03)
+        col_down = fhe.ubench_scaler(par.down_scaler(0), 0.03)
     stop.set()
     th.join()
     # the clock the SMU reports while the integer pipe is saturated, and while the real pipeline runs
@@ -208,33 +216,62 @@ def int_issue_roofline(fhe, dev, prof, n, L, K, batch, steps, pipeline_step=None
         sclk_pipeline = sclk_under_load(work)
     bf_row = (n // 2) * (n.bit_length() - 1)                     # butterflies of one row transform
     fw, fn_, iv = rates["fwd_butterfly"], rates["fwd_butterfly_narrow"], rates["inv_butterfly"]
-    # rows per ct x ct + relin by kernel and butterfly kind (C2: the L ciphertext primes are 60-bit -> narrow passes,
-    # the K - L extension primes 62-bit -> wide passes; the inverse narrow passes are priced with the wide inverse rate)
-    rows = {
-        "ntt_fwd": [(4 * (K - L), fw), (2 * L, fn_)],
-        "ntt_inv": [(4 * L, iv)],
-        "tensor_intt": [(3 * K, iv)],
-        "key_switch_fused": [(L * L, fn_)],
+    mac, tm, tm2 = rates["shoup_mac"], rates["tensor_mul"], rates["tensor_mac2"]
+    # work per ct x ct + relin by kernel family: (count, rate) pairs; counts in lane-operations.
+    # C2: the L ciphertext primes are 60-bit -> narrow forward passes, the K - L extension primes 62-bit -> wide passes;
+    # the inverse narrow passes are priced with the wide inverse rate (no separate register-resident loop for them).
+    work = {
+        "ntt_fwd": [(4 * (K - L) * bf_row, fw), (2 * L * bf_row, fn_)],
+        "ntt_inv": [(4 * L * bf_row, iv)],
+        # fused tensor + inverse NTT: per row of the extended basis two single products (slots 0, 2) and one double
+        # product (slot 1) per coefficient, then three inverse row transforms
+        "tensor_intt": [(2 * K * n, tm), (K * n, tm2), (3 * K * bf_row, iv)],
+        # fused key switch of c2 (PowerBasis: all L x L digit transforms) + two accumulator sets of L x L Shoup MACs
+        "key_switch_fused": [(L * L * bf_row, fn_), (2 * L * L * n, mac)],
     }
-    per_kernel = {}
-    for name, parts in rows.items():
+    if col_ext:
+        work["scale_extend"] = [(4 * n, col_ext)]                # 4 operand polynomials, one column per coefficient
+        work["scale_down"] = [(3 * n, col_down)]                 # 3 tensor slots
+    per_kernel, ideal_op_s = {}, 0.0
+    for name, parts in work.items():
+        ideal_one = sum(c / rate for c, rate in parts)           # seconds per operation at the no-HBM rates
+        ideal_op_s += ideal_one
         if name in prof and prof[name][1] > 0:
-            ideal_s = sum(r * bf_row / rate for r, rate in parts) * batch * steps
-            per_kernel[name] = dict(butterflies_per_s=round(sum(r for r, _ in parts) * bf_row * batch * steps
-                                                            / (prof[name][1] * 1e-3), 0),
-                                    frac_of_ceiling=round(ideal_s / (prof[name][1] * 1e-3), 4))
-    return dict(butterflies_per_s_ceiling=dict(forward_wide=round(fw, 0), forward_narrow_lt_2p60=round(fn_, 0),
-                                               inverse=round(iv, 0)),
-                row_ntt_per_s_ceiling=dict(forward_wide=round(fw / bf_row, 0), forward_narrow_lt_2p60=round(fn_ / bf_row, 0),
-                                           inverse=round(iv / bf_row, 0)),
-                mad_u64_u32_per_s=round(rates["mad_u64_u32"], 0), mul_lo_u32_per_s=round(rates["mul_lo_u32"], 0),
-                mul_hi_u32_per_s=round(rates["mul_hi_u32"], 0), shoup_lazy_per_s=round(rates["shoup_lazy"], 0),
-                sclk_mhz_observed=sclk_ubench or (round(sum(clocks) / len(clocks)) if clocks else None),
-                sclk_mhz_during_pipeline=sclk_pipeline,
-                sclk_source=("rocm-smi --showclocks (SMU current gfxclk) sampled once under each load" if sclk_ubench
-                             else "sysfs pp_dpm_sclk level table (the active LEVEL, not the instantaneous clock)"),
-                sclk_dpm_level_mhz=(round(sum(clocks) / len(clocks)) if clocks else None), per_kernel=per_kernel,
-                note="fhe_ubench_int, this process, this box; numerators count transform butterflies only")
+            d = dict(ideal_us_per_op=round(ideal_one * 1e6, 4),
+                     frac_of_ceiling=round(ideal_one * batch * steps / (prof[name][1] * 1e-3), 4))
+            if name in ("ntt_fwd", "ntt_inv", "tensor_intt", "key_switch_fused"):
+                rows = sum(c for c, _ in parts if c % bf_row == 0 and c >= bf_row)
+                d["butterflies_per_s"] = round(rows * batch * steps / (prof[name][1] * 1e-3), 0)
+            per_kernel[name] = d
+    out = dict(butterflies_per_s_ceiling=dict(forward_wide=round(fw, 0), forward_narrow_lt_2p60=round(fn_, 0),
+                                              inverse=round(iv, 0)),
+               row_ntt_per_s_ceiling=dict(forward_wide=round(fw / bf_row, 0), forward_narrow_lt_2p60=round(fn_ / bf_row, 0),
+                                          inverse=round(iv / bf_row, 0)),
+               mad_u64_u32_per_s=round(rates["mad_u64_u32"], 0), mul_lo_u32_per_s=round(rates["mul_lo_u32"], 0),
+               mul_hi_u32_per_s=round(rates["mul_hi_u32"], 0), shoup_lazy_per_s=round(rates["shoup_lazy"], 0),
+               shoup_mac_per_s=round(mac, 0), tensor_mul_per_s=round(tm, 0), tensor_mac2_per_s=round(tm2, 0),
+               scale_extend_columns_per_s=round(col_ext, 0) if col_ext else None,
+               scale_down_columns_per_s=round(col_down, 0) if col_down else None,
+               sclk_mhz_observed=sclk_ubench or (round(sum(clocks) / len(clocks)) if clocks else None),
+               sclk_mhz_during_pipeline=sclk_pipeline,
+               sclk_source=("rocm-smi --showclocks (SMU current gfxclk) sampled once under each load" if sclk_ubench
+                            else "sysfs pp_dpm_sclk level table (the active LEVEL, not the instantaneous clock)"),
+               sclk_dpm_level_mhz=(round(sum(clocks) / len(clocks)) if clocks else None), per_kernel=per_kernel,
+               note="fhe_ubench_int / fhe_ubench_scaler, this process, this box; numerators: transform butterflies, tensor "
+                    "products, key-switch MACs (register-resident loops) and scaler columns (scale_kernel on one "
+                    "L2-resident polynomial); lifts, final reductions and loads / stores are not priced")
+    if col_ext and value_per_gpu:
+        ceil_ops = 1.0 / ideal_op_s
+        out["whole_op"] = dict(ceiling_ops_per_s=round(ceil_ops, 1), ideal_us_per_op=round(ideal_op_s * 1e6, 3),
+                               frac=round(value_per_gpu / ceil_ops, 4),
+                               what="1 / sum over the six kernel families of (their arithmetic at the no-HBM rates): the "
+                                    "operation's integer-issue ceiling if the chip did nothing but that arithmetic")
+        if stage_bytes:
+            hbm_ops = HBM_PEAK_GBS * 1e9 / stage_bytes
+            out["hbm_whole_op"] = dict(ceiling_ops_per_s=round(hbm_ops, 1), frac=round(value_per_gpu / hbm_ops, 4))
+            out["binding"] = "int_issue" if ceil_ops < hbm_ops else "hbm"
+            out["value_over_min_ceiling"] = round(value_per_gpu / min(ceil_ops, hbm_ops), 4)
+    return out
 
 
 def workload_name(world, batch):
@@ -486,21 +523,28 @@ def next_rows(fhe, torch, par, timeit):
             d["note"] = note
         return d
 
-    # the box's own streaming ceiling: a 2 GiB device-to-device copy, read + write bytes counted (the guide's
-    # "achievable" HBM rate is ~6.3 TB/s; a plain copy on these boxes measures ~5.1 TB/s): the streaming rows below
-    # carry their fraction of THIS number next to the fraction of the nominal 8 TB/s
+    # The box's own streaming rates, read + write bytes counted: (a) torch's 2 GiB device-to-device copy (hipMemcpyDtoD:
+    # ~5.1 TB/s on these boxes -- NOT a ceiling, the path's own streaming kernels beat it), (b) the library's
+    # 16-byte-per-lane copy kernel with streaming loads / stores (fhe_ubench_copy; the guide's "achievable" HBM rate is
+    # ~6.3 TB/s).  The streaming rows below carry their fraction of the FASTER of the two next to the fraction of the
+    # nominal 8 TB/s.
     src = torch.empty(1 << 28, dtype=torch.int64, device=f"cuda:{ctx.device}")
     dst = torch.empty_like(src)
     copy_ms = timeit(lambda: dst.copy_(src))
     copy_gbs = 2 * src.numel() * 8 / copy_ms / 1e6
-    out["hbm_copy_ceiling"] = dict(GBps=round(copy_gbs, 1), frac=round(copy_gbs / HBM_PEAK_GBS, 4), ms=round(copy_ms, 3),
-                                   workload="torch D2D copy of 2 GiB, read + write bytes")
     del src, dst
+    kern_gbs = fhe.ubench_copy(1 << 31, 0.05, ctx.device) / 1e9
+    out["hbm_streaming_rates"] = dict(
+        torch_d2d_copy_GBps=round(copy_gbs, 1), torch_d2d_copy_frac=round(copy_gbs / HBM_PEAK_GBS, 4),
+        copy16_kernel_GBps=round(kern_gbs, 1), copy16_kernel_frac=round(kern_gbs / HBM_PEAK_GBS, 4),
+        note="2 GiB each, read + write bytes; torch D2D is hipMemcpyDtoD and is not a ceiling; `frac_of_measured_stream_rate` "
+             "below is against the faster of the two")
+    stream_gbs = max(copy_gbs, kern_gbs)
     _entry = entry
 
     def entry(ms, units, rows_per_unit, unit="ops_per_s", note=None, workload=None):   # noqa: F811
         d = _entry(ms, units, rows_per_unit, unit, note, workload)
-        d["frac_of_measured_copy_ceiling"] = round(d["stage_model_GBps"] / copy_gbs, 4)
+        d["frac_of_measured_stream_rate"] = round(d["stage_model_GBps"] / stream_gbs, 4)
         return d
 
     ksk = key_for(fhe, ctx, SEED + 0x100)
@@ -742,6 +786,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1,
                     help="streams of the TIMED region (1: exact per-kernel durations; 2: the handle's default mode)")
+    ap.add_argument("--sustain", type=float, default=3.0,
+                    help="seconds of a sustained event-free leg after the timed region (0: none)")
     ap.add_argument("--spawn-check", action="store_true",
                     help="rendezvous only: start the ranks, all-reduce their ranks, print a JSON line (no GPU work)")
     args = ap.parse_args()
@@ -848,7 +894,7 @@ def main():
     torch.cuda.synchronize()
     # N > 1: rank 0's rate on the SAME per-GPU batch while every other rank idles at a barrier -- the one-GPU
     # reference the scaling efficiency of this very run is computed against, and who is who
-    solo_rate, identities = None, None
+    solo_rate, identities, n1_reference = None, None, None
     if dist is not None:
         dist.barrier()
         if rank == 0:
@@ -856,7 +902,27 @@ def main():
             for _ in range(args.steps):
                 step()
             torch.cuda.synchronize()
-            solo_rate = batch * args.steps / (time.perf_counter() - t0)
+            dt = time.perf_counter() - t0
+            solo_rate = batch * args.steps / dt
+            # what ONE GPU does alone, at this run's per-GPU batch and at C2's 1,024 (the N = 1 line of BENCH / SCALE is
+            # measured at 1,024: this is the number to cross-check it against from inside an N > 1 run)
+            n1_reference = {f"batch_{batch}": dict(value=round(solo_rate, 1), ms_per_step=round(dt / args.steps * 1e3, 3))}
+            if batch > BATCH_PER_GPU:
+                b1 = BATCH_PER_GPU
+
+                def step_1024():
+                    _lib.check(_lib.lib().fhe_bfv_mul_dev(mul._h, C.c_void_p(lhs.data_ptr()), C.c_void_p(rhs.data_ptr()),
+                                                          C.c_void_p(out.data_ptr()), b1, C.c_void_p(stream)))
+                for _ in range(2):
+                    step_1024()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step_1024()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                n1_reference[f"batch_{b1}"] = dict(value=round(b1 * args.steps / dt, 1), ms_per_step=round(dt / args.steps * 1e3, 3))
+            n1_reference["note"] = "rank 0 alone (every other rank idle at a barrier), wall clock around K steps + synchronize"
         dist.barrier()
         props = torch.cuda.get_device_properties(dev)
         me = dict(rank=rank, local_rank=local_rank, device=dev, name=props.name,
@@ -871,7 +937,14 @@ def main():
     REPEATS = 3
     elapsed_all = [timed(step, args.steps) for _ in range(REPEATS)]
     fhe.prof_enable(False)
-    prof = fhe.prof_report()
+    prof_by_symbol = fhe.prof_report()
+    # the library labels the two tensor_intt instances separately (rows below 2^60: narrow passes); the roofline's
+    # families fold them, `dominant_by_symbol` below keeps them apart
+    prof = {}
+    for k_, (n_, ms_) in prof_by_symbol.items():
+        fam = k_[:-len("_narrow")] if k_.endswith("_narrow") else k_
+        a_ = prof.get(fam, (0, 0.0))
+        prof[fam] = (a_[0] + n_, a_[1] + ms_)
     elapsed = sorted(elapsed_all)[REPEATS // 2]
     prof_steps = args.steps * REPEATS    # the per-kernel event sums cover every repeat
     # every rank's own elapsed time for the same K steps (its barrier-to-barrier time is the slowest rank's)
@@ -889,6 +962,25 @@ def main():
         rates = [batch * args.steps / float(x.item()) for x in allt]
         per_rank = dict(ops_per_s=[round(r, 1) for r in rates], max_over_min=round(max(rates) / min(rates), 4),
                         note="each rank's own un-barriered K steps right after the timed region")
+
+    # A sustained, event-free leg (every rank, no barrier): the timed region above is a fraction of a second, too short
+    # for a utilisation sampler that looks every few seconds -- this keeps the device busy with the same step for
+    # `--sustain` seconds and reports the rate it held (`gpu_busy` saw 0 of 3 samples).
+    sustained = None
+    if args.sustain > 0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_sus = 0
+        while True:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            n_sus += 20
+            if time.perf_counter() - t0 >= args.sustain:
+                break
+        dt = time.perf_counter() - t0
+        sustained = dict(seconds=round(dt, 2), steps=n_sus, ops_per_s_this_rank=round(batch * n_sus / dt, 1),
+                         note="same step, library profiler off, back to back; this rank only")
 
     extras = {}
     if not args.no_extras:
@@ -976,6 +1068,14 @@ def main():
         per_kernel[k] = dict(launches=v[0], ms=round(v[1], 3),
                              frac=round(kb / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[1] > 0 and kb else None)
     kernel_sum_ms = sum(v[1] for v in prof.values())
+    # the dominant launch label with the two tensor_intt instances kept apart (by symbol the key switch leads)
+    sym_rows = dict(alg_rows, tensor_intt=7 * (K - L), tensor_intt_narrow=7 * L)
+    sname, (slaunches, sms) = max(prof_by_symbol.items(), key=lambda kv: kv[1][1]) if prof_by_symbol else ("none", (1, 1e-9))
+    sbytes = sym_rows.get(sname, 0) * R * batch * prof_steps
+    dominant_by_symbol = dict(kernel=sname, launches=slaunches, avg_launch_ms=round(sms / max(slaunches, 1), 4),
+                              achieved=round(sbytes / (sms * 1e-3) / 1e9, 1) if sms > 0 else 0.0,
+                              frac=round(sbytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sms > 0 else 0.0,
+                              share_of_kernel_time=round(sms / kernel_sum_ms, 4) if kernel_sum_ms else None)
     roofline = dict(bound="hbm", kernel=dname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                     traffic_observed_this_run=False,
@@ -990,10 +1090,17 @@ def main():
                     whole_op=dict(stage_model_bytes_per_op=stage_model_rows(L, K, L) * R,
                                   achieved=round(stage_model_rows(L, K, L) * R * value / world / 1e9, 1),
                                   frac=round(stage_model_rows(L, K, L) * R * value / world / 1e9 / HBM_PEAK_GBS, 4)),
-                    kernels=per_kernel)
+                    kernels=per_kernel, kernel_is="dominant FAMILY (instances of one kernel template summed)",
+                    dominant_by_symbol=dominant_by_symbol)
     if not args.no_extras:
         roofline["int_issue"] = int_issue_roofline(fhe, dev, prof, n, L, K, batch, prof_steps, pipeline_step=step,
-                                                   sync=torch.cuda.synchronize)
+                                                   sync=torch.cuda.synchronize, par=par, value_per_gpu=value / world,
+                                                   stage_bytes=stage_model_rows(L, K, L) * R)
+        if "binding" in roofline["int_issue"]:
+            roofline["binding"] = roofline["int_issue"]["binding"]
+            roofline["frac_of_binding_ceiling"] = roofline["int_issue"]["value_over_min_ceiling"]
+            roofline["frac_hbm_whole_op"] = roofline["int_issue"]["hbm_whole_op"]["frac"]
+            roofline["frac_int_issue_whole_op"] = roofline["int_issue"]["whole_op"]["frac"]
 
     result = {
         "metric": "BFV ct x ct + relinearize ops/s (n=8192, 4x60-bit moduli)",
@@ -1010,6 +1117,8 @@ def main():
         "roofline": roofline,
     }
     result.update(extras)
+    if sustained is not None:
+        result["sustained"] = sustained
     if per_rank is not None:
         result["per_rank"] = per_rank
     if dist is not None:
@@ -1019,7 +1128,7 @@ def main():
             distinct_devices=distinct, one_device_per_rank=bool(distinct == world),
             solo_rank0_ops_per_s=round(solo_rate, 1), solo_note="rank 0, same per-GPU batch, all other ranks idle at a barrier",
             efficiency_vs_1gpu_same_batch=round(value / (world * solo_rate), 4),
-            data_path_collectives=0)
+            n1_reference=n1_reference, data_path_collectives=0)
 
     if cpu_leg is not None:
         cb, cm, (clhs, crhs, last, count, npairs) = cpu_leg

@@ -52,6 +52,8 @@ SIGNATURES = {
     "fhe_bfv_switch_to_level": (i32, [vp, sz, sz, u64p, u64p, sz]),
     "fhe_bfv_switch_to_level_dev": (i32, [vp, sz, sz, vp, vp, sz, vp]),
     "fhe_ubench_int": (i32, [i32, i32, C.c_double, C.POINTER(C.c_double)]),
+    "fhe_ubench_scaler": (i32, [vp, C.c_double, C.POINTER(C.c_double)]),
+    "fhe_ubench_copy": (i32, [i32, sz, C.c_double, C.POINTER(C.c_double)]),
     "fhe_ctx_create": (i32, [i32, sz, sz, u64p, u64p, u64p, u64p, u64p, u64p, u64p, C.POINTER(vp)]),
     "fhe_ctx_destroy": (None, [vp]),
     "fhe_ctx_at_level": (i32, [vp, sz, C.POINTER(vp)]),

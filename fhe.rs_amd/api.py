@@ -1111,7 +1111,7 @@ def workspace_pool_stats(device=0):
 
 
 UBENCH_KINDS = {"mad_u64_u32": 0, "mul_lo_u32": 1, "mul_hi_u32": 2, "shoup_lazy": 3, "fwd_butterfly": 4,
-                "fwd_butterfly_narrow": 5, "inv_butterfly": 6}
+                "fwd_butterfly_narrow": 5, "inv_butterfly": 6, "shoup_mac": 7, "tensor_mul": 8, "tensor_mac2": 9}
 
 
 def ubench_int(kind, min_seconds=0.05, device=0):
@@ -1119,6 +1119,20 @@ def ubench_int(kind, min_seconds=0.05, device=0):
     v = C.c_double()
     check(_lib.lib().fhe_ubench_int(device, UBENCH_KINDS[kind] if isinstance(kind, str) else int(kind),
                                     float(min_seconds), C.byref(v)))
+    return v.value
+
+
+def ubench_scaler(scaler, min_seconds=0.05):
+    """RnsScaler::scale's no-HBM ceiling for this scaler's kernel instance (fhe_ubench_scaler): columns per second."""
+    v = C.c_double()
+    check(_lib.lib().fhe_ubench_scaler(scaler._h, float(min_seconds), C.byref(v)))
+    return v.value
+
+
+def ubench_copy(nbytes, min_seconds=0.05, device=0):
+    """The box's streaming rate (fhe_ubench_copy): read + write bytes per second of a 16-byte-per-lane copy."""
+    v = C.c_double()
+    check(_lib.lib().fhe_ubench_copy(int(device), int(nbytes), float(min_seconds), C.byref(v)))
     return v.value
 
 

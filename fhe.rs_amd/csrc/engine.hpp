@@ -800,7 +800,7 @@ inline void launch_tensor_intt_rows(const Ctx &e, const k::TensorSrc &ts, u64 *o
     const unsigned groups = (unsigned)(((((size_t)lrows * nb) << (logn - logm)) + 7) / 8);
 #define FHE_TI_LAUNCH(LM, SUB, NRW)                                                                              \
     allow_big_lds((k::tensor_intt_kernel<LM, SUB, NRW>), lds);                                                   \
-    FHE_LAUNCH("tensor_intt", (k::tensor_intt_kernel<LM, SUB, NRW>), dim3(groups * 24),                          \
+    FHE_LAUNCH((NRW ? "tensor_intt_narrow" : "tensor_intt"), (k::tensor_intt_kernel<LM, SUB, NRW>), dim3(groups * 24), \
                dim3(k::ntt_threads_c(LM)), lds, s, ts, out, e.dmods(), e.ditw(), e.dninv(), (uint32_t)e.L,       \
                (uint32_t)nb, logn, row_begin, lrows, reverse ? 1u : 0u);
 #define FHE_TI_CASE(LM)                               \

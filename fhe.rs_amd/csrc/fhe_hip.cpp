@@ -1748,6 +1748,23 @@ fhe_status fhe_ubench_int(int device, int which, double min_seconds, double *ops
         *ops_per_s = ub::run(device, which, min_seconds);
     });
 }
+fhe_status fhe_ubench_scaler(const fhe_scaler *scaler, double min_seconds, double *columns_per_s) {
+    return guard([&] {
+        need(scaler, "scaler");
+        need(columns_per_s, "columns_per_s");
+        *columns_per_s = ub::run_scaler(*scaler->s, min_seconds);
+    });
+}
+fhe_status fhe_ubench_copy(int device, size_t bytes, double min_seconds, double *bytes_per_s) {
+    return guard([&] {
+        need(bytes_per_s, "bytes_per_s");
+        *bytes_per_s = 0;
+        int ndev = 0;
+        FHE_HIP_CHECK(hipGetDeviceCount(&ndev));
+        require(device >= 0 && device < ndev, E_NO_DEVICE, "no such HIP device");
+        *bytes_per_s = ub::run_copy(device, bytes, min_seconds);
+    });
+}
 void fhe_prof_enable(int on) { Profiler::get().enabled = on != 0; }
 void fhe_prof_reset(void) {
     try {

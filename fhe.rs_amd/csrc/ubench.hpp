@@ -19,7 +19,11 @@ enum Kind : int {
     FWD_WIDE = 4,      // Harvey forward butterfly, any modulus < 2^62 (fwd_butterfly)
     FWD_NARROW = 5,    // forward butterfly for moduli < 2^60, approximate quotient (fwd_butterfly_narrow)
     INV_WIDE = 6,      // Gentleman-Sande inverse butterfly (inv_butterfly)
-    NKINDS = 7
+    // round 5: the rest of the multiply pipeline's arithmetic, so that the integer ceiling covers the WHOLE operation
+    SHOUP_MAC = 7,     // the key switch's accumulate: acc = csub(acc + v * k (Shoup, lazy), 2p)   (kernels_ks.hpp)
+    TENSOR_MUL = 8,    // tensor slots 0 / 2: one product of two residues + single-word Barrett, lazy  (mul_mod_lazy)
+    TENSOR_MAC2 = 9,   // tensor slot 1: a0 b1 + a1 b0 as one 128-bit sum + one Barrett  (mac2_wide62 + barrett_reduce_wide_lazy)
+    NKINDS = 10
 };
 constexpr int ILP = 8, ITERS = 2048;
 
@@ -31,7 +35,7 @@ __device__ __forceinline__ u64 opaque_s(u64 v) {
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(256) ubench_kernel(u64 *out, u64 seed, u64 p, u64 w, u64 ws) {
+__global__ void __launch_bounds__(256) ubench_kernel(u64 *out, u64 seed, u64 p, u64 w, u64 ws, DevMod md) {
     u64 x[ILP], y[ILP];
     uint32_t a[ILP], b[ILP];
 #pragma unroll
@@ -66,6 +70,16 @@ __global__ void __launch_bounds__(256) ubench_kernel(u64 *out, u64 seed, u64 p, 
             if (KIND == FWD_NARROW) fwd_butterfly_narrow<true>(x[i], y[i], w, ws, pm, false);
 #endif
             if (KIND == INV_WIDE) inv_butterfly<true>(x[i], y[i], w, ws, pm);
+            if (KIND == SHOUP_MAC) x[i] = csub_n(mul_shoup_lazy_add_n<true>(x[i], y[i], w, ws, pm.np), pm.p2, pm.np2);
+            // (operands masked below 2^60 as the kernels' residues are -- the 4-multiply product needs that -- and made
+            // to depend on the previous result so that the loop is a chain per lane, like the butterflies above)
+            if (KIND == TENSOR_MUL) x[i] = mul_mod_lazy(x[i] & 0x0FFFFFFFFFFFFFFFull, y[i] & 0x0FFFFFFFFFFFFFFFull, md) + y[i];
+            if (KIND == TENSOR_MAC2) {
+                u64 hi, lo;
+                const u64 xa = x[i] & 0x0FFFFFFFFFFFFFFFull, ya = y[i] & 0x0FFFFFFFFFFFFFFFull;
+                mac2_wide62(xa, ya, ya ^ 0x5555, xa ^ 0x3333, hi, lo);
+                x[i] = barrett_reduce_wide_lazy(hi & 0x00FFFFFFFFFFFFFFull, lo, md) + y[i];
+            }
         }
     }
     u64 acc = 0;
@@ -84,14 +98,19 @@ inline double run(int device, int kind, double min_seconds) {
     DevBuf<u64> out;
     out.alloc((size_t)blocks * threads);
     const u64 p = 1152921504606830593ull, w = 123456789012345ull, ws = shoup(w, p);
+    const ModConsts mc = make_mod_consts(p);
+    DevMod md;
+    static_assert(sizeof(DevMod) == sizeof(ModConsts), "DevMod layout");
+    std::memcpy(&md, &mc, sizeof(md));
     hipStream_t s;
     FHE_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto launch = [&](u64 seed) {
         switch (kind) {
 #define FHE_UB_CASE(K) \
-    case K: hipLaunchKernelGGL(ubench_kernel<K>, dim3(blocks), dim3(threads), 0, s, out.p, seed, p, w, ws); break;
+    case K: hipLaunchKernelGGL(ubench_kernel<K>, dim3(blocks), dim3(threads), 0, s, out.p, seed, p, w, ws, md); break;
             FHE_UB_CASE(0) FHE_UB_CASE(1) FHE_UB_CASE(2) FHE_UB_CASE(3) FHE_UB_CASE(4) FHE_UB_CASE(5) FHE_UB_CASE(6)
+            FHE_UB_CASE(7) FHE_UB_CASE(8) FHE_UB_CASE(9)
 #undef FHE_UB_CASE
         }
     };
@@ -122,6 +141,111 @@ inline double run(int device, int kind, double min_seconds) {
         (void)hipStreamDestroy(s);
         throw;
     }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
+    return result;
+}
+
+// A plain streaming copy, 16 bytes per lane, non-temporal loads and stores (what the path's element-wise kernels are made
+// of): the box's own streaming rate, read + write bytes per second.  (torch's D2D copy -- hipMemcpyDtoD -- measures
+// ~5.1 TB/s on these boxes and is NOT a ceiling: the path's own streaming kernels beat it.)
+__global__ void __launch_bounds__(256) ubench_copy_kernel(const k::u64x2 *__restrict__ src, k::u64x2 *__restrict__ dst, size_t n16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n16; i += stride) k::store_stream(dst + i, k::load_stream(src + i));
+}
+inline double run_copy(int device, size_t bytes, double min_seconds) {
+    require(min_seconds > 0 && min_seconds <= 10, E_ARG, "min_seconds must be in (0, 10]");
+    require(bytes >= 4096 && bytes <= ((size_t)16 << 30), E_ARG, "bytes must be in [4 KiB, 16 GiB]");
+    FHE_HIP_CHECK(hipSetDevice(device));
+    const size_t n16 = bytes / 16;
+    DevBuf<k::u64x2> a, b;
+    a.alloc(n16);
+    b.alloc(n16);
+    FHE_HIP_CHECK(hipMemset(a.p, 1, n16 * 16));
+    hipStream_t s;
+    FHE_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double result = 0;
+    try {
+        FHE_HIP_CHECK(hipEventCreate(&e0));
+        FHE_HIP_CHECK(hipEventCreate(&e1));
+        // one 16-byte element per lane (no grid-stride tail): enough workgroups in flight to cover HBM latency
+        const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)1 << 30);
+        hipLaunchKernelGGL(ubench_copy_kernel, dim3(blocks), dim3(256), 0, s, a.p, b.p, n16);
+        FHE_HIP_CHECK(hipStreamSynchronize(s));
+        double total_ms = 0;
+        u64 launches = 0;
+        while (total_ms < min_seconds * 1e3) {
+            FHE_HIP_CHECK(hipEventRecord(e0, s));
+            for (int r = 0; r < 4; r++) hipLaunchKernelGGL(ubench_copy_kernel, dim3(blocks), dim3(256), 0, s, a.p, b.p, n16);
+            FHE_HIP_CHECK(hipEventRecord(e1, s));
+            FHE_HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            FHE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total_ms += ms;
+            launches += 4;
+        }
+        result = 2.0 * (double)n16 * 16.0 * (double)launches / (total_ms * 1e-3);
+    } catch (...) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(s);
+        throw;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
+    return result;
+}
+
+// The scaler's ceiling: scale_kernel itself -- the very instance that serves `sc` -- over `columns` coefficient
+// columns whose polynomial strides are ZERO, i.e. every lane group reads the same nfrom rows (N * nfrom * 8 bytes: L2
+// resident) and writes the same rows: the instruction stream of RnsScaler::scale with no HBM traffic.  Returns columns
+// per second chip-wide.  (A cache-resident, not a register-resident ceiling: the loads and stores still issue.)
+inline double run_scaler(const Scaler &sc, double min_seconds) {
+    require(min_seconds > 0 && min_seconds <= 10, E_ARG, "min_seconds must be in (0, 10]");
+    const Ctx &f = *sc.from, &t = *sc.to;
+    f.need_device();
+    FHE_HIP_CHECK(hipSetDevice(f.device));
+    const size_t npolys = std::max<size_t>(1, ((size_t)1 << 23) / f.n);     // 8 M columns per launch
+    DevBuf<u64> in, out;
+    in.alloc(f.L * f.n);
+    out.alloc(t.L * t.n);
+    FHE_HIP_CHECK(hipMemset(in.p, 0x11, f.L * f.n * sizeof(u64)));           // (any bit pattern: residues below 2^61)
+    hipStream_t s;
+    FHE_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double result = 0;
+    const bool was_on = Profiler::get().enabled;
+    Profiler::get().enabled = false;
+    try {
+        FHE_HIP_CHECK(hipEventCreate(&e0));
+        FHE_HIP_CHECK(hipEventCreate(&e1));
+        launch_scale(sc, in.p, 0, out.p, 0, npolys, s);
+        FHE_HIP_CHECK(hipStreamSynchronize(s));
+        double total_ms = 0;
+        u64 launches = 0;
+        while (total_ms < min_seconds * 1e3) {
+            FHE_HIP_CHECK(hipEventRecord(e0, s));
+            for (int r = 0; r < 4; r++) launch_scale(sc, in.p, 0, out.p, 0, npolys, s);
+            FHE_HIP_CHECK(hipEventRecord(e1, s));
+            FHE_HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            FHE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total_ms += ms;
+            launches += 4;
+        }
+        result = (double)npolys * f.n * (double)launches / (total_ms * 1e-3);
+    } catch (...) {
+        Profiler::get().enabled = was_on;
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(s);
+        throw;
+    }
+    Profiler::get().enabled = was_on;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipStreamDestroy(s);

@@ -492,9 +492,18 @@ fhe_status fhe_workspace_pool_stats(int device, size_t *scratch_reserved_bytes, 
 /* Integer-issue ceiling ("report both ceilings"): register-resident loops of the instructions /
  * butterflies the NTT-type kernels are made of, chip-wide, no memory traffic, run for at least min_seconds
  * (0 < min_seconds <= 10).  which: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32, 3 lazy Shoup product,
- * 4 forward butterfly (any modulus < 2^62), 5 forward butterfly for moduli < 2^60, 6 inverse butterfly;
- * *ops_per_s = lane-operations (multiplies / products / butterflies) per second.  Measurement aid, not on the path. */
+ * 4 forward butterfly (any modulus < 2^62), 5 forward butterfly for moduli < 2^60, 6 inverse butterfly,
+ * 7 the key switch's Shoup multiply-accumulate, 8 the tensor product of slots 0 / 2 (one product + single-word Barrett),
+ * 9 the tensor product of slot 1 (two products, one 128-bit sum, one Barrett);
+ * *ops_per_s = lane-operations (multiplies / products / butterflies) per second.  Measurement aid, not on the path.
+ * fhe_ubench_scaler: RnsScaler::scale's ceiling -- the scale_kernel instance that serves `scaler`, run over coefficient
+ * columns that all alias ONE polynomial (L2 resident: the instruction stream without HBM traffic); *columns_per_s
+ * chip-wide.  With these, bench.py prices every kernel family of ct x ct + relinearise against an integer ceiling. */
 fhe_status fhe_ubench_int(int device, int which, double min_seconds, double *ops_per_s);
+fhe_status fhe_ubench_scaler(const fhe_scaler *scaler, double min_seconds, double *columns_per_s);
+/* The box's own streaming rate: a 16-byte-per-lane copy of `bytes` bytes with streaming loads / stores (the path's
+ * element-wise kernels are made of the same accesses); *bytes_per_s = read + write bytes per second. */
+fhe_status fhe_ubench_copy(int device, size_t bytes, double min_seconds, double *bytes_per_s);
 /* Per-kernel HIP-event timing (events recorded on the launching stream). */
 void fhe_prof_enable(int on);
 void fhe_prof_reset(void);

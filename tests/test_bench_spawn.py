@@ -64,3 +64,18 @@ def test_bench_rank_failure_is_reported():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--spawn-check"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode != 0
+
+
+def test_bench_eight_ranks_rendezvous_under_torchrun():
+    """The driver's SCALE launch at its largest world size, as far as a box without GPUs can walk it: eight ranks under
+    `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`, gloo rendezvous, an all-reduce of the
+    ranks, C4's workload name (8192 pairs per GPU, 65536 in all)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "8",
+                        "--spawn-check"], capture_output=True, text=True, timeout=600, env=_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _line(r.stdout)
+    assert line["n_gpus"] == 8 and line["batch_per_gpu"] == 8192 and "65536" in line["workload"]

@@ -81,6 +81,21 @@ def test_c_host_sharded_on_two_emulated_devices(tmp_path):
     assert r.stdout.count("identical to the unsharded result") == 2
 
 
+def test_c_host_sharded_on_eight_emulated_devices(tmp_path):
+    """CPU: the driver's node shape -- FHE_EMU_DEVICES = 8, eight host threads, eight sets of handles / streams / buffers,
+    19 pairs cut into blocks of 3, 3, 3, 2, 2, 2, 2, 2; every block equals its slice of the one-call result."""
+    from helpers import build_emu
+    emu = build_emu()
+    exe = str(tmp_path / "c4_sharded_emu8")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-pthread", "-I", INC, SHARD_SRC, "-o", exe, emu,
+                           "-Wl,-rpath," + os.path.dirname(emu)])
+    env = dict(os.environ, FHE_EMU_DEVICES="8")
+    r = subprocess.run([exe, "4108648450", "1032193", "19", "0", "256"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), r.stdout + r.stderr
+    assert "devices 8 of 8 visible" in r.stdout and "[0, 3)" in r.stdout and "[17, 19)" in r.stdout, r.stdout
+    assert r.stdout.count("identical to the unsharded result") == 8
+
+
 @pytest.mark.gpu
 def test_c_host_sharded_over_all_visible_gpus(tmp_path):
     """GPU: C4's per-GPU shard size scaled to this box -- every visible device takes its block of 1,024 x G pairs (one

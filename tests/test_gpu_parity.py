@@ -334,6 +334,27 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["roofline"]["kernel_sum_le_step"] in (True, False) and line["roofline"]["traffic_observed_this_run"] is False
 
 
+def test_bench_eight_ranks_on_one_gpu():
+    """The world size the driver's SCALE run uses: `python bench.py --gpus 8` spawns eight ranks (they share this box's
+    one GPU and rendezvous over gloo): the spawn, the NUMA pinning, the identity gather, the solo / n1_reference legs and
+    the efficiency block at world size 8, on a batch small enough for eight processes on one device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--batch", "32", "--no-cpu", "--no-extras", "--sustain", "0.2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 256 and line["value"] > 0
+    mg = line["multi_gpu"]
+    assert len(mg["ranks"]) == 8 and {x["rank"] for x in mg["ranks"]} == set(range(8)) and mg["data_path_collectives"] == 0
+    assert mg["n1_reference"]["batch_32"]["value"] > 0 and mg["solo_rank0_ops_per_s"] > 0
+    assert len(line["per_rank"]["ops_per_s"]) == 8 and line["sustained"]["steps"] >= 20
+    assert "cpu_baseline" not in line and line["scaling"] == "weak"
+
+
 def test_max_degree_n65536(fhe):
     """Largest degree the reference accepts (parameters.rs MAX_DEGREE = 65536): ct x ct + relin,
     rows go through the two-kernel NTT and the unfused key switch."""

@@ -1795,10 +1795,10 @@ fhe_status fhe_prof_get(size_t index, char *name, size_t name_cap, uint64_t *lau
 // Lab builds only (not in the header): reads and clears the phase-timing slots of kernels.hpp.
 fhe_status fhe_debug_phase_timing(uint64_t *out, size_t n) {
     return guard([&] {
-        unsigned long long h[64] = {0}, z[64] = {0};
+        static unsigned long long h[FHE_TS_TOTAL_SLOTS], z[FHE_TS_TOTAL_SLOTS];
         FHE_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(fhe::k::g_phase_ts), sizeof(h)));
         FHE_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(fhe::k::g_phase_ts), z, sizeof(z)));
-        for (size_t i = 0; i < n && i < 64; i++) out[i] = h[i];
+        for (size_t i = 0; i < n && i < FHE_TS_TOTAL_SLOTS; i++) out[i] = h[i];
     });
 }
 #endif

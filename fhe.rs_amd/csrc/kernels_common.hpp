@@ -54,6 +54,9 @@ __device__ __forceinline__ u64x2 load_last2(const u64x2 *p) {
 #include "lab/phase_timing.hpp"
 #else
 #define FHE_TS(k) do { } while (0)
+#define FHE_TSK(k) do { } while (0)
+#define FHE_TS_BEGIN() do { } while (0)
+#define FHE_TS_END() do { } while (0)
 #endif
 
 // Maps a workgroup index to (polynomial, row) and to source/destination addresses.

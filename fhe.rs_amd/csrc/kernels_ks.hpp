@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
 #endif
     uint32_t item = blockIdx.x;
     if (item >= total) return;
+    FHE_TS_BEGIN();
     do {
     const uint32_t bj = item >> G0, sub = item & (NS - 1);
     const uint32_t b = to_sgpr(bj / lk), j = bj - b * lk;
@@ -144,6 +145,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
     }
     const uint32_t nloop = ndigits - (own ? 1u : 0u);          // digits that go through the transform
     auto digit_of = [&](uint32_t ii) -> uint32_t { return ii + ((own && ii >= j) ? 1u : 0u); };
+    FHE_TSK(20);   // item prologue: index arithmetic, accumulator clears, the caller's own Ntt row (xhat)
     // The workgroup is alone on its CU (LDS), so nothing else hides the row load: digit i+1's
     // row is fetched into registers while digit i goes through its passes.
     constexpr bool PREFETCH = ks_acc1_in_lds_tt(LOGN, TT);   // (needs the VGPRs the LDS accumulators free)
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
         const uint32_t i = digit_of(ii);
         const uint32_t tid = opaque(tid0);
         const uint32_t sh = i * digit_shift_bits;
-        FHE_TS(0);
+        FHE_TSK(0);
         // RNS instances: one conditional subtraction per coefficient.  The generic lambda keeps the shift, the mask
         // and three uniform branches PER ELEMENT (round 3, from the ISA).
         if constexpr (PREFETCH) {
@@ -280,9 +282,9 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                 tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return lift((v >> sh) & mask_i); });
             }
         }
-        FHE_TS(1);
+        FHE_TSK(1);
         FHE_BARRIER();
-        FHE_TS(2);
+        FHE_TSK(2);
         if constexpr (PREFETCH) {
             if (ii + 1 < nloop) {
                 const u64x2 *nx = reinterpret_cast<const u64x2 *>(src0 + (u64)digit_of(ii + 1) * dstride);
@@ -299,6 +301,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
             constexpr bool KPF = PREFETCH && CH >= 2;
             // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
             ntt_fwd_lds<LOGN, T, GM, FHE_KS_TWPF && LOGN == 13, !KPF, (NARROW ? (G0 ? 4 : 1) : 0), NoSrc, KS_LATE>(lds, twr, NS + sub, pm, tid);
+            FHE_TSK(7);
             // (all four chunks prefetched -- 118 VGPRs, no scratch: no change; three: 2 % slower.  ABBA runs in
             // profiles/r02_ks_kpf_ab.txt: the key words' latency is not what the MAC waits for)
             constexpr int KPFN = KPF ? (FHE_KS_KPF_CHUNKS < CH ? FHE_KS_KPF_CHUNKS : CH) : 0;   // chunks whose key words are prefetched
@@ -309,9 +312,9 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                     const uint32_t ci = c * T + tid;
                     kq[4 * c] = a0[ci], kq[4 * c + 1] = a0s[ci], kq[4 * c + 2] = a1[ci], kq[4 * c + 3] = a1s[ci];
                 }
-                FHE_TS(3);
+                FHE_TSK(3);
                 FHE_BARRIER();
-                FHE_TS(4);
+                FHE_TSK(4);
             }
 #pragma unroll
             for (int c = 0; c < CH; c++) {
@@ -346,9 +349,9 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
         }
         // (wave-contiguous chunk ownership, which makes this barrier and the one before the MAC wave-local as
         // well, was measured: nothing beyond what the late pass plan already gives)
-        FHE_TS(5);
+        FHE_TSK(5);
         FHE_BARRIER();
-        FHE_TS(6);
+        FHE_TSK(6);
     }
     // (FHE_DEBUG_KS_NOMEM -- every polynomial aliased to the first: rows, addends and outputs out of L2 -- makes this
     // kernel 11 % faster at C2: what its one workgroup per CU cannot hide.  Requesting the addends during the last
@@ -405,7 +408,9 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
         out0[ooff + tid] = r0;
         out1[ooff + tid] = r1;
     }
+    FHE_TSK(21);   // epilogue: next item's row prefetch, final reductions, addends, stores
     } while (ITEM_LOOP && (item += gridDim.x) < total);
+    FHE_TS_END();
 }
 
 // The same for rows that do not fit LDS (N = 2^(13+G0) >= 32768): one workgroup per (ciphertext,

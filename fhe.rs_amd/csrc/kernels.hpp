@@ -23,7 +23,7 @@
 //   phase_kernel, decrypt_tail_kernel   SecretKey::try_decrypt      F/bfv/keys/secret_key.rs:198-247
 //   wire_pack_kernel, wire_unpack_kernel  Rq payload bit packing    M/rq/convert.rs:17-99, fhe-util lib.rs:71-148
 //   synth_kernel            synthetic uniform residues (bench/test inputs)
-// Compile-time knobs live in knobs.hpp (pinned in the release build); rejected kernel variants in lab/ (lab builds only).
+// Compile-time knobs live in knobs.hpp (pinned in the release build); rejected kernel variants in tools/lab/ (lab builds only).
 #pragma once
 #include "kernels_common.hpp"
 #include "kernels_passes.hpp"

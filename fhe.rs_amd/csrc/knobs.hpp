@@ -4,7 +4,7 @@
 // written here are the ones the measurements of rounds 1-2 picked.  The release build
 // (__graft_entry__.build()) pins them: defining any of them on the command line without -DFHE_LAB is a compile error,
 // so a -D typo cannot ship a different kernel.  -DFHE_LAB builds (tools/ab_*.sh; never loaded by the package) may
-// override them, additionally compile the rejected kernels under csrc/lab/ and read FHE_LAB_* environment switches.
+// override them, additionally compile the rejected kernels under tools/lab/ (outside the product tree; tools/build_variant.sh adds -I tools) and read FHE_LAB_* environment switches.
 // The release library reads no environment variable at all.
 #pragma once
 

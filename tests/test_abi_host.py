@@ -59,13 +59,14 @@ def test_release_build_reads_no_environment(fhe):
     entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
     assert "FHE_LAB" not in entry
     csrc = os.path.join(ROOT, "fhe.rs_amd", "csrc")
-    shipped = [f for f in os.listdir(csrc) if os.path.isfile(os.path.join(csrc, f))]   # (csrc/lab/ is lab-only)
+    shipped = [f for f in os.listdir(csrc) if os.path.isfile(os.path.join(csrc, f))]   # (lab-only sources live in tools/lab/)
     assert {"kernels.hpp", "kernels_ntt.hpp", "kernels_ks.hpp", "kernels_scaler.hpp"} <= set(shipped)
     for f in shipped:
         text = open(os.path.join(csrc, f)).read()
         for rejected in ("ntt_fwd_swap_kernel<", "ntt_fwd8_kernel<", "ks_pair_kernel<", "FHE_SENS &", "getenv(\"FHE_DEBUG"):
             assert rejected not in text, (f, rejected)
-        if "lab/" in text:   # every include of a lab file sits behind the FHE_LAB guard
+        assert not os.path.isdir(os.path.join(csrc, "lab")), "lab sources belong in tools/lab/, not in the product tree"
+        if "lab/" in text:   # every include of a lab file (tools/lab/, found through -I tools in lab builds) sits behind the FHE_LAB guard
             for m in re.finditer(r'#include "lab/', text):
                 assert "#if defined(FHE_LAB)" in text[max(0, m.start() - 200):m.start()], f
 

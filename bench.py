@@ -436,6 +436,24 @@ def reference_bench_ids(fhe, torch, par, rk, batch, timeit):
     out["rq/mul_shoup_assign"] = dict(polys_per_s=round(batch * 2 / ms * 1e3, 1), ms=round(ms, 3),
                                       GBps=round(batch * 2 * 4 * L * R / ms / 1e6, 1),
                                       frac=round(batch * 2 * 4 * L * R / ms / 1e6 / HBM_PEAK_GBS, 4))
+    # fhe-math/benches/rq.rs:120-148 (`rq_add_assign`, `rq_sub_assign`, `rq_mul_assign`, `rq_neg`: element-wise on Ntt polys;
+    # the non-assign forms compute the same values into a new Poly) and benches/zq.rs:10-57 (the same operations on one
+    # residue row: a Poly with one modulus).  Bytes: two operands read, one written (neg: one read, one written).
+    other = b.view(batch * 2, L, n)
+    for name, fn, rows_rw in (("rq_add_assign", lambda: ctx.add(polys, other), 3), ("rq_sub_assign", lambda: ctx.sub(polys, other), 3),
+                              ("rq_mul_assign", lambda: ctx.mul(polys, other), 3), ("rq_neg", lambda: ctx.neg(polys), 2)):
+        ms = timeit(fn)
+        out[f"rq/{name}"] = dict(polys_per_s=round(batch * 2 / ms * 1e3, 1), ms=round(ms, 3),
+                                 GBps=round(batch * 2 * rows_rw * L * R / ms / 1e6, 1),
+                                 frac=round(batch * 2 * rows_rw * L * R / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                 workload=f"{batch * 2} polys of {L} x {n}; zq/*_vec is the same kernel on one row")
+    # rq_dot_product/opt (rq.rs:150-195): 256 x 256 polynomial dot product, L = 4
+    pv, qv = ctx.synth_uniform(SEED, 0, 0, 1, 256), ctx.synth_uniform(SEED, 300, 0, 1, 256).reshape(256, L, n)
+    ms = timeit(lambda: ctx.dot_product_scalar(pv, qv))
+    out["rq_dot_product/opt/256"] = dict(ms=round(ms, 4), dot_products_per_s=round(1e3 / ms, 1),
+                                         GBps=round((2 * 256 + 1) * L * R / ms / 1e6, 1),
+                                         note="ONE dot product of 256 polynomial pairs per call (Criterion's shape): a launch that does not fill the device")
+    del pv, qv
     ms = timeit(lambda: ctx.ntt_backward(polys))
     out["rq/change_representation/Ntt_to_PowerBasis"] = dict(
         poly_ntt_per_s=round(batch * 2 / ms * 1e3, 1), row_ntt_per_s=round(batch * 2 * L / ms * 1e3, 1), ms=round(ms, 3),

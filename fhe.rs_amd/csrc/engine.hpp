@@ -680,21 +680,28 @@ inline bool lab_try_ks_pair(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
                             const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s);
 #endif
 
-template <bool INV, bool NARROW = false>
+template <bool INV, bool NARROW = false, bool GATHER = false>
 inline void launch_ntt_lds(const char *name, uint32_t logm, unsigned grid, hipStream_t s, const u64 *in, u64 *out,
                            const k::RowMap &map, const DevMod *mods, const k::u64x2 *tw, const k::u64x2 *ninv,
                            uint32_t logn) {
     const size_t lds = k::lds_words(1u << logm) * sizeof(u64);
 #define FHE_NTT_CASE(LM)                                                                                        \
     case LM:                                                                                                    \
-        allow_big_lds((k::ntt_kernel<INV, LM, NARROW>), lds);                                                   \
-        FHE_LAUNCH(name, (k::ntt_kernel<INV, LM, NARROW>), dim3(grid), dim3(k::ntt_threads_c(LM)), lds, s, in,   \
+        allow_big_lds((k::ntt_kernel<INV, LM, NARROW, 1, GATHER>), lds);                                        \
+        FHE_LAUNCH(name, (k::ntt_kernel<INV, LM, NARROW, 1, GATHER>), dim3(grid), dim3(k::ntt_threads_c(LM)), lds, s, in, \
                    out, map, mods, tw, ninv, logn);                                                             \
         break;
-    switch (logm) {
-        FHE_NTT_CASE(3) FHE_NTT_CASE(4) FHE_NTT_CASE(5) FHE_NTT_CASE(6) FHE_NTT_CASE(7) FHE_NTT_CASE(8)
-        FHE_NTT_CASE(9) FHE_NTT_CASE(10) FHE_NTT_CASE(11) FHE_NTT_CASE(12) FHE_NTT_CASE(13) FHE_NTT_CASE(14)
-        default: throw StatusError(E_ARG, "unsupported NTT tile size");
+    if constexpr (GATHER) {   // (galois_apply folds the substitution from N = 4096 on: three tile sizes)
+        switch (logm) {
+            FHE_NTT_CASE(12) FHE_NTT_CASE(13) FHE_NTT_CASE(14)
+            default: throw StatusError(E_ARG, "unsupported NTT tile size for the gathering loader");
+        }
+    } else {
+        switch (logm) {
+            FHE_NTT_CASE(3) FHE_NTT_CASE(4) FHE_NTT_CASE(5) FHE_NTT_CASE(6) FHE_NTT_CASE(7) FHE_NTT_CASE(8)
+            FHE_NTT_CASE(9) FHE_NTT_CASE(10) FHE_NTT_CASE(11) FHE_NTT_CASE(12) FHE_NTT_CASE(13) FHE_NTT_CASE(14)
+            default: throw StatusError(E_ARG, "unsupported NTT tile size");
+        }
     }
 #undef FHE_NTT_CASE
 }
@@ -724,7 +731,12 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
             bool narrow = !FHE_LAB_FLAG("NO_NARROW");
             for (uint32_t r = 0; r < map.rows; r++)
                 narrow = narrow && (c.root->moduli[(size_t)((int32_t)(map.row_begin + r) + map.mod_offset)] >> 60) == 0;
-            if (narrow)
+            if (map.subst_exp) {   // the source rows are read through the substitution x -> x^subst_exp (galois_apply)
+                if (narrow)
+                    launch_ntt_lds<true, true, true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
+                else
+                    launch_ntt_lds<true, false, true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
+            } else if (narrow)
                 launch_ntt_lds<true, true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(),
                                            logn);
             else
@@ -743,6 +755,7 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     inplace.src_poly_stride = map.dst_poly_stride;
     inplace.src_row_fixed = -1;
     inplace.in2 = nullptr;   // (the second half of the transform works in `out`: one array)
+    inplace.subst_exp = 0;
     if (!inverse) {
         if (g0 == 2)
             FHE_LAUNCH("ntt_fwd_global", (k::ntt_global_kernel<false, 2>), dim3(gblocks), dim3(gth), 0, s, in, out,
@@ -760,7 +773,12 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
                                   logn);
         }
     } else {
-        if (narrow)
+        if (map.subst_exp) {
+            if (narrow)
+                launch_ntt_lds<true, true, true>("ntt_inv", logm, rows_total << g0, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
+            else
+                launch_ntt_lds<true, false, true>("ntt_inv", logm, rows_total << g0, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
+        } else if (narrow)
             launch_ntt_lds<true, true>("ntt_inv", logm, rows_total << g0, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
         else
             launch_ntt_lds<true>("ntt_inv", logm, rows_total << g0, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
@@ -789,6 +807,7 @@ inline k::RowMap full_map(const Ctx &c, size_t rows_in_poly) {
     m.in2 = nullptr;
     m.split = 0;
     m.reverse = 0;
+    m.subst_exp = 0;
     return m;
 }
 
@@ -1278,10 +1297,10 @@ inline void ksk_validate(const Ctx &ct_ctx, const Ctx &ksk_ctx, size_t ndigits, 
 template <int LOGN>
 inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
                             const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s,
-                            const u64 *xhat, u64 xhat_stride) {
+                            const u64 *xhat, u64 xhat_stride, uint32_t gal) {
     const Ctx &kc = *k_.ksk_ctx;
 #if defined(FHE_LAB)
-    if (lab_try_ks_pair<LOGN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s)) return;   // lab/lab_engine.hpp
+    if (!gal && lab_try_ks_pair<LOGN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s)) return;   // lab/lab_engine.hpp
 #endif
     const size_t lds = (k::lds_words(1u << LOGN) + (k::ks_acc1_in_lds_c(LOGN) ? (size_t)1 << LOGN : 0)) * sizeof(u64);
     // key moduli below 2^60: the transform runs without most conditional subtractions (fwd_butterfly_narrow)
@@ -1305,12 +1324,26 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     // round 3 that instance spilled 52 B; it no longer does, and measured again at C3 in round 4 it changes nothing --
     // relinearise of 512: 4.09 / 4.18 / 4.18 ms against 4.17 / 4.14 / 4.13, profiles/r04_ks14_rns_ab.jsonl.)
     const bool rns = (LOGN == 12 || LOGN == 13) && k_.digit_arg() == (1u << 8);
-#define FHE_KS_LAUNCH_R(NW, GMV, RNS)                                                                                 \
-    allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 0, RNS>), lds);                                                  \
-    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV, 0, RNS>), dim3(ks_grid),                        \
+#define FHE_KS_LAUNCH_G(NW, GMV, RNS, GALV)                                                                           \
+    allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 0, RNS, 0, GALV>), lds);                                         \
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV, 0, RNS, 0, GALV>), dim3(ks_grid),               \
                dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p,       \
                k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L,               \
-               k_.digit_arg(), xhat, xhat_stride, (uint32_t)(npolys * kc.L))
+               k_.digit_arg(), xhat, xhat_stride, (uint32_t)(npolys * kc.L), gal)
+    // (the Galois instances exist from N = 4096 on: galois_apply folds the substitution only there)
+#define FHE_KS_LAUNCH_R(NW, GMV, RNS)                                                                                 \
+    do {                                                                                                              \
+        if constexpr (LOGN >= 12) {                                                                                   \
+            if (gal) {                                                                                                \
+                FHE_KS_LAUNCH_G(NW, GMV, RNS, true);                                                                  \
+            } else {                                                                                                  \
+                FHE_KS_LAUNCH_G(NW, GMV, RNS, false);                                                                 \
+            }                                                                                                         \
+        } else {                                                                                                      \
+            require(!gal, E_ARG, "folded Galois substitution below N = 4096");                                        \
+            FHE_KS_LAUNCH_G(NW, GMV, RNS, false);                                                                     \
+        }                                                                                                             \
+    } while (0)
 #define FHE_KS_LAUNCH(NW, GMV)                                                                                        \
     do {                                                                                                              \
         if constexpr (LOGN == 12 || LOGN == 13) {                                                                     \
@@ -1335,7 +1368,7 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 512, RNS>), lds2);                                            \
     FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV, 512, RNS>), dim3(grid2), dim3(512), lds2, s, \
                p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p,            \
-               kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, grid2)
+               kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, grid2, gal)
 #define FHE_KS_T512(NW, GMV)                                                                                       \
     do {                                                                                                           \
         if (rns) {                                                                                                 \
@@ -1369,7 +1402,7 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 512, true>), lds2);                                               \
     FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV, 512, true>), dim3(grid2), dim3(512), lds2, s, p, \
                p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(),       \
-               kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, grid2)
+               kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, grid2, gal)
             if (t512 == 2) {
                 if (narrow) { FHE_KS14_T512(true, 3); } else { FHE_KS14_T512(false, 3); }
             } else {
@@ -1405,6 +1438,7 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     }
 #undef FHE_KS_LAUNCH
 #undef FHE_KS_LAUNCH_R
+#undef FHE_KS_LAUNCH_G
     (void)rns;
 }
 
@@ -1466,7 +1500,7 @@ inline void launch_ks_ntt(const Ksk &k_, bool narrow, bool rns, unsigned grid, h
 }
 inline void key_switch_polys_unfused(const Ksk &k_, int mode, const u64 *p, u64 p_stride, u64 *o0, u64 *o1,
                                      u64 out_stride, const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys,
-                                     hipStream_t s, const u64 *xhat, u64 xhat_stride) {
+                                     hipStream_t s, const u64 *xhat, u64 xhat_stride, uint32_t gal) {
     const Ctx &kc = *k_.ksk_ctx;
     const size_t N = kc.n, nd = k_.ndigits, Lk = kc.L;
     const uint32_t logn = (uint32_t)kc.logn;
@@ -1523,7 +1557,7 @@ inline void key_switch_polys_unfused(const Ksk &k_, int mode, const u64 *p, u64 
             FHE_LAUNCH("ks_mac", k::ks_mac_kernel, dim3(grid_b), dim3(256), 0, s, w.u(), o0 + b0 * out_stride,
                        o1 + b0 * out_stride, out_stride, a0 ? a0 + b0 * a_stride : nullptr, a1 ? a1 + b0 * a_stride : nullptr,
                        a_stride, k_.c0.p, k_.c1.p, kc.dmods(), (uint32_t)nd, (uint32_t)Lk, (uint32_t)j0, (uint32_t)njg, logn,
-                       xhat ? xhat + b0 * xhat_stride : nullptr, xhat_stride, (uint32_t)nb);
+                       xhat ? xhat + b0 * xhat_stride : nullptr, xhat_stride, (uint32_t)nb, gal);
         }
     }
 }
@@ -1534,17 +1568,20 @@ inline void key_switch_polys_unfused(const Ksk &k_, int mode, const u64 *p, u64 
 // xhat (optional, poly stride xhat_stride): the same polynomials in Ntt form, when the caller has them (it
 // produced p by an inverse transform): row j of xhat is digit j's transform under key modulus j, which the
 // kernels then read instead of recomputing (L of the L * Lk transforms).
+// gal != 0 (galois_apply): `xhat` and `a0` are the caller's UNPERMUTED Ntt rows, read through the substitution
+// x -> x^gal inside the kernels (needs xhat; a1 must be null).
 inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
                              const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s,
-                             const u64 *xhat = nullptr, u64 xhat_stride = 0) {
-    if (FHE_LAB_FLAG("NO_KS_XHAT")) xhat = nullptr;
+                             const u64 *xhat = nullptr, u64 xhat_stride = 0, uint32_t gal = 0) {
+    if (FHE_LAB_FLAG("NO_KS_XHAT") && !gal) xhat = nullptr;
+    require(!gal || (xhat != nullptr && a1 == nullptr), E_ARG, "galois key switch: needs the Ntt rows, adds to c0 only");
     const Ctx &kc = *k_.ksk_ctx;
     kc.need_device();
     if (!npolys) return;
     {
         const int mode = k_.mode.load(std::memory_order_relaxed);
         if (ks_use_unfused(k_, mode, npolys)) {
-            key_switch_polys_unfused(k_, mode, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride);
+            key_switch_polys_unfused(k_, mode, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride, gal);
             return;
         }
     }
@@ -1556,7 +1593,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     static const bool half13 = FHE_LAB_INT("KS_HALF13", 0) != 0;
     if (kc.logn <= 12 || (kc.logn == 13 && !half13) || (kc.logn == 14 && !split14)) {
 #define FHE_KS_CASE(LN) \
-    case LN: launch_ks_fused<LN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride); break;
+    case LN: launch_ks_fused<LN>(k_, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride, gal); break;
         switch (kc.logn) {
             FHE_KS_CASE(3) FHE_KS_CASE(4) FHE_KS_CASE(5) FHE_KS_CASE(6) FHE_KS_CASE(7) FHE_KS_CASE(8)
             FHE_KS_CASE(9) FHE_KS_CASE(10) FHE_KS_CASE(11) FHE_KS_CASE(12) FHE_KS_CASE(13) FHE_KS_CASE(14)
@@ -1583,12 +1620,20 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
         const size_t lds_ = k::lds_words(1u << 14) * sizeof(u64);
         const unsigned grid = (unsigned)((npolys * kc.L) << (kc.logn - 14));
         const bool rns = half15 == 2 && k_.digit_arg() == (1u << 8);
-#define FHE_KS_HALF15_LAUNCH(NW, RNS, G0)                                                                             \
-    allow_big_lds((k::ks_fused_kernel<14, NW, k::GM_MIXED, 0, RNS, G0>), lds_);                                       \
-    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<14, NW, k::GM_MIXED, 0, RNS, G0>), dim3(grid),                 \
+#define FHE_KS_HALF15_LAUNCH_G(NW, RNS, G0, GALV)                                                                     \
+    allow_big_lds((k::ks_fused_kernel<14, NW, k::GM_MIXED, 0, RNS, G0, GALV>), lds_);                                 \
+    FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<14, NW, k::GM_MIXED, 0, RNS, G0, GALV>), dim3(grid),           \
                dim3(k::ks_threads_c(14)), lds_, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, \
                k_.c1.p, k_.c1s.p, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat,   \
-               xhat_stride, grid)
+               xhat_stride, grid, gal)
+#define FHE_KS_HALF15_LAUNCH(NW, RNS, G0)                                                                             \
+    do {                                                                                                              \
+        if (gal) {                                                                                                    \
+            FHE_KS_HALF15_LAUNCH_G(NW, RNS, G0, true);                                                                \
+        } else {                                                                                                      \
+            FHE_KS_HALF15_LAUNCH_G(NW, RNS, G0, false);                                                               \
+        }                                                                                                             \
+    } while (0)
 #define FHE_KS_HALF15_PICK(G0)                                                                                        \
     if (narrow) {                                                                                                     \
         if (rns) { FHE_KS_HALF15_LAUNCH(true, true, G0); } else { FHE_KS_HALF15_LAUNCH(true, false, G0); }            \
@@ -1598,6 +1643,7 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
         if (kc.logn == 15) { FHE_KS_HALF15_PICK(1) } else { FHE_KS_HALF15_PICK(2) }
 #undef FHE_KS_HALF15_PICK
 #undef FHE_KS_HALF15_LAUNCH
+#undef FHE_KS_HALF15_LAUNCH_G
         return;
     }
     // 8192-point sub-blocks, logn - 13 folded stages (ks_fused_split_kernel; rounds 1-3: every launch)
@@ -1609,13 +1655,13 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
             FHE_LAUNCH("key_switch_fused_sub", (k::ks_fused_split_kernel<G0, LM, NW, true>),                           \
                        dim3((unsigned)((npolys * kc.L) << G0)), dim3((1u << LM) / 8), lds_, s, p, p_stride, o0,    \
                        o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(),         \
-                       kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride);         \
+                       kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, gal);    \
         } else {                                                                                                   \
             allow_big_lds((k::ks_fused_split_kernel<G0, LM, NW, false>), lds_);                                    \
             FHE_LAUNCH("key_switch_fused_sub", (k::ks_fused_split_kernel<G0, LM, NW, false>),                          \
                        dim3((unsigned)((npolys * kc.L) << G0)), dim3((1u << LM) / 8), lds_, s, p, p_stride, o0,    \
                        o1, out_stride, a0, a1, a_stride, k_.c0.p, k_.c0s.p, k_.c1.p, k_.c1s.p, kc.dmods(),         \
-                       kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride);         \
+                       kc.dtw(), (uint32_t)k_.ndigits, (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, gal);    \
         }                                                                                                          \
     } while (0)
 #define FHE_KS_SPLIT_LAUNCH(G0, NW) FHE_KS_SPLIT_LAUNCH_M(G0, 13, NW)
@@ -1695,13 +1741,14 @@ inline void switch_down_to_ntt(const Ctx &from, size_t iters, const u64 *in, u64
 // out0/out1 [npolys][Lct][N] (poly stride out_stride) = a + switch_down_to(key_switch(p), ct_ctx)
 inline void key_switch_add(const Ksk &k_, const u64 *p, u64 p_stride, const u64 *a0, const u64 *a1, u64 a_stride,
                            u64 *out0, u64 *out1, u64 out_stride, size_t npolys, hipStream_t s,
-                           const u64 *xhat = nullptr, u64 xhat_stride = 0) {
+                           const u64 *xhat = nullptr, u64 xhat_stride = 0, uint32_t gal = 0) {
     const Ctx &kc = *k_.ksk_ctx, &cc = *k_.ct_ctx;
     const long iters = kc.niterations_to(cc);
     if (iters == 0) {
-        key_switch_polys(k_, p, p_stride, out0, out1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride);
+        key_switch_polys(k_, p, p_stride, out0, out1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride, gal);
         return;
     }
+    require(!gal, E_ARG, "the folded Galois substitution needs the key at the ciphertext's level");
     const u64 kstride = (u64)kc.L * kc.n, cstride = (u64)cc.L * cc.n;
     WsGuard r0(npolys * kstride * sizeof(u64), s), r1(npolys * kstride * sizeof(u64), s);
     WsGuard d0(npolys * cstride * sizeof(u64), s), d1(npolys * cstride * sizeof(u64), s);
@@ -1769,6 +1816,26 @@ inline void galois_apply(const Ksk &ks, size_t exponent, const u64 *ct, u64 *out
     const Ctx &cc = *ks.ct_ctx;
     const u64 PL = (u64)cc.L * cc.n;
     if (!batch) return;
+    const size_t e = exponent % (2 * cc.n);
+    require((e & 1) == 1, E_INVALID_SUBST, "InvalidSubstitutionExponent");
+    // Round 5: no separate permutation pass from N = 4096 on when the key sits at the ciphertext's level (every
+    // EvaluationKey the reference builds by default; smaller rows keep the copying path and its kernel instances) -- the Ntt-domain substitution is a gather, and its three consumers read through it:
+    //   c2 = PowerBasis(substitute(c1))     the inverse transform's loader            (ntt_kernel<true, ..., GATHER>)
+    //   digit j under key modulus j         = row j of substitute(c1): the key switch's own-row read
+    //   out0 = key_switch0 + substitute(c0) the key switch's addend read              (galois_key.rs:66-79)
+    // (before: substitute_kernel wrote both permuted parts -- 2 polynomials out, 3 row sets read back: 9 % of a rotation)
+    // (the consumers gather from `ct` while `out` is being written: a caller that rotates in place takes the copying path)
+    const bool overlap = out < ct + batch * 2 * PL && ct < out + batch * 2 * PL;
+    if (cc.logn >= 12 && ks.ksk_ctx->niterations_to(cc) == 0 && !overlap && !FHE_LAB_FLAG("NO_GALOIS_FOLD")) {
+        WsGuard c2(batch * PL * sizeof(u64), s);
+        k::RowMap m = full_map(cc, cc.L);
+        m.src_poly_stride = 2 * PL;
+        m.dst_poly_stride = PL;
+        m.subst_exp = (uint32_t)e;
+        launch_ntt(cc, true, ct + PL, c2.u(), m, batch, s);
+        key_switch_add(ks, c2.u(), PL, ct, nullptr, 2 * PL, out, out + PL, 2 * PL, batch, s, ct + PL, 2 * PL, (uint32_t)e);
+        return;
+    }
     // substitute both parts at once: sub [b][2][L][N]; c2 = PowerBasis(substitute(c1))
     WsGuard sub(batch * 2 * PL * sizeof(u64), s), c2(batch * PL * sizeof(u64), s);
     substitute_polys(cc, exponent, ct, sub.u(), batch * 2, true, s);

@@ -77,6 +77,10 @@ struct RowMap {
     // workgroups walk the launch's tiles from the last one backwards (the producer of `in` ran ascending, so its
     // most recent output -- what still sits in the Infinity Cache -- is at the end)
     uint32_t reverse;
+    // ntt_kernel<true, ..., GATHER = true> only (round 5): the source row is read through the Ntt-domain substitution
+    // x -> x^subst_exp (Poly::substitute, M/rq/mod.rs:360-412) -- element d of the row the transform works on is element
+    // galois_src_index(d) of the stored row -- so that a Galois rotation needs no separate permutation pass
+    uint32_t subst_exp;
 };
 // the source polynomial of workgroup-uniform index `poly`
 __device__ __forceinline__ const u64 *rowmap_src(const RowMap &map, const u64 *in, uint32_t poly) {
@@ -84,6 +88,23 @@ __device__ __forceinline__ const u64 *rowmap_src(const RowMap &map, const u64 *i
                                                      : in + (u64)poly * map.src_poly_stride;
 }
 
+
+// Ntt-domain substitution x -> x^e as a gather (M/rq/mod.rs:389-402: q[bitrev(j)] = p[bitrev((e-1)/2 + j e mod N)]):
+// the source index of destination element d of a row of 2^logn points.
+FHE_HD uint32_t bitrev_n(uint32_t v, uint32_t logn) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v) >> (32 - logn);
+#else
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < logn; i++) r |= ((v >> i) & 1u) << (logn - 1 - i);
+    return r;
+#endif
+}
+FHE_HD uint32_t galois_src_index(uint32_t d, uint32_t e, uint32_t logn) {
+    const uint32_t mask = (1u << logn) - 1;
+    const uint32_t jj = bitrev_n(d, logn);
+    return bitrev_n((uint32_t)(((u64)(e - 1) / 2 + (u64)jj * e) & mask), logn);
+}
 
 // LDS padding: one extra u64 every 16 keeps the 16-element-strided accesses of the last
 // radix pass (lane stride 128 B) on distinct banks (ds_read_b64: 64 banks x 4 B, conflicts

@@ -34,14 +34,20 @@ constexpr int ks_min_waves(int logn, int tt) { return (logn == 14 && tt == 512) 
 // for their two folded stages (C5 relinearise 1.46 -> 1.25 ms, profiles/r04_ks_half15_ab.txt); G0 = 2: three products
 // instead of the seven of eight 8192-point parts.  The remaining LOGN stages run in LDS with twiddle base 2^G0 + sub.
 // Workgroups are (ciphertext, key modulus, part).
-template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false, int G0 = 0>
+// GAL (round 5): the instance GaloisKey::relinearize launches -- see `gal` below.  A template flag, not a runtime branch:
+// with the gathers behind `if (gal)` EVERY instance spilled (72-96 B of scratch at N = 8192, 532-548 B at N = 16384, whose
+// digit loop sits at 124 of 128 VGPRs); the relinearisation / multiply instances are the round-4 kernels, bit for bit.
+template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false, int G0 = 0, bool GAL = false>
 __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT))
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
                     u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
                     u64 addend_poly_stride, const u64 *__restrict__ k0, const u64 *__restrict__ k0s,
                     const u64 *__restrict__ k1, const u64 *__restrict__ k1s, const DevMod *__restrict__ mods,
                     const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk, uint32_t digit_arg,
-                    const u64 *__restrict__ xhat, u64 xhat_poly_stride, uint32_t total) {
+                    const u64 *__restrict__ xhat, u64 xhat_poly_stride, uint32_t total, uint32_t gal) {
+    // gal (round 5; GAL instances only, otherwise ignored): GaloisKey::relinearize (F/bfv/keys/galois_key.rs:63-86) -- `xhat` and `addend0` are the
+    // caller's UNPERMUTED Ntt rows (c1 and c0) and are read through the substitution x -> x^gal (galois_src_index):
+    // the rotation's separate permutation pass is gone.  Block-uniform; only the item prologue and epilogue look at it.
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ks_threads_tt(LOGN, TT);
     constexpr int N = 1 << LOGN;             // the tile: the whole row, or (G0 = 1) one half of it
@@ -125,7 +131,14 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
 #pragma unroll
             for (int c = 0; c < CH; c++) {
                 const uint32_t ci = c * T + tid0;
-                const u64x2 v = reinterpret_cast<const u64x2 *>(xr)[ci];
+                u64x2 v;
+                if constexpr (GAL) {
+                    const uint32_t d = (uint32_t)suboff + 2 * ci;
+                    v.x = (xr - suboff)[galois_src_index(d, gal, LOGN + G0)];
+                    v.y = (xr - suboff)[galois_src_index(d + 1, gal, LOGN + G0)];
+                } else {
+                    v = reinterpret_cast<const u64x2 *>(xr)[ci];
+                }
                 const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
                 acc0[2 * c] = mul_shoup_lazy_n(v.x, q0.x, q0s.x, pm.np);        // below 2p, like every accumulator value
                 acc0[2 * c + 1] = mul_shoup_lazy_n(v.y, q0.y, q0s.y, pm.np);
@@ -138,7 +151,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                 }
             }
         } else if (tid0 < N) {
-            const u64 v = xr[tid0];
+            const u64 v = GAL ? xr[galois_src_index(tid0, gal, LOGN)] : xr[tid0];   // (CH == 0: whole small rows, G0 == 0)
             acc0[0] = mul_shoup_lazy_n(v, k0[koff + tid0], k0s[koff + tid0], pm.np);
             acc1[0] = mul_shoup_lazy_n(v, k1[koff + tid0], k1s[koff + tid0], pm.np);
         }
@@ -389,7 +402,15 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
             r1.x = csub_n(a1.x, p, pm.np);
             r1.y = csub_n(a1.y, p, pm.np);
             if (d0) {
-                const u64x2 a = d0[ci];
+                u64x2 a;
+                if constexpr (GAL) {
+                    const u64 *arow = addend0 + aoff - suboff;
+                    const uint32_t d = (uint32_t)suboff + 2 * ci;
+                    a.x = arow[galois_src_index(d, gal, LOGN + G0)];
+                    a.y = arow[galois_src_index(d + 1, gal, LOGN + G0)];
+                } else {
+                    a = d0[ci];
+                }
                 r0.x = add_mod_n(r0.x, a.x, pm);
                 r0.y = add_mod_n(r0.y, a.y, pm);
             }
@@ -403,7 +424,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
         }
     } else if (tid < N) {
         u64 r0 = csub(acc0[0], p), r1 = csub(acc1[0], p);
-        if (addend0) r0 = add_mod(r0, addend0[aoff + tid], p);
+        if (addend0) r0 = add_mod(r0, addend0[aoff + (GAL ? galois_src_index(tid, gal, LOGN) : tid)], p);
         if (addend1) r1 = add_mod(r1, addend1[aoff + tid], p);
         out0[ooff + tid] = r0;
         out1[ooff + tid] = r1;
@@ -427,8 +448,8 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
                           const u64 *__restrict__ addend1, u64 addend_poly_stride, const u64 *__restrict__ k0,
                           const u64 *__restrict__ k0s, const u64 *__restrict__ k1, const u64 *__restrict__ k1s,
                           const DevMod *__restrict__ mods, const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t lk,
-                          uint32_t digit_arg, const u64 *__restrict__ xhat, u64 xhat_poly_stride) {
-    FHE_DYN_SMEM(u64, lds);
+                          uint32_t digit_arg, const u64 *__restrict__ xhat, u64 xhat_poly_stride, uint32_t gal) {
+    FHE_DYN_SMEM(u64, lds);   // (gal: see ks_fused_kernel)
     constexpr int M = 1 << LOGM, T = M / 8, CH = M / (2 * T), NS = 1 << G0;
     constexpr u64 N = (u64)M << G0;
     const uint32_t tid0 = threadIdx.x;
@@ -461,7 +482,16 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const uint32_t ci = c * T + tid0;
-            const u64x2 v = xr[ci], q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+            u64x2 v;
+            if (gal) {
+                const u64 *xrow = xhat + (u64)b * xhat_poly_stride + (u64)j * N;
+                const uint32_t d = sub * M + 2 * ci;
+                v.x = xrow[galois_src_index(d, gal, LOGM + G0)];
+                v.y = xrow[galois_src_index(d + 1, gal, LOGM + G0)];
+            } else {
+                v = xr[ci];
+            }
+            const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
             acc0[2 * c] = mul_shoup_lazy_n(v.x, q0.x, q0s.x, pm.np);
             acc0[2 * c + 1] = mul_shoup_lazy_n(v.y, q0.y, q0s.y, pm.np);
             acc1_lds[ci] = u64x2{mul_shoup_lazy_n(v.x, q1.x, q1s.x, pm.np), mul_shoup_lazy_n(v.y, q1.y, q1s.y, pm.np)};
@@ -555,7 +585,15 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
         r1.x = csub_n(a1v.x, p, pm.np);
         r1.y = csub_n(a1v.y, p, pm.np);
         if (d0) {
-            const u64x2 a = d0[ci];
+            u64x2 a;
+            if (gal) {
+                const u64 *arow = addend0 + (u64)b * addend_poly_stride + (u64)j * N;
+                const uint32_t d = sub * M + 2 * ci;
+                a.x = arow[galois_src_index(d, gal, LOGM + G0)];
+                a.y = arow[galois_src_index(d + 1, gal, LOGM + G0)];
+            } else {
+                a = d0[ci];
+            }
             r0.x = add_mod_n(r0.x, a.x, pm);
             r0.y = add_mod_n(r0.y, a.y, pm);
         }
@@ -662,7 +700,7 @@ __global__ void __launch_bounds__(256)
                   const u64 *__restrict__ addend0, const u64 *__restrict__ addend1, u64 addend_poly_stride,
                   const u64 *__restrict__ k0, const u64 *__restrict__ k1, const DevMod *__restrict__ mods,
                   uint32_t ndigits, uint32_t lk, uint32_t j0, uint32_t jg, uint32_t logn, const u64 *__restrict__ xhat,
-                  u64 xhat_poly_stride, uint32_t npolys) {
+                  u64 xhat_poly_stride, uint32_t npolys, uint32_t gal) {   // (gal: see ks_fused_kernel)
     const uint32_t n = 1u << logn;
     const uint32_t cpr = n >= 512 ? n / 512 : 1;          // 256-lane chunks per row
     const uint32_t nkr = jg * cpr;                        // key ranges of this launch
@@ -691,9 +729,18 @@ __global__ void __launch_bounds__(256)
 #pragma unroll 4
         for (uint32_t i = i0; i < i1; i++) {
             // (W is read exactly once, by this lane: a streaming load; the key words are every polynomial's: cached)
-            const u64x2 xv = (own && i == j)
-                                 ? *reinterpret_cast<const u64x2 *>(xhat + (u64)b * xhat_poly_stride + (u64)j * n + roff)
-                                 : load_stream(reinterpret_cast<const u64x2 *>(wp + (u64)i * jg * n));
+            u64x2 xv;
+            if (own && i == j) {
+                const u64 *xrow = xhat + (u64)b * xhat_poly_stride + (u64)j * n;
+                if (gal) {
+                    xv.x = xrow[galois_src_index((uint32_t)roff, gal, logn)];
+                    xv.y = xrow[galois_src_index((uint32_t)roff + 1, gal, logn)];
+                } else {
+                    xv = *reinterpret_cast<const u64x2 *>(xrow + roff);
+                }
+            } else {
+                xv = load_stream(reinterpret_cast<const u64x2 *>(wp + (u64)i * jg * n));
+            }
             const u64x2 q0 = *reinterpret_cast<const u64x2 *>(kp0 + (u64)i * lk * n);
             const u64x2 q1 = *reinterpret_cast<const u64x2 *>(kp1 + (u64)i * lk * n);
             mac(a0x, xv.x, q0.x);
@@ -710,7 +757,14 @@ __global__ void __launch_bounds__(256)
     const u64 ooff = (u64)b * out_poly_stride + (u64)j * n + roff;
     const u64 aoff = (u64)b * addend_poly_stride + (u64)j * n + roff;
     if (addend0) {
-        const u64x2 a = *reinterpret_cast<const u64x2 *>(addend0 + aoff);
+        u64x2 a;
+        if (gal) {
+            const u64 *arow = addend0 + aoff - roff;
+            a.x = arow[galois_src_index((uint32_t)roff, gal, logn)];
+            a.y = arow[galois_src_index((uint32_t)roff + 1, gal, logn)];
+        } else {
+            a = *reinterpret_cast<const u64x2 *>(addend0 + aoff);
+        }
         r0.x = add_mod(r0.x, a.x, md.p);
         r0.y = add_mod(r0.y, a.y, md.p);
     }

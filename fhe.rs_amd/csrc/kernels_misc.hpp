@@ -49,10 +49,7 @@ __global__ void substitute_kernel(const u64 *__restrict__ in, u64 *__restrict__ 
     u64 *dst = out + poly * out_poly_stride + (u64)r * n;
     if (repr_is_ntt) {
         // q[bitrev[j]] = p[bitrev((e-1)/2 + j*e mod N)]; index the gather by destination d = bitrev(j)
-        const uint32_t d = j;
-        const uint32_t jj = __brev(d) >> (32 - logn);
-        const uint32_t srci = (uint32_t)(((u64)(exponent - 1) / 2 + (u64)jj * exponent) & mask);
-        dst[d] = src[__brev(srci) >> (32 - logn)];
+        dst[j] = src[galois_src_index(j, exponent, logn)];
     } else {
         const u64 power = (u64)j * exponent;
         const u64 v = src[j];

@@ -18,7 +18,10 @@ namespace k {
 // NARROW (forward, whole row, every modulus of the launch below 2^60): see fwd_butterfly_narrow.
 // FWD_B0 (forward, NARROW): the loader's values are below FWD_B0 * p -- 1: canonical input (whole rows); 4: this is the
 // LDS half of a row larger than LDS, behind ntt_global_kernel's Harvey stages, which leave values below 4p.
-template <bool INVERSE, int LOGM, bool NARROW = false, int FWD_B0 = 1>
+// GATHER (inverse only, round 5): the tile is read through the Ntt-domain substitution map.subst_exp (galois_src_index):
+// GaloisKey::relinearize's `substitute(c1)` followed by the inverse transform (F/bfv/keys/galois_key.rs:66-70) in one pass --
+// per-lane 8-byte gathers inside one row (L2 hits after the first touch) instead of a permutation kernel's write + re-read.
+template <bool INVERSE, int LOGM, bool NARROW = false, int FWD_B0 = 1, bool GATHER = false>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     ntt_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map, const DevMod *__restrict__ mods,
                const u64x2 *__restrict__ tw, const u64x2 *__restrict__ ninv, uint32_t logn) {
@@ -60,7 +63,14 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         const bool whole = logn == LOGM;  // ninv[2*mi] = {N^-1, shoup}, ninv[2*mi+1] = {z_last * N^-1, shoup}
         // (feeding the first pass straight from global memory, as the forward transform does, was
         // measured for the inverse: no gain -- its groups are runs of consecutive coefficients)
-        tile_to_lds<CH, M, T, (FHE_PIPE_NT & 4) != 0>(lds, src, tid, [](u64 v) { return v; });
+        if constexpr (GATHER) {
+            const u64 *row = src - (u64)sub * M;          // the stored row; this tile holds its elements [sub M, (sub + 1) M)
+            const uint32_t e = map.subst_exp;
+#pragma unroll 8
+            for (uint32_t i = tid; i < (uint32_t)M; i += T) lds[padi(i)] = row[galois_src_index(sub * M + i, e, logn)];
+        } else {
+            tile_to_lds<CH, M, T, (FHE_PIPE_NT & 4) != 0>(lds, src, tid, [](u64 v) { return v; });
+        }
         FHE_BARRIER();
         ntt_inv_lds<LOGM, T, 0, 0, NARROW>(lds, twr, logn, sub, pm, tid, whole, ninv[2 * mi], ninv[2 * mi + 1], tw0);
         if (whole)

@@ -863,3 +863,38 @@ def test_workspace_limit_bounds_device_memory(fhe):
     s.destroy()
     fhe.workspace_set_limit()
     fhe.workspace_trim()
+
+
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_galois_in_place_and_folded_substitution(fhe, n):
+    """Round 5: from N = 4096 on a rotation reads c0 / c1 through the Ntt-domain substitution inside the inverse transform
+    and the key switch (no separate permutation pass) -- which gathers from the input while the output is written.  A
+    caller that rotates IN PLACE (out == ct through the `_dev` entry point) must therefore take the copying path: both
+    forms against the C oracle, every key-switch strategy."""
+    import ctypes as C
+    import torch
+    import full_size
+    from fhe_oracle import bfv as obfv, coracle
+    from fhe_oracle.rq import Context as OCtx
+    from fhe_rs_amd import _lib
+    q = obfv.generate_moduli([60, 58, 60], n)
+    cc = coracle.CCtx(OCtx(q, n))
+    seed = 0xF4E50A00 + n
+    ck = full_size.host_key(cc, seed, len(q))
+    ctx = fhe.Context(q, n)
+    c0, c1 = full_size.device_key(ctx, seed, len(q))
+    for mode in (0, 1, 2):
+        ksk = fhe.KeySwitchingKey(ctx, ctx, c0, c1).set_mode(mode)
+        for e in (3, 2 * n - 1, n + 1):
+            ct = ctx.synth_uniform(seed, 0, 0, 2, 3)
+            want = [ck.galois_relinearize(e, full_size.u64(ct[i])) for i in range(3)]
+            out = fhe.GaloisKey(ksk, e).relinearize(ct)
+            torch.cuda.synchronize()
+            for i in range(3):
+                assert np.array_equal(full_size.u64(out[i]), want[i]), (mode, e, i, "out of place")
+            same = ct.clone()
+            _lib.check(_lib.lib().fhe_bfv_galois_dev(ksk._h, e, C.c_void_p(same.data_ptr()), C.c_void_p(same.data_ptr()), 3,
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+            for i in range(3):
+                assert np.array_equal(full_size.u64(same[i]), want[i]), (mode, e, i, "in place")

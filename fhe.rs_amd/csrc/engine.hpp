@@ -964,7 +964,11 @@ struct Scaler {
 
 // NF of the scale_kernel<NF> instance for `nfrom` source moduli (the column's residues live in registers)
 inline size_t scale_kernel_nf(size_t nfrom) {
-    return nfrom <= 4 ? 4 : nfrom <= 9 ? 9 : nfrom <= 17 ? 17 : nfrom <= 33 ? 33 : 64;
+    // 4 / 9 / 17 / 33: the operand and product bases of BASELINE's configs (L = 4, 8, 16; K = 9, 17, 33).  Round 5 adds
+    // 6 / 12 / 20 for the reference's stock sets (default_parameters_128: L = 3, 5, 9 and K = 6, 10, 18), which ran on
+    // the next instance up -- K = 10 on NF = 17, K = 18 on NF = 33: up to 1.8 x the term loops, all of it zero padding.
+    return nfrom <= 4 ? 4 : nfrom <= 6 ? 6 : nfrom <= 9 ? 9 : nfrom <= 12 ? 12 : nfrom <= 17 ? 17 : nfrom <= 20 ? 20
+         : nfrom <= 33 ? 33 : 64;
 }
 
 inline void scaler_upload(Scaler &s) {
@@ -1156,8 +1160,11 @@ inline void launch_scale(const Scaler &sc, const u64 *in, u64 in_stride, u64 *ou
                    sc.dev, t.dmods(), (uint32_t)f.logn, total, asc)
     switch (scale_kernel_nf(f.L)) {   // (the same NF scaler_upload padded the tables to)
         case 4: FHE_SCALE_CASE(4); break;
+        case 6: FHE_SCALE_CASE(6); break;
         case 9: FHE_SCALE_CASE(9); break;
+        case 12: FHE_SCALE_CASE(12); break;
         case 17: FHE_SCALE_CASE(17); break;
+        case 20: FHE_SCALE_CASE(20); break;
         case 33: FHE_SCALE_CASE(33); break;
         default:
             require(f.L <= 64, E_ARG, "RNS scaler supports at most 64 source moduli");

@@ -409,3 +409,28 @@ def test_reference_default_parameter_set_n16384(fhe):
     ref_params.check_mul(fhe, False, 16384, relin=True, batch=1)
     ref_params.check_relin_rotate(fhe, False, 16384, batch=1)
     ref_params.check_mul2(fhe, False, 16384, batch=1)
+
+
+@pytest.mark.parametrize("n,mode", [(4096, 1), (4096, 2), (16384, 1), (32768, 1), (32768, 4), (32768, 2)])
+def test_galois_folded_substitution_rows(fhe, n, mode):
+    """Round 5: from N = 4096 on, GaloisKey::relinearize reads c1 / c0 through the Ntt-domain substitution inside the
+    inverse transform's loader (whole rows, and the 8192-point sub-blocks of rows larger than LDS) and inside the key
+    switch (own-row read and addend: fused whole rows, 16384-point parts, 8192-point sub-blocks, and the unfused MAC) --
+    no separate permutation pass.  Exponents 3, 2N - 1 and N + 1 (the expansion's first), 60- and 62-bit rows, against the
+    C oracle."""
+    import numpy as np
+    from fhe_oracle import coracle
+    from fhe_oracle.rq import Context as OCtx
+    from fhe_oracle.zq import generate_prime
+    import full_size
+    q = [generate_prime(60, 2 * n, 1 << 60), generate_prime(62, 2 * n, 1 << 62)]
+    cc = coracle.CCtx(OCtx(q, n))
+    seed = 0xF4E50B00 + n
+    ck = full_size.host_key(cc, seed, len(q))
+    ctx = fhe.Context(q, n)
+    ksk = fhe.KeySwitchingKey(ctx, ctx, ck.c0, ck.c1).set_mode(mode)
+    ct = np.stack([np.stack([cc.synth_poly(seed, b, p) for p in range(2)]) for b in range(2)])
+    for e in (3, 2 * n - 1, n + 1):
+        got = fhe.GaloisKey(ksk, e).relinearize(ct)
+        for b in range(2):
+            assert np.array_equal(np.asarray(got[b]), ck.galois_relinearize(e, ct[b])), (n, mode, e, b)

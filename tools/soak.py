@@ -117,7 +117,42 @@ def auto_small(reps):
     sys.exit(1 if bad else 0)
 
 
+def single(reps):
+    """Round 5: one ciphertext pair per call (the reference's Criterion shape).  Such a launch runs the tensor + iNTT of
+    ALL rows on the general passes in one launch, where a batch runs the 60-bit rows on the narrow passes: the pair's
+    result must equal its slice of the batch-1024 result (cross-path equality) every time (determinism) -- at C2 and on
+    the reference's stock n = 8192 / log q = 218 set, whose rotation (folded substitution, unfused key switch) is checked
+    the same way."""
+    bad, total, t0 = 0, 0, time.time()
+    n = 8192
+    t = fhe.generate_prime(20, 2 * n, 1 << 20)
+    for q in (None, [0x7fffffd8001, 0x7fffffc8001, 0xfffffffc001, 0xffffff6c001, 0xfffffebc001]):
+        par = fhe.BfvParameters(n, t, moduli_sizes=[60] * 4) if q is None else fhe.BfvParameters(n, t, moduli=q)
+        ctx = par.context_at_level(0)
+        L = ctx.nmoduli
+        kk = ctx.synth_uniform(7, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, n)
+        ksk = fhe.KeySwitchingKey(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous())
+        mul = fhe.Multiplicator.default(par, fhe.RelinearizationKey(ksk), 0)
+        gk = fhe.GaloisKey(ksk, 3)
+        a, b = ctx.synth_uniform(7, 0, 0, 2, 1024), ctx.synth_uniform(7, 0, 2, 2, 1024)
+        ref_m, ref_r = mul.multiply(a, b), gk.relinearize(a)
+        torch.cuda.synchronize()
+        for i in range(reps):
+            k = i % 1024
+            a1, b1 = a[k:k + 1].contiguous(), b[k:k + 1].contiguous()
+            m, r = mul.multiply(a1, b1), gk.relinearize(a1)
+            if not (torch.equal(m[0], ref_m[k]) and torch.equal(r[0], ref_r[k])):
+                bad += 1
+            total += 2
+    torch.cuda.synchronize()
+    print(json.dumps(dict(config="one pair per call (C2 and stock n=8192/log q=218) against its slice of the batch-1024 result",
+                          repetitions=reps, ops=total, mismatches=bad, seconds=round(time.time() - t0, 1))))
+    sys.exit(1 if bad else 0)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "single":
+        single(int(sys.argv[1]))
     if len(sys.argv) > 3 and sys.argv[3] == "auto_small":
         auto_small(int(sys.argv[1]))
     if len(sys.argv) > 3 and sys.argv[3] == "c3":

@@ -1471,7 +1471,8 @@ constexpr size_t KS_W_BUDGET_DEFAULT = (size_t)4 << 30;
 // tiles and fills the device from a single ciphertext on: C3 batch 1 0.220 -> 0.055 ms, batch 16 0.225 -> 0.155; C5 batch 1
 // 0.32 -> 0.12 ms; C2 batch 1 0.054 -> 0.030, batch 32 0.063 -> 0.054.  The crossover sits between 128 and 256 fused
 // workgroups at every size measured (N = 4096 ... 32768): KS_AUTO takes the unfused form while 2 x workgroups <= compute
-// units (at least three digits, N >= 4096: below that the second launch costs what the parallelism gains).
+// units (at least three digits, N >= 4096: below that the second launch costs what the parallelism gains).  Round 5
+// refines the rule by the fused launch's LAST round of workgroups: see the end of ks_use_unfused.
 inline bool ks_use_unfused(const Ksk &k_, int mode, size_t npolys) {
     if (k_.log_base != 0) return false;                 // base-2^k digits of one row: the fused loader extracts them
     if (mode == KS_UNFUSED || mode == KS_UNFUSED_SUB) return true;
@@ -1484,7 +1485,19 @@ inline bool ks_use_unfused(const Ksk &k_, int mode, size_t npolys) {
     // (rows larger than LDS with short digit loops: the 8192-point fused sub-blocks take over earlier -- N = 32768, 4
     // moduli: 96 parts 0.093 vs 0.092 ms, 128 parts 0.112 vs 0.101; profiles/r04_final5_ks_small_launch_ab.jsonl)
     if (kc.logn > 14 && k_.ndigits < 8) return 8 * fused_wg < 3 * cus;
-    return 2 * fused_wg <= cus;
+    // Round 5 (profiles/r05_ks_small_launch_stock.jsonl, r05_ks_rounds12_ab.jsonl): the fused kernels have ONE workgroup
+    // per CU from N = 8192 on, so a fused launch's time is a step function of its rounds of workgroups, while the unfused
+    // form's grows with the work.  (a) N = 4096 (two workgroups per CU, three short digits): unfused only up to a fifth of
+    // the CUs' worth (3 moduli: 48 workgroups 0.0310 vs 0.0311 ms, 72: 0.0330 vs 0.0319).  (b) Less than 0.6 of one round
+    // (was 0.5; 9 moduli at N = 16384, 144 workgroups: 0.217 vs 0.267 ms).  (c) One or two full rounds and a last round at
+    // most half full: 288 / 320 / 384 workgroups at C2 0.095 / 0.105 / 0.115 vs 0.113 / 0.114 / 0.117 ms, at C3 0.349 /
+    // 0.382 / 0.443 vs 0.461 / 0.465 / 0.479, at C5 (320 / 384 parts) 0.834 / 0.967 vs 1.040 / 1.045; 576: 0.669 vs 0.727
+    // (C3), 1.440 vs 1.562 (C5); with the last round more than half full the fused kernel is ahead again (448: 0.120 vs 0.128).
+    if (kc.logn == 12) return 5 * fused_wg <= cus;
+    if (5 * fused_wg <= 3 * cus) return true;
+    const size_t full = fused_wg / cus, rem = fused_wg % cus;
+    // (after two full rounds only up to 0.4 of a third: 640 workgroups at C2 0.192 vs 0.182 ms)
+    return rem > 0 && ((full == 1 && 2 * rem <= cus) || (full == 2 && 5 * rem <= 2 * cus));
 }
 template <int LOGM, int G0>
 inline void launch_ks_ntt(const Ksk &k_, bool narrow, bool rns, unsigned grid, hipStream_t s, const u64 *p, u64 p_stride,

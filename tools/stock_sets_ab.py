@@ -29,6 +29,9 @@ def main():
         mul, plain = fhe.Multiplicator.default(par, rk, 0), fhe.Multiplicator.default(par, None, 0)
         d = {"mul_and_relin": round(batch / timeit(lambda: mul.multiply(a, b)) * 1e3, 1),
              "mul": round(batch / timeit(lambda: plain.multiply(a, b)) * 1e3, 1)}
+        mul.set_streams(1)
+        d["mul_and_relin_one_stream"] = round(batch / timeit(lambda: mul.multiply(a, b)) * 1e3, 1)
+        mul.set_streams(2)
         a1, b1 = a[:1].contiguous(), b[:1].contiguous()
         d["mul_and_relin_single_ms"] = round(timeit(lambda: mul.multiply(a1, b1)), 4)
         out[f"n={n}"] = d

@@ -747,8 +747,9 @@ def test_key_switch_decomposition_rows(fhe, n, bits):
 
 def test_key_switch_auto_picks_strategy_by_launch_size(fhe):
     """What FHE_KS_AUTO does (engine.hpp ks_use_unfused / key_switch_polys; profiles/r04_ks_small_batches_all_modes.txt,
-    r04_ks_small_launch_ab.txt), read back from the library's per-launch profiler: launches with at most half the compute
-    units' worth of fused workgroups run the unfused kernels, larger ones the fused kernel; a key with fewer than three
+    r04_ks_small_launch_ab.txt; round 5: r05_ks_rounds12_ab.jsonl), read back from the library's per-launch profiler: launches
+    with at most 0.6 of the compute units' worth of fused workgroups run the unfused kernels, larger ones the fused kernel
+    unless a nearly empty last round of workgroups follows one or two full ones; a key with fewer than three
     digits stays fused, on 8192-point sub-blocks while those fit the device at once (N >= 32768).  Values are compared
     with the oracle by every other test of this file; this one pins the choice."""
     import torch
@@ -776,6 +777,12 @@ def test_key_switch_auto_picks_strategy_by_launch_size(fhe):
     assert {"ks_digit_ntt", "ks_mac"} <= kernels_of(ctx, L, small) and "key_switch_fused" not in kernels_of(ctx, L, small)
     ks = kernels_of(ctx, L, large)
     assert "key_switch_fused" in ks and "ks_mac" not in ks
+    # round 5 (profiles/r05_ks_rounds12_ab.jsonl): one workgroup per CU makes the fused launch's time a step function of
+    # its rounds -- after one full round a last round at most half full goes to the unfused kernels (1.125 and 1.5
+    # rounds), a fuller one stays fused (1.75 rounds), and so do exactly two rounds
+    for rounds8, want_unfused in ((9, True), (12, True), (14, False), (16, False)):
+        ks = kernels_of(ctx, L, rounds8 * cus // (8 * L))
+        assert ("ks_mac" in ks) == want_unfused and ("key_switch_fused" in ks) == (not want_unfused), (rounds8, ks)
     n, L = 32768, 2                                  # two digits: never unfused; sub-blocks while they fit at once
     ctx = fhe.Context(fhe.generate_moduli([60] * L, n), n)
     ks = kernels_of(ctx, L, cus // (4 * L))          # batch x L x 4 sub-blocks = CUs

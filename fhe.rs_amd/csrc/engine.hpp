@@ -850,7 +850,10 @@ inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, s
     // (C2, one pair: tensor_intt 2 x 16.4 us -> 1 x; profiles/r05_latency_breakdown.json)
     {
         const uint32_t lsub = e.logn > 14 ? (uint32_t)e.logn - 13 : 0;
-        if ((((size_t)3 * e.L * nb) << lsub) <= (size_t)device_cus(e.device) * 2 / 3 && device_cus(e.device) > 8) allow = false;
+        // (threshold: one round of workgroups -- two fit a CU with 8192-point tiles and smaller, one with 16384-point
+        // tiles; C2 at 8 / 16 pairs: profiles/r05_tensor_one_launch_ab.jsonl)
+        const size_t slots = (size_t)device_cus(e.device) * (e.logn == 14 ? 1 : 2);
+        if ((((size_t)3 * e.L * nb) << lsub) <= slots && device_cus(e.device) > 8) allow = false;
     }
     struct Run {
         uint32_t r0, n;

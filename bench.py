@@ -378,6 +378,34 @@ def make_timeit(torch, reps=3):
     return timeit
 
 
+def graph_replay_ms(torch, fn, reps=50):
+    """ms per replay of `fn`'s launches captured into a hipGraph (torch.cuda.CUDAGraph on a side stream, after two warm-up
+    calls there so that the stream's workspace exists); None when capture is not possible.  VERDICT r04 #4 asked for the
+    eager / graph pair: a call's time is the sum of its kernels' single-workgroup latencies (gaps 0.2-0.9 us per launch,
+    profiles/r05_latency_breakdown_*.json), so a replay buys nothing -- the line says so with numbers."""
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            fn()
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1) / reps, 4)
+    except Exception:
+        return None
+
+
 def reference_bench_ids(fhe, torch, par, rk, batch, timeit):
     """The rest of the reference's own Criterion IDs on the C2 parameter set (informational, same process):
     crates/fhe/benches/bfv.rs:219-245 `mul` (&c1 * &c2, three parts, no relinearisation), `square` (&c1 * &c1),
@@ -412,7 +440,10 @@ def reference_bench_ids(fhe, torch, par, rk, batch, timeit):
     m1 = fhe.Multiplicator.default(par, rk, 0)
     out["single_ciphertext_latency_c2"] = dict(mul_and_relin_ms=round(timeit(lambda: m1.multiply(a1, b1)), 4),
                                                relinearize_ms=round(timeit(lambda: rk.relinearizes(c31)), 4),
-                                               note="one ciphertext (pair) per call, inputs resident")
+                                               mul_and_relin_graph_replay_ms=graph_replay_ms(torch, lambda: m1.multiply(a1, b1)),
+                                               relinearize_graph_replay_ms=graph_replay_ms(torch, lambda: rk.relinearizes(c31)),
+                                               note="one ciphertext (pair) per call, inputs resident; *_graph_replay_ms: the same "
+                                                    "launches replayed from a captured hipGraph")
     del c3, plain, a1, b1, c31, m1
     # fhe-math/benches/rns.rs: the reference's 3 -> 4 modulus lists, PowerBasis columns of [batch*2] polynomials
     q3 = [4611686018326724609, 4611686018309947393, 4611686018282684417]
@@ -487,7 +518,8 @@ def other_configs(fhe, torch, reps=3):
     # fused workgroups, FHE_KS_AUTO takes the unfused key switch (profiles/r04_ks_small_batches_all_modes.txt)
     one3, one2 = ct3[:1].contiguous(), ct2[:1].contiguous()
     lat = {"C3_relinearize_ms": round(timeit(lambda: rk.relinearizes(one3)), 4),
-           "C3_rotate_columns_ms": round(timeit(lambda: gk3.relinearize(one2)), 4)}
+           "C3_rotate_columns_ms": round(timeit(lambda: gk3.relinearize(one2)), 4),
+           "C3_relinearize_graph_replay_ms": graph_replay_ms(torch, lambda: rk.relinearizes(one3))}
     del ct3, ct2, one3, one2, rk, gk3, gkr, ksk, ctx
     n, L = 32768, 16
     t = fhe.generate_prime(20, 2 * n, 1 << 20)
@@ -515,6 +547,7 @@ def other_configs(fhe, torch, reps=3):
         del a, b
     a, b = ctx.synth_uniform(0xF4E50005, 0, 0, 2, 1), ctx.synth_uniform(0xF4E50005, 0, 2, 2, 1)
     lat["C5_level0_mul_relin_modswitch_ms"] = round(timeit(lambda: mul.multiply(a, b)), 4)
+    lat["C5_level0_mul_relin_modswitch_graph_replay_ms"] = graph_replay_ms(torch, lambda: mul.multiply(a, b), 20)
     out["single_ciphertext_latency"] = dict(lat, note="one ciphertext (pair) per call, caller's stream, inputs resident")
     return out
 
@@ -715,6 +748,8 @@ def reference_default_128(fhe, torch, cpu_ms=None, sets=(4096, 8192, 16384)):
                 d = ids.setdefault(name, {})
                 if b == 1:
                     d["single_ms"] = round(ms, 4)
+                    if name == "mul_and_relin":
+                        d["single_graph_replay_ms"] = graph_replay_ms(torch, fn)
                 else:
                     nb = be if name.startswith("expand_") else b
                     d["batch"] = nb

@@ -68,7 +68,7 @@ def main():
             traffic[lab] = int(fb + wb)
     json.dump(out, open(os.path.join(prof, f"{rnd}_pmc_hbm.json"), "w"), indent=1)
     traffic["_source"] = (f"profiles/{rnd}_pmc_hbm.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, "
-                          "separate passes over `bench.py --steps 5 --no-cpu --no-extras`, bytes per launch")
+                          "separate passes over `bench.py --steps K --warmup 5 --no-cpu --no-extras` (tools/collect_profiles.sh), bytes per launch")
     json.dump(traffic, open(os.path.join(prof, "roofline_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

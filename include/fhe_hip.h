@@ -278,7 +278,10 @@ fhe_status fhe_bfv_relinearize_dev(const fhe_ksk *rk, const uint64_t *ct3, uint6
                                    void *stream);
 /* GaloisKey::relinearize / relinearize_into (F/bfv/keys/galois_key.rs:63-123), i.e.
  * EvaluationKey::rotates_columns_by (exponent 3^i mod 2N) / rotates_rows (exponent 2N-1)
- * (F/bfv/keys/evaluation_key.rs:110-170, 278-286): ct, out [batch][2][L][N] Ntt. */
+ * (F/bfv/keys/evaluation_key.rs:110-170, 278-286): ct, out [batch][2][L][N] Ntt.
+ * From N = 4096 on (key at the ciphertext's level) there is no separate permutation pass: the Ntt-domain substitution is
+ * read as a gather inside the inverse transform and the key switch.  `out` may be `ct` itself (the reference's
+ * `c1 = ek.rotates_rows(&c1)`): any overlap of `ct` and `out` takes the copying path (every read of `ct` precedes the first write of `out`). */
 fhe_status fhe_bfv_galois(const fhe_ksk *gk, size_t exponent, const uint64_t *ct, uint64_t *out, size_t batch);
 fhe_status fhe_bfv_galois_dev(const fhe_ksk *gk, size_t exponent, const uint64_t *ct, uint64_t *out,
                               size_t batch, void *stream);

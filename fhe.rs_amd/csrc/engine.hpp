@@ -2164,7 +2164,14 @@ inline ChunkPlan plan_chunks(const Ctx &base, const Ctx &mulc, size_t batch, siz
         const size_t nc = (batch + cap - 1) / cap;
         return (batch + nc - 1) / nc;
     };
-    if (streams_opt >= 2) {
+    // Round 5 (profiles/r05_plan14_ab.jsonl: same box, alternating builds; r05_chunk_sweep_n16384.jsonl, r05_chunk_sweep_c5.jsonl):
+    // at N = 16384 the small-chunk plan below is skipped -- two or three large chunks alternating between the two streams
+    // (the 3 GiB cut at the end) run the reference's stock n = 16384 set 6.7 % (256 pairs) / 8.4 % (1,024 pairs) faster and
+    // a 12-moduli basis 3.6 %, at the price of 1.0-1.6 % on 4- and 8-moduli bases: at this size every NTT-type kernel is one
+    // 1024-thread workgroup per CU and so is the key switch, so small launches are mostly tail (9 digits x 32 pairs = 288
+    // key-switch workgroups: one round and an eighth).  N = 8192 (C2, stock n = 8192: unchanged in the same A/B) and
+    // N = 32768 (C5 at 32 / 64 / 128 pairs, 8 moduli at 128 pairs: the default plan is the best cell of the sweep) keep it.
+    if (streams_opt >= 2 && base.logn != 14) {
         // Two streams: chunks small enough that a chunk's intermediates mostly stay in the 256 MiB Infinity Cache, at
         // least four of them.  Round 3 (profiles/r03_chunk_sweep_event_free.jsonl, C2): 64 ... 256 pairs per chunk are
         // within 1 % of each other, 96 - 128 best at 8,192 pairs -- but 66 pairs (what the 384 MB budget gave there)

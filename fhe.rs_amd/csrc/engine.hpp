@@ -2179,7 +2179,13 @@ inline ChunkPlan plan_chunks(const Ctx &base, const Ctx &mulc, size_t batch, siz
         // of 64 pairs or more are therefore cut to a multiple of 32.
         for (const size_t budget : {(size_t)768 << 20, (size_t)384 << 20}) {
             size_t c = equal_chunks(budget, 8);
-            if (c >= 64) c = c / 32 * 32;
+            if (c >= 64) {
+                c = c / 32 * 32;
+                // (round 5: rounding down can leave a small ragged last chunk -- 1,024 pairs of the stock n = 4096 set: 342 ->
+                // 320 = 320 + 320 + 320 + 64; equal chunks over the same count instead: 4 x 256, profiles/r05_plan_ragged_ab.jsonl)
+                const size_t nc = nchunks(c), ce = (batch + nc - 1) / nc;
+                if (ce >= 64 && ce % 32 == 0) c = ce;
+            }
             if (nchunks(c) >= 4) return ChunkPlan{c, true};
         }
     }

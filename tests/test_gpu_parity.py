@@ -905,3 +905,30 @@ def test_galois_in_place_and_folded_substitution(fhe, n):
             torch.cuda.synchronize()
             for i in range(3):
                 assert np.array_equal(full_size.u64(same[i]), want[i]), (mode, e, i, "in place")
+
+
+def test_measurement_aids(fhe):
+    """The measurement aids behind bench.py's ceilings (not on the path): every fhe_ubench_int kind returns a positive
+    rate, fhe_ubench_scaler runs the scaler's own kernel instance, fhe_ubench_copy streams; bad arguments are refused with
+    the ABI's status codes instead of crashing."""
+    for kind in fhe.UBENCH_KINDS:
+        assert fhe.ubench_int(kind, 0.005) > 1e9, kind
+    par = fhe.BfvParameters(4096, fhe.generate_prime(20, 8192, 1 << 20), moduli_sizes=[60, 60])
+    assert fhe.ubench_scaler(par.extender(0), 0.005) > 1e8 and fhe.ubench_scaler(par.down_scaler(0), 0.005) > 1e8
+    assert fhe.ubench_copy(1 << 26, 0.005) > 1e11
+
+    def code(fn):
+        try:
+            fn()
+        except fhe.FheError as e:
+            return e.code
+        return 0
+    assert code(lambda: fhe.ubench_int(99, 0.01)) == -1 and code(lambda: fhe.ubench_int(0, 0.0)) == -1
+    assert code(lambda: fhe.ubench_int(0, 0.01, device=77)) == -18
+    assert code(lambda: fhe.ubench_copy(16, 0.01)) == -1 and code(lambda: fhe.ubench_copy(1 << 20, 100.0)) == -1
+    assert code(lambda: fhe.ubench_scaler(par.extender(0), 0.0)) == -1
+    host_only = fhe.Context(par.moduli, 4096, device=-1)
+    assert code(lambda: fhe.ubench_scaler(fhe.Scaler(host_only, host_only, 3, 7), 0.01)) == -18
+    st = fhe.workspace_pool_stats(0)
+    assert set(st) == {"scratch_reserved_bytes", "scratch_used_bytes", "buffers_reserved_bytes", "buffers_used_bytes"}
+    assert fhe.workspace_pool_stats(99)["scratch_reserved_bytes"] == 0

@@ -1502,15 +1502,27 @@ inline bool ks_use_unfused(const Ksk &k_, int mode, size_t npolys) {
     // (after two full rounds only up to 0.4 of a third: 640 workgroups at C2 0.192 vs 0.182 ms)
     return rem > 0 && ((full == 1 && 2 * rem <= cus) || (full == 2 && 5 * rem <= 2 * cus));
 }
+// `extra` (optional, G0 == 0): residue rows transformed in place by `extra_grid` more workgroups of the same launch
+struct KsExtraFwd {
+    u64 *rows = nullptr;      // [npolys][nrows][N], row r under modulus r of the key context, canonical in / out
+    u64 poly_stride = 0;
+    size_t npolys = 0, nrows = 0;
+};
 template <int LOGM, int G0>
 inline void launch_ks_ntt(const Ksk &k_, bool narrow, bool rns, unsigned grid, hipStream_t s, const u64 *p, u64 p_stride,
-                          u64 *w, uint32_t j0, uint32_t jg, uint32_t skip_own) {
+                          u64 *w, uint32_t j0, uint32_t jg, uint32_t skip_own, const KsExtraFwd *extra = nullptr) {
     const Ctx &kc = *k_.ksk_ctx;
     const size_t lds = k::lds_words(1u << LOGM) * sizeof(u64);
+    const bool with_extra = G0 == 0 && extra != nullptr && extra->rows != nullptr;
+    u64 *const erows = with_extra ? extra->rows : nullptr;
+    const u64 estride = with_extra ? extra->poly_stride : 0;
+    const uint32_t enr = with_extra ? (uint32_t)extra->nrows : 1u;
+    const unsigned egrid = with_extra ? (unsigned)(extra->npolys * extra->nrows) : 0u;
 #define FHE_KSN(NW, RNS)                                                                                         \
     allow_big_lds((k::ks_ntt_kernel<LOGM, G0, NW, RNS>), lds);                                                   \
-    FHE_LAUNCH("ks_digit_ntt", (k::ks_ntt_kernel<LOGM, G0, NW, RNS>), dim3(grid), dim3(k::ntt_threads_c(LOGM)), \
-               lds, s, p, p_stride, w, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, j0, jg, k_.digit_arg(), skip_own)
+    FHE_LAUNCH("ks_digit_ntt", (k::ks_ntt_kernel<LOGM, G0, NW, RNS>), dim3(grid + egrid), dim3(k::ntt_threads_c(LOGM)), \
+               lds, s, p, p_stride, w, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, j0, jg, k_.digit_arg(), skip_own,   \
+               erows, estride, enr, (uint32_t)grid)
     if constexpr (LOGM >= 12) {
         if (rns) {
             if (narrow) { FHE_KSN(true, true); } else { FHE_KSN(false, true); }
@@ -1523,15 +1535,18 @@ inline void launch_ks_ntt(const Ksk &k_, bool narrow, bool rns, unsigned grid, h
 }
 inline void key_switch_polys_unfused(const Ksk &k_, int mode, const u64 *p, u64 p_stride, u64 *o0, u64 *o1,
                                      u64 out_stride, const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys,
-                                     hipStream_t s, const u64 *xhat, u64 xhat_stride, uint32_t gal) {
+                                     hipStream_t s, const u64 *xhat, u64 xhat_stride, uint32_t gal,
+                                     const KsExtraFwd *extra = nullptr) {
     const Ctx &kc = *k_.ksk_ctx;
     const size_t N = kc.n, nd = k_.ndigits, Lk = kc.L;
     const uint32_t logn = (uint32_t)kc.logn;
     // tile geometry of stage A: whole rows up to 16384 points, 8192-point sub-blocks above (and at 16384 on request)
     // (KS_AUTO at N = 16384: sub-block tiles while the whole-row tiles of stage A would leave half the device idle --
     // one ciphertext at 8 moduli: 64 rows, 0.0527 vs 0.0556 ms; four: 256 rows, 0.0684 vs 0.0668)
+    // (with extra rows to transform in the same launch -- bfv_mul's c0, c1 -- whole-row tiles: saving that launch is worth
+    // more than the smaller tiles, 21 us against 3 us at one ciphertext)
     const bool sub14 = logn == 14 && (mode == KS_UNFUSED_SUB ||
-                                      (mode == KS_AUTO && 2 * npolys * nd * Lk <= (size_t)device_cus(kc.device)));
+                                      (mode == KS_AUTO && !extra && 2 * npolys * nd * Lk <= (size_t)device_cus(kc.device)));
     const uint32_t logm = logn > 14 ? 13 : sub14 ? 13 : logn;
     const uint32_t g0 = logn - logm;
     bool narrow = !FHE_LAB_FLAG("NO_NARROW");
@@ -1553,6 +1568,15 @@ inline void key_switch_polys_unfused(const Ksk &k_, int mode, const u64 *p, u64 
     pc = (npolys + ((npolys + pc - 1) / pc) - 1) / ((npolys + pc - 1) / pc);
     WsGuard w(pc * nd * jg * row_bytes, s);
     const uint32_t skip_own = xhat != nullptr ? 1u : 0u;
+    // the extra rows ride on the stage-A launch only when there is exactly one (whole-row tiles, one chunk of polynomials,
+    // one group of key moduli); otherwise they get their own forward transform first, as before
+    const bool merge_extra = extra != nullptr && g0 == 0 && logm == logn && pc == npolys && jg == Lk;
+    if (extra != nullptr && !merge_extra) {
+        k::RowMap m = full_map(kc, extra->nrows);
+        m.src_poly_stride = m.dst_poly_stride = extra->poly_stride;
+        launch_ntt(kc, false, extra->rows, extra->rows, m, extra->npolys, s);
+    }
+    const KsExtraFwd *ride = merge_extra ? extra : nullptr;
     for (size_t b0 = 0; b0 < npolys; b0 += pc) {
         const size_t nb = std::min(pc, npolys - b0);
         for (size_t j0 = 0; j0 < Lk; j0 += jg) {
@@ -1560,7 +1584,7 @@ inline void key_switch_polys_unfused(const Ksk &k_, int mode, const u64 *p, u64 
             const unsigned grid_a = (unsigned)((nb * nd * njg) << g0);
             const u64 *pp = p + b0 * p_stride;
 #define FHE_KSN_CASE(LM)                                                                                         \
-    case LM: launch_ks_ntt<LM, 0>(k_, narrow, rns, grid_a, s, pp, p_stride, w.u(), (uint32_t)j0, (uint32_t)njg, skip_own); break;
+    case LM: launch_ks_ntt<LM, 0>(k_, narrow, rns, grid_a, s, pp, p_stride, w.u(), (uint32_t)j0, (uint32_t)njg, skip_own, ride); break;
             if (g0 == 0) {
                 switch (logm) {
                     FHE_KSN_CASE(3) FHE_KSN_CASE(4) FHE_KSN_CASE(5) FHE_KSN_CASE(6) FHE_KSN_CASE(7) FHE_KSN_CASE(8)
@@ -1593,9 +1617,13 @@ inline void key_switch_polys_unfused(const Ksk &k_, int mode, const u64 *p, u64 
 // kernels then read instead of recomputing (L of the L * Lk transforms).
 // gal != 0 (galois_apply): `xhat` and `a0` are the caller's UNPERMUTED Ntt rows, read through the substitution
 // x -> x^gal inside the kernels (needs xhat; a1 must be null).
+// extra (optional): residue rows over the key context to be forward-transformed IN PLACE before the sums are formed
+// (bfv_mul's c0, c1, which are also a0 / a1): they ride on the unfused form's stage-A launch when that is one launch,
+// and get their own launch otherwise.
 inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, u64 *o1, u64 out_stride,
                              const u64 *a0, const u64 *a1, u64 a_stride, size_t npolys, hipStream_t s,
-                             const u64 *xhat = nullptr, u64 xhat_stride = 0, uint32_t gal = 0) {
+                             const u64 *xhat = nullptr, u64 xhat_stride = 0, uint32_t gal = 0,
+                             const KsExtraFwd *extra = nullptr) {
     if (FHE_LAB_FLAG("NO_KS_XHAT") && !gal) xhat = nullptr;
     require(!gal || (xhat != nullptr && a1 == nullptr), E_ARG, "galois key switch: needs the Ntt rows, adds to c0 only");
     const Ctx &kc = *k_.ksk_ctx;
@@ -1604,9 +1632,15 @@ inline void key_switch_polys(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0,
     {
         const int mode = k_.mode.load(std::memory_order_relaxed);
         if (ks_use_unfused(k_, mode, npolys)) {
-            key_switch_polys_unfused(k_, mode, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride, gal);
+            key_switch_polys_unfused(k_, mode, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride, gal,
+                                     extra);
             return;
         }
+    }
+    if (extra != nullptr && extra->rows != nullptr) {   // (a fused launch: the extra rows' transform is its own launch)
+        k::RowMap m = full_map(kc, extra->nrows);
+        m.src_poly_stride = m.dst_poly_stride = extra->poly_stride;
+        launch_ntt(kc, false, extra->rows, extra->rows, m, extra->npolys, s);
     }
     // N = 16384: whole-row kernel (1024 threads x 16 coefficients, 24 VGPRs spilled) or two 8192-point sub-blocks
     // with the first stage folded into the loader (FHE_KS_SPLIT14=1)
@@ -1764,13 +1798,15 @@ inline void switch_down_to_ntt(const Ctx &from, size_t iters, const u64 *in, u64
 // out0/out1 [npolys][Lct][N] (poly stride out_stride) = a + switch_down_to(key_switch(p), ct_ctx)
 inline void key_switch_add(const Ksk &k_, const u64 *p, u64 p_stride, const u64 *a0, const u64 *a1, u64 a_stride,
                            u64 *out0, u64 *out1, u64 out_stride, size_t npolys, hipStream_t s,
-                           const u64 *xhat = nullptr, u64 xhat_stride = 0, uint32_t gal = 0) {
+                           const u64 *xhat = nullptr, u64 xhat_stride = 0, uint32_t gal = 0,
+                           const KsExtraFwd *extra = nullptr) {
     const Ctx &kc = *k_.ksk_ctx, &cc = *k_.ct_ctx;
     const long iters = kc.niterations_to(cc);
     if (iters == 0) {
-        key_switch_polys(k_, p, p_stride, out0, out1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride, gal);
+        key_switch_polys(k_, p, p_stride, out0, out1, out_stride, a0, a1, a_stride, npolys, s, xhat, xhat_stride, gal, extra);
         return;
     }
+    require(extra == nullptr, E_ARG, "extra rows ride only on a key switch at the ciphertext's level");
     require(!gal, E_ARG, "the folded Galois substitution needs the key at the ciphertext's level");
     const u64 kstride = (u64)kc.L * kc.n, cstride = (u64)cc.L * cc.n;
     WsGuard r0(npolys * kstride * sizeof(u64), s), r1(npolys * kstride * sizeof(u64), s);
@@ -2359,9 +2395,21 @@ inline void bfv_mul(const Mul &m, const u64 *lhs, const u64 *rhs, u64 *out, size
             // transforms c2 forward and, at mul.rs:212, back again; iNTT(NTT(x)) = x exactly).
             // (Transforming c2 as well and handing it to the key switch as `xhat` was measured at C2: the key
             // switch gains 1.0 ms per 10 steps, the larger forward launch costs 1.6: profiles/r02_mul_xhat_ab.txt.)
-            launch_ntt(b, false, d.u(), d.u(), back, nb * 2, s);
+            // Round 5: when the key switch of this chunk runs unfused (a launch that does not fill the device) and the key
+            // sits at the ciphertext's level, the forward transform of (c0, c1) rides on its stage-A launch -- one launch
+            // less on the critical path of a small call (C2, one pair: 0.088 -> 0.077 ms, profiles/r05_merged_fwd_ab.jsonl)
+            const bool ride = m.rk->ksk_ctx->niterations_to(*m.rk->ct_ctx) == 0 && b.logn <= 14 &&
+                              ks_use_unfused(*m.rk, m.rk->mode.load(std::memory_order_relaxed), nb) &&
+                              !FHE_LAB_FLAG("NO_MERGED_FWD");
+            KsExtraFwd ex;
+            ex.rows = d.u();
+            ex.poly_stride = PL;
+            ex.npolys = nb * 2;
+            ex.nrows = L;
+            if (!ride) launch_ntt(b, false, d.u(), d.u(), back, nb * 2, s);
             // RELINEARIZE (mul.rs:211-227): (c0, c1) += key_switch(c2), written to the output layout
-            key_switch_add(*m.rk, d.u() + 2 * nb * PL, PL, d.u(), d.u() + nb * PL, PL, dst, dst + PL, 2 * PL, nb, s);
+            key_switch_add(*m.rk, d.u() + 2 * nb * PL, PL, d.u(), d.u() + nb * PL, PL, dst, dst + PL, 2 * PL, nb, s, nullptr, 0, 0,
+                           ride ? &ex : nullptr);
         } else {
             // no relinearisation: three Ntt parts, slot-major scratch -> [b][3][L][N]
             launch_ntt(b, false, d.u(), d.u(), back, nb * 3, s);

@@ -627,7 +627,7 @@ template <int LOGM, int G0, bool NARROW, bool RNS>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     ks_ntt_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ w, const DevMod *__restrict__ mods,
                   const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t j0, uint32_t jg, uint32_t digit_arg,
-                  uint32_t skip_own) {
+                  uint32_t skip_own, u64 *extra, u64 extra_poly_stride, uint32_t extra_rows, uint32_t main_rows) {
     FHE_DYN_SMEM(u64, lds);
     constexpr int T = ntt_threads_c(LOGM);
     constexpr int M = 1 << LOGM, NS = 1 << G0;
@@ -635,6 +635,32 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     constexpr u64 N = (u64)M << G0;
     const uint32_t tid = threadIdx.x;
     const uint32_t sub = blockIdx.x & (NS - 1);
+    // Round 5 (G0 == 0 only; extra == nullptr otherwise): workgroups behind the `main_rows` digit tiles transform
+    // EXTRA residue rows in place -- `extra` [polys][extra_rows][N], row r under modulus r, canonical in and out: the
+    // forward NTT of (c0, c1) that Multiplicator::multiply runs next to its key switch (F/bfv/ops/mul.rs:207-227).  One
+    // launch instead of two: a launch that does not fill the device takes one workgroup's time whatever it contains
+    // (C2, one pair: ntt_fwd 12 us + ks_digit_ntt 12 us -> 12 us).
+    if constexpr (G0 == 0) {
+        if (blockIdx.x >= main_rows) {   // (block-uniform)
+            const uint32_t er = blockIdx.x - main_rows;
+            const uint32_t ep = to_sgpr(er / extra_rows), r = er - ep * extra_rows;
+            const DevMod md = mods[r];
+            const PM pm = make_pm(md);
+            const u64 p2 = md.p2;
+            u64 *row = extra + (u64)ep * extra_poly_stride + (u64)r * N;
+            const u64x2 *twr = tw + (u64)r * N;
+            ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? 1 : 0)>(lds, twr, 1, pm, tid, [&](uint32_t idx, uint32_t) { return row[idx]; });
+            if constexpr (NARROW) {   // below 16p -> canonical
+                const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
+                lds_to_tile<CH, M, T>(lds, row, tid, [&](u64 v) {
+                    return csub_n(csub_n(csub_n(csub_n(v, p8, np8), p4, np4), p2, pm.np2), md.p, pm.np);
+                });
+            } else {
+                lds_to_tile<CH, M, T>(lds, row, tid, [&](u64 v) { return csub_n(csub_n(v, p2, pm.np2), md.p, pm.np); });
+            }
+            return;
+        }
+    }
     const uint32_t rowb = blockIdx.x >> G0;                       // (b * ndigits + i) * jg + jj
     const uint32_t bi = to_sgpr(rowb / jg), jj = rowb - bi * jg, j = j0 + jj;
     const uint32_t b = to_sgpr(bi / ndigits), i = bi - b * ndigits;

@@ -304,6 +304,23 @@ def test_unfused_multiply(fhe, nmod, level, chunk):
         cases.case_multiply(fhe, False, nmod=2, n=512, batch=2)
 
 
+def test_multiply_forward_transform_rides_on_unfused_stage_a(fhe):
+    """Round 5: when the multiply's key switch runs unfused at the ciphertext's level, the forward transform of (c0, c1)
+    is done by extra workgroups of the key switch's stage-A launch (`KsExtraFwd`); when stage A is more than one launch
+    (W budget of one row: one key modulus x one polynomial per launch) the rows get their own launch first.  Both,
+    and the fused form, against the oracle -- general multiply, the squaring shortcut, with modulus switching, and the
+    stock n = 4096 set (an LDS-row instance) through the C oracle."""
+    import ref_params
+    for w in (0, 1):
+        with _unfused(fhe, w_budget=w):
+            cases.case_multiply_square(fhe, False)
+            cases.case_multiply(fhe, False, nmod=3, level=0, batch=2)
+            ref_params.check_mul(fhe, False, 4096, relin=True, batch=2)
+    with _unfused(fhe, mode=fhe.KeySwitchingKey.FUSED):
+        cases.case_multiply_square(fhe, False)
+        ref_params.check_mul(fhe, False, 4096, relin=True, batch=2)
+
+
 def test_unfused_decomposition_keys_stay_fused(fhe):
     with _unfused(fhe):
         cases.case_key_switch_decomposition(fhe, False)

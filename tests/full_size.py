@@ -170,6 +170,37 @@ def check_relin_rotate(fhe, n, sizes, batch, cfg, sample=None):
             assert np.array_equal(u64(r[i]), ck.galois_relinearize(e, np.stack(parts[:2]))), f"rotate e={e} ct {i}"
 
 
+def check_relin_rotate_host(fhe, n, sizes, batch, cfg):
+    """check_relin_rotate through the host-pointer entry points (numpy in / out), every ciphertext."""
+    q = obfv.generate_moduli(sizes, n)
+    seed = synth.seed_for_config(cfg)
+    L = len(q)
+    ctx = fhe.Context(q, n)
+    cc = coracle.CCtx(OCtx(q, n))
+    ck = host_key(cc, seed, L)
+    ksk = fhe.KeySwitchingKey(ctx, ctx, ck.c0, ck.c1)
+    ct3 = np.stack([np.stack([cc.synth_poly(seed, i, p) for p in range(3)]) for i in range(batch)])
+    got = fhe.RelinearizationKey(ksk).relinearizes(ct3)
+    ct2 = np.ascontiguousarray(ct3[:, :2])
+    rots = {e: fhe.GaloisKey(ksk, e).relinearize(ct2) for e in (3, 2 * n - 1)}
+    for i in range(batch):
+        k0, k1 = ck.key_switch(cc.poly_ntt_backward(ct3[i, 2]))
+        want = np.stack([cc.poly_add(ct3[i, 0], k0), cc.poly_add(ct3[i, 1], k1)])
+        assert np.array_equal(np.asarray(got[i]).view(np.uint64), want), f"relinearize {i}"
+        for e, r in rots.items():
+            assert np.array_equal(np.asarray(r[i]).view(np.uint64), ck.galois_relinearize(e, ct2[i])), f"rotate e={e} ct {i}"
+
+
+def check_random_shape_host(fhe, idx, big=False):
+    """check_random_shape on host buffers (the emulation build of the kernel sources runs it without a GPU)."""
+    n, sizes, batch = random_shape(idx, big)
+    cfg = 100 + idx
+    L = len(sizes)
+    check_mul_host(fhe, n, sizes, batch, relin=L >= 2, cfg=cfg, mod_switch=L >= 2 and idx % 2 == 0)
+    if L >= 2:
+        check_relin_rotate_host(fhe, n, sizes, batch, cfg)
+
+
 def check_chain(fhe, n, sizes, batch, levels, cfg):
     import torch
     q = obfv.generate_moduli(sizes, n)

@@ -623,6 +623,10 @@ __global__ void __launch_bounds__((1 << LOGM) / 8, 4)
 // Cooley-Tukey stages are folded into the loader exactly as in ks_fused_split_kernel.
 // Output range: NARROW (key moduli below 2^60) values below 4p < 2^62, otherwise canonical: both below 2^62, which
 // is what stage B's four-multiply product (mul_wide62) takes.
+template <int V>
+struct KsLiftMode {
+    static constexpr int value = V;
+};
 template <int LOGM, int G0, bool NARROW, bool RNS>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     ks_ntt_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ w, const DevMod *__restrict__ mods,
@@ -673,40 +677,59 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     const uint32_t digit_shift_bits = digit_arg & 0xff, lift_mode = digit_arg >> 8;  // see ks_fused_kernel
     const uint32_t sh = i * digit_shift_bits;
     const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
-    auto lift = [&](u64 v) -> u64 {
-        if constexpr (RNS) return csub_n(v, p, pm.np);
-        v = (v >> sh) & mask;
-        if (lift_mode == 1) return csub_n(v, p, pm.np);
-        if (lift_mode == 2) return csub_n(csub_n(v, p2, pm.np2), p, pm.np);
-        return reduce_u64(v, md);
-    };
     const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N) + (G0 ? 0 : (u64)sub * M);
-    auto load = [&](uint32_t idx, uint32_t) -> u64 {
-        if constexpr (G0 == 0) {
-            return lift(src[idx]);
-        } else {
-            u64 v[NS];
-#pragma unroll
-            for (int k = 0; k < NS; k++) v[k] = lift(src[idx + (u64)k * M]);
-#pragma unroll
-            for (int st = 0; st < G0; st++) {   // stage st keeps the half of the pairs whose output leads to `sub`
-                const int half = NS >> (st + 1);
-                const u64x2 wv = twr[(1u << st) + (sub >> (G0 - st))];
-                const bool minus = (sub >> (G0 - st - 1)) & 1;   // (uniform over the workgroup)
-                if (minus) {
-#pragma unroll
-                    for (int m = 0; m < half; m++)
-                        v[m] = csub_n(v[m], p2, pm.np2) + p2 - mul_shoup_lazy_n<true>(v[m + half], wv.x, wv.y, pm.np);
-                } else {
-#pragma unroll
-                    for (int m = 0; m < half; m++)
-                        v[m] = mul_shoup_lazy_add_n<true>(csub_n(v[m], p2, pm.np2), v[m + half], wv.x, wv.y, pm.np);
-                }
+    // The lift mode is a compile-time constant of the transform's loader (three uniform branches around the whole
+    // transform, below).  Round 5: as a run-time test inside the loader it put a branch diamond behind every one of the
+    // first pass's sixteen global loads, and the compiler then waited for each load before issuing the next (global
+    // loads are not speculated across a branch): `global_load -> s_waitcnt vmcnt(0) -> s_cbranch` sixteen times per
+    // thread, 5-6 us of a 12 us single-workgroup transform on every basis whose moduli differ in width -- the
+    // reference's stock sets (43/44-bit and 48/49-bit rows: lift mode 2), which have no RNS instance.
+    auto run = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;   // 1: digit < 2p, 2: digit < 4p, 0: anything (Barrett), 3: RNS instance
+        auto lift = [&](u64 v) -> u64 {
+            if constexpr (MODE == 3) {
+                return csub_n(v, p, pm.np);
+            } else {
+                v = (v >> sh) & mask;
+                if constexpr (MODE == 1) return csub_n(v, p, pm.np);
+                if constexpr (MODE == 2) return csub_n(csub_n(v, p2, pm.np2), p, pm.np);
+                return reduce_u64(v, md);
             }
-            return v[0];   // below 4p
-        }
+        };
+        auto load = [&](uint32_t idx, uint32_t) -> u64 {
+            if constexpr (G0 == 0) {
+                return lift(src[idx]);
+            } else {
+                u64 v[NS];
+#pragma unroll
+                for (int k = 0; k < NS; k++) v[k] = lift(src[idx + (u64)k * M]);
+#pragma unroll
+                for (int st = 0; st < G0; st++) {   // stage st keeps the half of the pairs whose output leads to `sub`
+                    const int half = NS >> (st + 1);
+                    const u64x2 wv = twr[(1u << st) + (sub >> (G0 - st))];
+                    const bool minus = (sub >> (G0 - st - 1)) & 1;   // (uniform over the workgroup)
+                    if (minus) {
+#pragma unroll
+                        for (int m = 0; m < half; m++)
+                            v[m] = csub_n(v[m], p2, pm.np2) + p2 - mul_shoup_lazy_n<true>(v[m + half], wv.x, wv.y, pm.np);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < half; m++)
+                            v[m] = mul_shoup_lazy_add_n<true>(csub_n(v[m], p2, pm.np2), v[m + half], wv.x, wv.y, pm.np);
+                    }
+                }
+                return v[0];   // below 4p
+            }
+        };
+        ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? (G0 ? 4 : 1) : 0)>(lds, twr, NS + sub, pm, tid, load);
     };
-    ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? (G0 ? 4 : 1) : 0)>(lds, twr, NS + sub, pm, tid, load);
+    if constexpr (RNS) {
+        run(KsLiftMode<3>{});
+    } else {
+        if (lift_mode == 1) run(KsLiftMode<1>{});          // (block-uniform: digit_arg is a kernel argument)
+        else if (lift_mode == 2) run(KsLiftMode<2>{});
+        else run(KsLiftMode<0>{});
+    }
     u64 *dst = w + (u64)rowb * N + (u64)sub * M;
     if constexpr (NARROW) {   // below 16p -> below 4p
         const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;

@@ -708,14 +708,14 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
                     const int half = NS >> (st + 1);
                     const u64x2 wv = twr[(1u << st) + (sub >> (G0 - st))];
                     const bool minus = (sub >> (G0 - st - 1)) & 1;   // (uniform over the workgroup)
-                    if (minus) {
+                    // x + t or x + 2p - t as a SELECT, not a branch: a branch diamond here sits between this group's
+                    // global loads and the next group's, and the compiler then finishes each group before it issues the
+                    // next loads (ISA, round 5: `2 x global_load -> s_waitcnt vmcnt(0) -> s_cbranch` sixteen times per
+                    // thread) -- the same serialisation the lift mode caused above
 #pragma unroll
-                        for (int m = 0; m < half; m++)
-                            v[m] = csub_n(v[m], p2, pm.np2) + p2 - mul_shoup_lazy_n<true>(v[m + half], wv.x, wv.y, pm.np);
-                    } else {
-#pragma unroll
-                        for (int m = 0; m < half; m++)
-                            v[m] = mul_shoup_lazy_add_n<true>(csub_n(v[m], p2, pm.np2), v[m + half], wv.x, wv.y, pm.np);
+                    for (int m = 0; m < half; m++) {
+                        const u64 t = mul_shoup_lazy_n<true>(v[m + half], wv.x, wv.y, pm.np);   // below 2p
+                        v[m] = csub_n(v[m], p2, pm.np2) + (minus ? p2 - t : t);
                     }
                 }
                 return v[0];   // below 4p

@@ -3,7 +3,7 @@
 tools/isa_mix.py) counts the loads that are followed by `s_waitcnt vmcnt(0)` before any other load is issued -- a load the
 wave sits out alone -- next to the kernel's loads, branches and instructions.  High counts with many branches are loaders whose
 per-element control flow keeps the compiler from batching their loads (round 5: ks_ntt_kernel's lift mode and folded stages).
-usage: python tools/isa_serial_loads.py /tmp/fhe_dev.s"""
+usage: python tools/isa_serial_loads.py /tmp/fhe_dev.s [regex on the kernel name]   (TOP=n lines, default 60)"""
 import re,sys,subprocess,collections
 lines=open(sys.argv[1]).read().split("\n")
 kern=None; res={}
@@ -38,4 +38,6 @@ for (k,v),nm in zip(res.items(),names):
     short=re.sub(r"\(.*","",nm).replace("void fhe::k::","")
     out.append((v[0],v[1],v[2],v[3],short))
 out.sort(reverse=True)
-for o in out[:60]: print("%4d isolated-wait loads of %4d loads, %4d branches, %6d instrs  %s"%o)
+import os
+flt = re.compile(sys.argv[2]) if len(sys.argv) > 2 else None
+for o in [x for x in out if flt is None or flt.search(x[4])][:int(os.environ.get("TOP", "60"))]: print("%4d isolated-wait loads of %4d loads, %4d branches, %6d instrs  %s"%o)

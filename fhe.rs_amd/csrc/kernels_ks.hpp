@@ -687,14 +687,16 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     auto run = [&](auto mode_c) {
         constexpr int MODE = decltype(mode_c)::value;   // 1: digit < 2p, 2: digit < 4p, 0: anything (Barrett), 3: RNS instance
         auto lift = [&](u64 v) -> u64 {
+            u64 r;   // (one return: g++ -- the emulation build -- misreads returns inside `if constexpr` of a nested lambda)
             if constexpr (MODE == 3) {
-                return csub_n(v, p, pm.np);
+                r = csub_n(v, p, pm.np);
             } else {
                 v = (v >> sh) & mask;
-                if constexpr (MODE == 1) return csub_n(v, p, pm.np);
-                if constexpr (MODE == 2) return csub_n(csub_n(v, p2, pm.np2), p, pm.np);
-                return reduce_u64(v, md);
+                if constexpr (MODE == 1) r = csub_n(v, p, pm.np);
+                else if constexpr (MODE == 2) r = csub_n(csub_n(v, p2, pm.np2), p, pm.np);
+                else r = reduce_u64(v, md);
             }
+            return r;
         };
         auto load = [&](uint32_t idx, uint32_t) -> u64 {
             if constexpr (G0 == 0) {

@@ -157,6 +157,7 @@ SIGNATURES = {
     "fhe_prof_reset": (None, []),
     "fhe_prof_count": (sz, []),
     "fhe_prof_get": (i32, [sz, C.c_char_p, sz, u64p, C.POINTER(C.c_double)]),
+    "fhe_prof_get_symbol": (i32, [sz, C.c_char_p, sz]),
 }
 
 _lib = None

@@ -145,11 +145,11 @@ class DeviceArray:
         if not 0 <= i < self.shape[0]:
             raise IndexError(i)
         sub = self.nbytes // self.shape[0]
-        return DeviceArray(self.shape[1:], self.device, self.itemsize, _ptr=self._p + i * sub, _base=self._base or self)
+        return DeviceArray(self.shape[1:], self.device, self.itemsize, _ptr=self._p + i * sub, _base=self if self._base is None else self._base)
 
     def reshape(self, *shape):
         shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
-        v = DeviceArray(shape, self.device, self.itemsize, _ptr=self._p, _base=self._base or self)
+        v = DeviceArray(shape, self.device, self.itemsize, _ptr=self._p, _base=self if self._base is None else self._base)
         if v.nbytes != self.nbytes:
             raise ValueError("reshape changes the size")
         return v
@@ -164,7 +164,7 @@ class DeviceArray:
         """Called for every engine call that takes this array: remembers whether any of them ran on a stream other
         than the allocating one (an array used inside another `with Stream` block and dropped after
         returning to its own stream must not be freed in the allocating stream's order)."""
-        root = self._base or self
+        root = self if self._base is None else self._base   # (not `or`: __len__ makes an empty base falsy)
         if root._astream is not None and getattr(_tls, "stream", None) is not root._astream:
             root._other_stream_use = True
 
@@ -1071,14 +1071,25 @@ def prof_reset():
 
 
 def prof_report():
-    """{kernel name: (launches, total_ms)} from HIP events recorded on the launching stream."""
-    L = _lib.lib()
+    """{launch label: (launches, total_ms)} from the HIP events the launches carried (entries of one label summed)."""
     out = {}
+    for label, _sym, n, ms in prof_entries():
+        a = out.get(label, (0, 0.0))
+        out[label] = (a[0] + n, a[1] + ms)
+    return out
+
+
+def prof_entries():
+    """[(launch label, kernel symbol, launches, total_ms)]: one entry per kernel instantiation, named as rocprofv3 names
+    it (fhe_prof_get + fhe_prof_get_symbol)."""
+    L = _lib.lib()
+    out = []
     for i in range(L.fhe_prof_count()):
-        name = C.create_string_buffer(64)
+        name, sym = C.create_string_buffer(64), C.create_string_buffer(512)
         n, ms = C.c_uint64(), C.c_double()
         check(L.fhe_prof_get(i, name, 64, C.byref(n), C.byref(ms)))
-        out[name.value.decode()] = (n.value, ms.value)
+        check(L.fhe_prof_get_symbol(i, sym, 512))
+        out.append((name.value.decode(), sym.value.decode(), n.value, ms.value))
     return out
 
 
@@ -1111,7 +1122,10 @@ def workspace_pool_stats(device=0):
 
 
 UBENCH_KINDS = {"mad_u64_u32": 0, "mul_lo_u32": 1, "mul_hi_u32": 2, "shoup_lazy": 3, "fwd_butterfly": 4,
-                "fwd_butterfly_narrow": 5, "inv_butterfly": 6, "shoup_mac": 7, "tensor_mul": 8, "tensor_mac2": 9}
+                "fwd_butterfly_narrow": 5, "inv_butterfly": 6, "shoup_mac": 7, "tensor_mul": 8, "tensor_mac2": 9,
+                # round 6: the FP64-FMA forms for moduli below 2^50 (csrc/zq_f64.hpp)
+                "f64_fma": 10, "f64_rndne": 11, "f64_mulmod": 12, "f64_fwd_butterfly": 13, "f64_inv_butterfly": 14,
+                "f64_mac": 15}
 
 
 def ubench_int(kind, min_seconds=0.05, device=0):

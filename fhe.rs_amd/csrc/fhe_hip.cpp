@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <map>
 
+#include <cxxabi.h>
+
 #include "engine.hpp"
 #include "ubench.hpp"
 
@@ -1788,6 +1790,24 @@ fhe_status fhe_prof_get(size_t index, char *name, size_t name_cap, uint64_t *lau
         if (name && name_cap) std::snprintf(name, name_cap, "%s", e.name.c_str());
         if (launches) *launches = e.launches;
         if (total_ms) *total_ms = e.ms;
+    });
+}
+fhe_status fhe_prof_get_symbol(size_t index, char *symbol, size_t symbol_cap) {
+    return guard([&] {
+        Profiler &p = Profiler::get();
+        std::lock_guard<std::mutex> lk(p.mu);
+        if (index >= p.entries.size()) throw StatusError(FHE_E_ARG, "profile index out of range");
+        if (!symbol || !symbol_cap) throw StatusError(FHE_E_ARG, "symbol buffer is null");
+        const auto &e = p.entries[index];
+        const char *mangled = e.fn ? hipKernelNameRefByPtr(e.fn, nullptr) : nullptr;
+        std::string text = e.name;                     // (no symbol known to the runtime: the label)
+        if (mangled && *mangled) {
+            int st = 0;
+            char *dm = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+            text = (st == 0 && dm) ? dm : mangled;
+            std::free(dm);
+        }
+        std::snprintf(symbol, symbol_cap, "%s", text.c_str());
     });
 }
 

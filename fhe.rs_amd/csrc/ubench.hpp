@@ -7,6 +7,7 @@
 // Nothing here is on the product path; tools/ubench_int.cpp holds the wider catalogue of round 1-2 experiments.
 #pragma once
 #include "engine.hpp"
+#include "zq_f64.hpp"
 
 namespace fhe {
 namespace ub {
@@ -23,7 +24,14 @@ enum Kind : int {
     SHOUP_MAC = 7,     // the key switch's accumulate: acc = csub(acc + v * k (Shoup, lazy), 2p)   (kernels_ks.hpp)
     TENSOR_MUL = 8,    // tensor slots 0 / 2: one product of two residues + single-word Barrett, lazy  (mul_mod_lazy)
     TENSOR_MAC2 = 9,   // tensor slot 1: a0 b1 + a1 b0 as one 128-bit sum + one Barrett  (mac2_wide62 + barrett_reduce_wide_lazy)
-    NKINDS = 10
+    // round 6: the FP64-FMA alternative for moduli below 2^50 (zq_f64.hpp), priced before it is built
+    F64_FMA = 10,      // v_fma_f64, a dependent chain per lane
+    F64_RNDNE = 11,    // v_rndne_f64 (+ one v_add_f64 that keeps the chain alive)
+    F64_MULMOD = 12,   // mulmod_f64: one exact lazy modular product, precomputed w / p
+    F64_FWD = 13,      // fwd_butterfly_f64 + the amortised reduction (both outputs reduced every fourth stage)
+    F64_INV = 14,      // inv_butterfly_f64 + the sum reduced every second stage
+    F64_MAC = 15,      // the key switch's accumulate on doubles: acc += v k (lazy), acc reduced every eighth term
+    NKINDS = 16
 };
 constexpr int ILP = 8, ITERS = 2048;
 
@@ -88,6 +96,50 @@ __global__ void __launch_bounds__(256) ubench_kernel(u64 *out, u64 seed, u64 p, 
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// The same loop on doubles holding integers (zq_f64.hpp).  The modulus is a 49-bit prime of the reference's stock
+// n = 16384 set (parameters.rs:243-251); values stay exact residues here (the reductions are part of the stream).
+template <int KIND>
+__global__ void __launch_bounds__(256) ubench_f64_kernel(u64 *out, u64 seed, double p, double ip, double w, double wp) {
+    double x[ILP], y[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; i++) {
+        x[i] = (double)((seed + threadIdx.x * 977 + i * 131 + blockIdx.x) & 0xFFFFFFFFFFFFull);
+        y[i] = (double)(((seed + threadIdx.x * 977 + i * 131 + blockIdx.x) * 0x9E3779B97F4A7C15ull) >> 16);
+    }
+    // (wave-uniform constants kept opaque, as the kernels load them: no folding into immediates)
+    union {
+        double d;
+        u64 u;
+    } cp{p}, cip{ip}, cw{w}, cwp{wp};
+    cp.u = opaque_s(cp.u), cip.u = opaque_s(cip.u), cw.u = opaque_s(cw.u), cwp.u = opaque_s(cwp.u);
+    const PF m{cp.d, cip.d};
+    w = cw.d, wp = cwp.d;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            if (KIND == F64_FMA) x[i] = f64_fma(x[i], w, y[i]);
+            if (KIND == F64_RNDNE) x[i] = f64_rint(x[i]) + y[i];
+            if (KIND == F64_MULMOD) x[i] = mulmod_f64(x[i], w, wp, m.p);
+            if (KIND == F64_FWD) {
+                fwd_butterfly_f64(x[i], y[i], w, wp, m.p);
+                if ((it & 3) == 3) x[i] = reduce_f64(x[i], m), y[i] = reduce_f64(y[i], m);
+            }
+            if (KIND == F64_INV) {
+                inv_butterfly_f64(x[i], y[i], w, wp, m.p);
+                if (it & 1) x[i] = reduce_f64(x[i], m);
+            }
+            if (KIND == F64_MAC) {
+                x[i] = mulmod_add_f64(x[i], y[i], w, wp, m.p);
+                if ((it & 7) == 7) x[i] = reduce_f64(x[i], m);
+            }
+        }
+    }
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; i++) acc += x[i] + y[i];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = (u64)(long long)acc;
+}
+
 // Runs kernel `kind` for at least `min_seconds` on `device` (one warm-up launch first); returns operations per second
 // chip-wide (one operation = one multiply / one modular product / one butterfly per lane).
 inline double run(int device, int kind, double min_seconds) {
@@ -98,6 +150,7 @@ inline double run(int device, int kind, double min_seconds) {
     DevBuf<u64> out;
     out.alloc((size_t)blocks * threads);
     const u64 p = 1152921504606830593ull, w = 123456789012345ull, ws = shoup(w, p);
+    const double pf = 562949951979521.0 /* 0x1fffffff68001 */, wf = 123456789012345.0;
     const ModConsts mc = make_mod_consts(p);
     DevMod md;
     static_assert(sizeof(DevMod) == sizeof(ModConsts), "DevMod layout");
@@ -111,6 +164,10 @@ inline double run(int device, int kind, double min_seconds) {
     case K: hipLaunchKernelGGL(ubench_kernel<K>, dim3(blocks), dim3(threads), 0, s, out.p, seed, p, w, ws, md); break;
             FHE_UB_CASE(0) FHE_UB_CASE(1) FHE_UB_CASE(2) FHE_UB_CASE(3) FHE_UB_CASE(4) FHE_UB_CASE(5) FHE_UB_CASE(6)
             FHE_UB_CASE(7) FHE_UB_CASE(8) FHE_UB_CASE(9)
+#undef FHE_UB_CASE
+#define FHE_UB_CASE(K) \
+    case K: hipLaunchKernelGGL(ubench_f64_kernel<K>, dim3(blocks), dim3(threads), 0, s, out.p, seed, pf, 1.0 / pf, wf, wf / pf); break;
+            FHE_UB_CASE(10) FHE_UB_CASE(11) FHE_UB_CASE(12) FHE_UB_CASE(13) FHE_UB_CASE(14) FHE_UB_CASE(15)
 #undef FHE_UB_CASE
         }
     };
@@ -203,7 +260,9 @@ inline double run_copy(int device, size_t bytes, double min_seconds) {
 // The scaler's ceiling: scale_kernel itself -- the very instance that serves `sc` -- over `columns` coefficient
 // columns whose polynomial strides are ZERO, i.e. every lane group reads the same nfrom rows (N * nfrom * 8 bytes: L2
 // resident) and writes the same rows: the instruction stream of RnsScaler::scale with no HBM traffic.  Returns columns
-// per second chip-wide.  (A cache-resident, not a register-resident ceiling: the loads and stores still issue.)
+// per second chip-wide.  (A cache-resident, not a register-resident ceiling: the loads and stores still issue -- and,
+// the output strides being zero too, every workgroup stores to the same lines: the rate includes those same-line store
+// conflicts, so it is a slightly LOW ceiling.)
 inline double run_scaler(const Scaler &sc, double min_seconds) {
     require(min_seconds > 0 && min_seconds <= 10, E_ARG, "min_seconds must be in (0, 10]");
     const Ctx &f = *sc.from, &t = *sc.to;
@@ -218,8 +277,7 @@ inline double run_scaler(const Scaler &sc, double min_seconds) {
     FHE_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     double result = 0;
-    const bool was_on = Profiler::get().enabled;
-    Profiler::get().enabled = false;
+    const Profiler::Suppress no_profile;   // (this thread's launches only; other threads keep profiling)
     try {
         FHE_HIP_CHECK(hipEventCreate(&e0));
         FHE_HIP_CHECK(hipEventCreate(&e1));
@@ -239,13 +297,11 @@ inline double run_scaler(const Scaler &sc, double min_seconds) {
         }
         result = (double)npolys * f.n * (double)launches / (total_ms * 1e-3);
     } catch (...) {
-        Profiler::get().enabled = was_on;
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
         (void)hipStreamDestroy(s);
         throw;
     }
-    Profiler::get().enabled = was_on;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipStreamDestroy(s);

@@ -497,7 +497,9 @@ fhe_status fhe_workspace_pool_stats(int device, size_t *scratch_reserved_bytes, 
  * (0 < min_seconds <= 10).  which: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32, 3 lazy Shoup product,
  * 4 forward butterfly (any modulus < 2^62), 5 forward butterfly for moduli < 2^60, 6 inverse butterfly,
  * 7 the key switch's Shoup multiply-accumulate, 8 the tensor product of slots 0 / 2 (one product + single-word Barrett),
- * 9 the tensor product of slot 1 (two products, one 128-bit sum, one Barrett);
+ * 9 the tensor product of slot 1 (two products, one 128-bit sum, one Barrett); 10-15 (round 6) the FP64 forms for
+ * moduli below 2^50 (csrc/zq_f64.hpp): 10 v_fma_f64, 11 v_rndne_f64, 12 exact lazy modular product, 13 forward and
+ * 14 inverse butterfly with their amortised reductions, 15 the key switch's multiply-accumulate;
  * *ops_per_s = lane-operations (multiplies / products / butterflies) per second.  Measurement aid, not on the path.
  * fhe_ubench_scaler: RnsScaler::scale's ceiling -- the scale_kernel instance that serves `scaler`, run over coefficient
  * columns that all alias ONE polynomial (L2 resident: the instruction stream without HBM traffic); *columns_per_s
@@ -507,11 +509,15 @@ fhe_status fhe_ubench_scaler(const fhe_scaler *scaler, double min_seconds, doubl
 /* The box's own streaming rate: a 16-byte-per-lane copy of `bytes` bytes with streaming loads / stores (the path's
  * element-wise kernels are made of the same accesses); *bytes_per_s = read + write bytes per second. */
 fhe_status fhe_ubench_copy(int device, size_t bytes, double min_seconds, double *bytes_per_s);
-/* Per-kernel HIP-event timing (events recorded on the launching stream). */
+/* Per-kernel HIP-event timing (events carried by the launches, on the launching stream).  One entry per (launch label,
+ * kernel symbol): fhe_prof_get gives the entry's label -- several entries share a label when several instantiations of a
+ * kernel template run under it; sum them for the family -- and fhe_prof_get_symbol the kernel's demangled symbol, the
+ * name rocprofv3 lists it under.  (No reference counterpart: fhe.rs times with Criterion on the host.) */
 void fhe_prof_enable(int on);
 void fhe_prof_reset(void);
 size_t fhe_prof_count(void);
 fhe_status fhe_prof_get(size_t index, char *name, size_t name_cap, uint64_t *launches, double *total_ms);
+fhe_status fhe_prof_get_symbol(size_t index, char *symbol, size_t symbol_cap);
 
 #ifdef __cplusplus
 }

@@ -135,6 +135,8 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+// (no code objects here: the profiler's symbol lookup falls back to the launch label)
+inline const char *hipKernelNameRefByPtr(const void *, hipStream_t) { return nullptr; }
 // FHE_EMU_DEVICES=<n> (read once): the emulator reports n "devices" (all of them this host), each thread has a
 // current one -- enough to walk the engine's per-device bookkeeping (handles, scratch pools, the sharded multiply)
 // in CI without a second GPU

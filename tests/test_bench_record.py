@@ -1,0 +1,136 @@
+"""bench.py's record line (CPU): the LAST stdout line must be a compact JSON object the driver can keep whole.
+
+Round 5 lost its driver-checked measurement because the single line had grown to 24.6 KB and the driver keeps a
+2,000-character tail.  `compact_record` builds the record from the full result; these tests feed it
+round 5's real 24.6 KB line (profiles/r05_final5_bench_steps20.json), with the N > 1 and binding-ceiling blocks a run
+can add on top, and check length and keys.  The integer-ceiling model the record's `configs` block comes from is checked
+against round 5's published C2 figure.  (The GPU-side check -- the real command's last line -- is
+tests/test_gpu_parity.py::test_bench_record_is_compact.)"""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (no side effects: main() is guarded)
+
+R05 = os.path.join(ROOT, "profiles", "r05_final5_bench_steps20.json")
+
+RECORD_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "ntt"}
+ROOFLINE_KEYS = {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_observed_this_run",
+                 "kernel_sum_ms_per_step", "kernel_sum_le_step", "launches", "avg_launch_ms", "algorithmic_bytes_per_launch",
+                 "binding", "frac_of_binding_ceiling", "frac_hbm_whole_op"}
+
+
+def _full():
+    full = json.load(open(R05))
+    assert len(json.dumps(full)) > 20000          # the line that did not parse
+    return full
+
+
+def _worst_case(full, n1=False):
+    """Everything a run can add on top.  N > 1: eight ranks' identities, per-rank rates (no informational legs run there).
+    N = 1 (n1): every config's ceiling entry, the symbol-keyed dominant kernel, errors."""
+    full = dict(full)
+    if n1:
+        full["roofline"]["dominant_by_symbol"] = dict(
+            kernel="ks_fused_kernel<13, true, 3, 0, true, 0, false>", label="key_switch_fused", launches=120, ms=58.623,
+            avg_launch_ms=0.4885, achieved=2197.9, frac=0.2747, share_of_kernel_time=0.185)
+        names = ["C2", "C3_relinearize", "C3_rotate_columns", "C3_rotate_rows", "C5_level0", "C5_level0_batch64", "C5_chain"]
+        names += ["stock%d_%s" % (n, i) for n in (4096, 8192, 16384) for i in ("relinearize", "rotate_columns", "mul_and_relin")]
+        full["binding_ceilings"] = {k: bench.ceiling_entry(123456.7, 19660800, 3.4e-6) for k in names}
+        full["binding_ceilings"]["note"] = "y" * 300
+        full["errors"] = ["leg: RuntimeError: " + "z" * 150]
+        return full
+    full["n_gpus"] = 8
+    full["config"] = dict(full["config"], workload=bench.workload_name(8, bench.BATCH_PER_GPU_SHARDED), dist_backend="nccl",
+                          dist_world_size=8, global_batch=65536, batch_per_gpu=8192)
+    full["multi_gpu"] = dict(rccl_world_size=8, dist_backend="nccl", distinct_devices=8, one_device_per_rank=True,
+                             ranks=[dict(rank=r, pci="0000:%02x:00.0" % r, uuid="GPU-%032x" % r, name="AMD Instinct MI355X")
+                                    for r in range(8)],
+                             solo_rank0_ops_per_s=191234.5, efficiency_vs_1gpu_same_batch=0.9876, data_path_collectives=0,
+                             n1_reference={"batch_8192": dict(value=190000.1, ms_per_step=43.1),
+                                           "batch_1024": dict(value=191362.4, ms_per_step=5.351), "note": "x" * 200})
+    full["per_rank"] = dict(ops_per_s=[191000.5 + r for r in range(8)], max_over_min=1.0123)
+    return full
+
+
+def test_compact_record_fits_the_driver_tail_and_has_the_keys():
+    for full in (_full(), _worst_case(_full()), _worst_case(_full(), n1=True)):
+        line = bench.compact_record(full)
+        assert "\n" not in line and len(line) < bench.COMPACT_LIMIT <= 1900, len(line)   # (the driver's tail: 2,000)
+        rec = json.loads(line)
+        assert RECORD_KEYS <= set(rec), RECORD_KEYS - set(rec)
+        assert ROOFLINE_KEYS <= set(rec["roofline"]), ROOFLINE_KEYS - set(rec["roofline"])
+        assert {"value", "unit", "cores", "kind", "sample", "single_thread_ops_per_s"} <= set(rec["cpu_baseline"])
+        assert {"poly_ntt_per_s", "row_ntt_per_s", "frac"} <= set(rec["ntt"])
+        assert {"workload", "batch_per_gpu", "global_batch", "parallelism"} <= set(rec["config"])
+        assert rec["metric"] == full["metric"] and rec["value"] == full["value"] and rec["dtype"] == "u64"
+        assert rec["roofline"]["frac"] == full["roofline"]["frac"] and rec["vs_baseline"] is None
+        assert rec["detail"] == "bench_detail.json"
+    rec = json.loads(bench.compact_record(_worst_case(_full())))
+    assert rec["multi_gpu"]["distinct_devices"] == 8 and rec["multi_gpu"]["n1_batch_1024_value"] == 191362.4
+    assert rec["multi_gpu"]["efficiency_vs_1gpu_same_batch"] == 0.9876 and "ranks" not in rec["multi_gpu"]
+    rec = json.loads(bench.compact_record(_worst_case(_full(), n1=True)))
+    assert rec["roofline"]["dominant_symbol"]["kernel"].startswith("ks_fused_kernel<13")
+    assert len(rec["configs"]) == 8 and len(rec["configs"]["C3_relinearize"]) == 2 and rec["errors"] == 1
+
+
+def test_compact_record_never_drops_the_contract_when_it_must_shed():
+    """A pathological result (a very long workload string, many configs): optional blocks go, the contract stays."""
+    full = _worst_case(_full(), n1=True)
+    full["config"]["workload"] = "W" * 900
+    full["binding_ceilings"] = {("config_%03d" % i): bench.ceiling_entry(1.0 + i, 1 << 20, 1e-6) for i in range(60)}
+    line = bench.compact_record(full)
+    assert len(line) < 2000
+    rec = json.loads(line)
+    assert {"metric", "value", "unit", "n_gpus", "ms_per_step", "roofline", "cpu_baseline", "config"} <= set(rec)
+    assert "configs" not in rec
+
+
+def test_emit_prints_detail_first_and_the_record_last(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "DETAIL_FILE", str(tmp_path / "bench_detail.json"))
+    full = _full()
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit(full)
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 2 and lines[0].startswith("DETAIL {") and lines[1].startswith("{") and len(lines[1]) < 2000
+    assert json.loads(lines[0][len("DETAIL "):])["value"] == json.loads(lines[1])["value"] == full["value"]
+    assert json.load(open(tmp_path / "bench_detail.json"))["other_configs"].keys() == full["other_configs"].keys()
+    # what the driver does: the last line that parses as a JSON object, out of a 2,000-character tail
+    tail = buf.getvalue()[-2000:]
+    last = [l for l in tail.splitlines() if l.startswith("{")][-1]
+    assert json.loads(last)["roofline"]["bound"] == "hbm" and "cpu_baseline" in json.loads(last)
+
+
+def test_short_symbol():
+    s = "void fhe::k::ntt_kernel<false, 13, true, 1, false>(unsigned long const*, unsigned long*, fhe::k::RowMap, fhe::DevMod const*)"
+    assert bench.short_symbol(s) == "ntt_kernel<false, 13, true, 1, false>"
+    assert bench.short_symbol("fhe::k::ew_kernel(unsigned long*, unsigned long const*)") == "ew_kernel"
+    assert bench.short_symbol("key_switch_fused") == "key_switch_fused"
+
+
+def test_integer_ceiling_model_reproduces_round5_c2():
+    """mul_relin_work / ideal_seconds with round 5's measured rates give round 5's published whole-op ceiling (277.2 k
+    ops/s, 3.607 us: roofline.int_issue.whole_op of the same file), and key_switch_work prices C3's relinearise at the
+    reviewer's estimate (56 transforms + 2.10 M MACs ~ 3.42 us at the narrow / MAC rates; the model adds
+    the 8 inverse rows at the inverse rate)."""
+    ii = _full()["roofline"]["int_issue"]
+    rates = dict(fwd_butterfly=ii["butterflies_per_s_ceiling"]["forward_wide"],
+                 fwd_butterfly_narrow=ii["butterflies_per_s_ceiling"]["forward_narrow_lt_2p60"],
+                 inv_butterfly=ii["butterflies_per_s_ceiling"]["inverse"], shoup_mac=ii["shoup_mac_per_s"],
+                 tensor_mul=ii["tensor_mul_per_s"], tensor_mac2=ii["tensor_mac2_per_s"], shoup_lazy=ii["shoup_lazy_per_s"])
+    work = bench.mul_relin_work(8192, 4, 9, rates, ii["scale_extend_columns_per_s"], ii["scale_down_columns_per_s"])
+    ideal = bench.ideal_seconds(work)
+    assert abs(ideal * 1e6 - ii["whole_op"]["ideal_us_per_op"]) < 0.002
+    for fam, d in ii["per_kernel"].items():
+        assert abs(bench.ideal_seconds(work[fam]) * 1e6 - d["ideal_us_per_op"]) < 0.001, fam
+    ks = bench.key_switch_work(16384, 8, rates)
+    fwd_and_mac = sum(c / r for c, r in ks[1:])
+    assert abs(fwd_and_mac * 1e6 - 3.42) < 0.02
+    e = bench.ceiling_entry(115000.0, (2 * 8 + 64 + 32) * 8 * 16384, bench.ideal_seconds(ks))
+    assert e["binding"] == "int_issue" and 0.4 < e["frac_int_issue"] < 0.6 and abs(e["frac_hbm"] - 0.211) < 0.002

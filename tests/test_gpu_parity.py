@@ -312,6 +312,58 @@ def test_config_c5_bench_batches_n32768(fhe, batch):
     fhe.workspace_trim()
 
 
+def _bench_lines(stdout):
+    """(record, detail) of a bench.py run: the record is the LAST stdout line and must be what the driver can keep whole
+    (< 2,000 characters); everything else bench.py measured is the `DETAIL ` line before it."""
+    import json
+    lines = stdout.splitlines()
+    assert lines and lines[-1].startswith("{") and len(lines[-1]) < 2000, (len(lines[-1]) if lines else 0)
+    detail = [l for l in lines if l.startswith("DETAIL {")]
+    assert len(detail) == 1 and not [l for l in lines[:-1] if l.startswith("{")]     # nothing else can be mistaken for it
+    rec, det = json.loads(lines[-1]), json.loads(detail[0][len("DETAIL "):])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data"):
+        assert rec[k] == det[k], k
+    assert rec["vs_baseline"] is None and rec["roofline"]["bound"] == "hbm" and rec["roofline"]["frac"] == det["roofline"]["frac"]
+    return rec, det
+
+
+def test_bench_record_is_compact():
+    """the default-flags shape of the command the driver runs (extras ON, CPU leg ON), at a small step
+    count: the last stdout line parses, is below 2,000 characters and carries `roofline`, `cpu_baseline`, `ntt` and the
+    other configs' binding ceilings; the full result is in the DETAIL line and in bench_detail.json."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec, det = _bench_lines(r.stdout)
+    assert rec["n_gpus"] == 1 and rec["config"]["workload"].startswith("C2:") and rec["config"]["batch_per_gpu"] == 1024
+    rf = rec["roofline"]
+    for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_observed_this_run", "kernel_sum_ms_per_step",
+              "kernel_sum_le_step", "launches", "avg_launch_ms", "algorithmic_bytes_per_launch", "binding",
+              "frac_of_binding_ceiling", "frac_hbm_whole_op", "dominant_symbol"):
+        assert k in rf, k
+    assert rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["kernel_sum_le_step"] is True
+    # the dominant kernel by SYMBOL is a real kernel instantiation, named as rocprofv3 names it
+    assert "_kernel<" in rf["dominant_symbol"]["kernel"] and 0 < rf["dominant_symbol"]["share_of_kernel_time"] < 1
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"] and cb["unit"] == "ops/s"
+    assert rec["ntt"]["row_ntt_per_s"] == 4 * rec["ntt"]["poly_ntt_per_s"] or abs(rec["ntt"]["row_ntt_per_s"] / rec["ntt"]["poly_ntt_per_s"] - 4) < 1e-3
+    assert rec["parity"].startswith("bit-identical")
+    # binding ceilings of the other BASELINE configs and the stock sets: [frac_hbm, frac_int_issue]
+    for k in ("C3_relinearize", "C3_rotate_columns", "C5_level0", "C5_chain", "stock8192_mul_and_relin", "stock16384_relinearize"):
+        assert k in rec["configs"] and 0 < rec["configs"][k][0] < 1 and 0 < rec["configs"][k][1] < 1.05, (k, rec["configs"].get(k))
+    assert not det.get("errors"), det.get("errors")
+    assert det["binding_ceilings"]["C3_relinearize"]["binding"] in ("hbm", "int_issue")
+    syms = [e["kernel"] for e in det["roofline"]["by_symbol"]]
+    assert len(syms) == len(set(syms)) and sum("ntt_kernel<false, 13" in x for x in syms) == 2     # wide and narrow apart
+    on_disk = json.load(open(os.path.join(root, "bench_detail.json")))
+    assert on_disk["value"] == rec["value"] and "other_configs" in on_disk
+
+
 def test_bench_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` starts its own two ranks; on a one-GPU box they share the device and
     rendezvous over gloo (RCCL needs one device per rank).  The line must say n_gpus = 2."""
@@ -323,7 +375,8 @@ def test_bench_two_ranks_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--batch", "128", "--no-cpu", "--no-extras"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rec, line = _bench_lines(r.stdout)
+    assert rec["n_gpus"] == 2 and rec["multi_gpu"]["data_path_collectives"] == 0 and "efficiency_vs_1gpu_same_batch" in rec["multi_gpu"]
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256 and line["value"] > 0
     # round 4: the line says who ran where and what one GPU does alone on the same per-GPU batch
     mg = line["multi_gpu"]
@@ -346,7 +399,14 @@ def test_bench_eight_ranks_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
                         "--batch", "32", "--no-cpu", "--no-extras", "--sustain", "0.2"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rec, line = _bench_lines(r.stdout)
+    # the compact record of an N > 1 run (what SCALE_rNN.json keeps): world size, who ran where in summary, the one-GPU reference
+    mgc = rec["multi_gpu"]
+    assert rec["n_gpus"] == 8 and rec["config"]["dist_world_size"] == 8 and rec["config"]["global_batch"] == 256
+    for k in ("dist_backend", "distinct_devices", "one_device_per_rank", "efficiency_vs_1gpu_same_batch", "data_path_collectives",
+              "rank_max_over_min"):
+        assert k in mgc, k
+    assert "cpu_baseline" not in rec and "ranks" not in mgc and rec["scaling"] == "weak"
     assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 256 and line["value"] > 0
     mg = line["multi_gpu"]
     assert len(mg["ranks"]) == 8 and {x["rank"] for x in mg["ranks"]} == set(range(8)) and mg["data_path_collectives"] == 0

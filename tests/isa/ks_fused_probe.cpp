@@ -1,15 +1,18 @@
-// TEST INFRASTRUCTURE (tests/test_isa_guards.py): explicit instantiations of the FUSED key switch's generic (non-RNS)
-// instances for rows larger than LDS -- the loaders whose lift mode became a compile-time constant in round 6 -- so that
-// their device assembly can be produced in seconds and checked for serialised loads (tools/isa_serial_loads.py).
+// TEST INFRASTRUCTURE (tests/test_isa_guards.py): explicit instantiations of the FUSED key switch -- the two hot instances of
+// BASELINE configs C3 / C5 (N = 16384 tiles, RNS loader) and the generic (non-RNS) instances for rows larger than LDS -- so
+// that their device assembly can be produced in seconds and checked for scratch (spills) and serialised loads.
 #include "kernels.hpp"
 namespace fhe {
 namespace k {
-#define FHE_PROBE_F(NW, G0)                                                                                            \
-    template __global__ void ks_fused_kernel<14, NW, GM_MIXED, 0, false, G0, false>(                                   \
+#define FHE_PROBE_F(LOGN, NW, GM, RNS, G0)                                                                             \
+    template __global__ void ks_fused_kernel<LOGN, NW, GM, 0, RNS, G0, false>(                                         \
         const u64 *, u64, u64 *, u64 *, u64, const u64 *, const u64 *, u64, const u64 *, const u64 *, const u64 *,     \
         const u64 *, const DevMod *, const u64x2 *, uint32_t, uint32_t, uint32_t, const u64 *, u64, uint32_t, uint32_t);
-FHE_PROBE_F(true, 1)
-FHE_PROBE_F(true, 2)
+FHE_PROBE_F(14, true, GM_MIXED, true, 0)    // C3 relinearise / rotate
+FHE_PROBE_F(14, true, GM_MIXED, true, 1)    // C5 (N = 32768 as two halves)
+FHE_PROBE_F(13, true, KS_GMAX, true, 0)     // C2
+FHE_PROBE_F(14, true, GM_MIXED, false, 1)   // generic loaders, rows larger than LDS
+FHE_PROBE_F(14, true, GM_MIXED, false, 2)
 #define FHE_PROBE_S(G0, NW)                                                                                            \
     template __global__ void ks_fused_split_kernel<G0, 13, NW, false>(                                                 \
         const u64 *, u64, u64 *, u64 *, u64, const u64 *, const u64 *, u64, const u64 *, const u64 *, const u64 *,     \

@@ -182,18 +182,21 @@ def bf_row(n):
     return (n // 2) * (n.bit_length() - 1)
 
 
-def key_switch_work(n, L, rates, narrow=True, inverse_rows=None):
+def key_switch_work(n, L, rates, narrow=True, inverse_rows=None, f64=False):
     """Integer work of ONE key switch of a level-0 polynomial (key_switching_key.rs:241-320; relinearization_key.rs:69-102,
     galois_key.rs:63-123 wrap it): the inverse transform of the switched polynomial (L rows; relinearise: c2, rotation: the
     substituted c1), L (L - 1) digit transforms forward -- digit j under key modulus j is the caller's own Ntt-form row
     (`xhat`, kernels_ks.hpp) -- and two accumulator sets of L x L Shoup multiply-accumulates per coefficient.
-    (count, rate) pairs in lane-operations."""
-    fwd = rates["fwd_butterfly_narrow"] if narrow else rates["fwd_butterfly"]
+    (count, rate) pairs in lane-operations.  f64 (round 6): every modulus below 2^50 -- the FP64-FMA kernels' own
+    register-resident rates (csrc/zq_f64.hpp), so the ceiling is the FP64 issue ceiling."""
+    fwd = rates["f64_fwd_butterfly"] if f64 else rates["fwd_butterfly_narrow"] if narrow else rates["fwd_butterfly"]
+    inv = rates["f64_inv_butterfly"] if f64 else rates["inv_butterfly"]
+    mac = rates["f64_mac"] if f64 else rates["shoup_mac"]
     inv_rows = L if inverse_rows is None else inverse_rows
-    return [(inv_rows * bf_row(n), rates["inv_butterfly"]), (L * (L - 1) * bf_row(n), fwd), (2 * L * L * n, rates["shoup_mac"])]
+    return [(inv_rows * bf_row(n), inv), (L * (L - 1) * bf_row(n), fwd), (2 * L * L * n, mac)]
 
 
-def mul_relin_work(n, L, K, rates, col_ext, col_down, narrow=True, mod_switch=False):
+def mul_relin_work(n, L, K, rates, col_ext, col_down, narrow=True, mod_switch=False, f64=False):
     """Integer work of one Multiplicator::multiply with relinearisation (mul.rs:165-243) by kernel family, as (count, rate)
     pairs: the L ciphertext primes take the narrow forward passes when they are below 2^60, the K - L extension primes
     (62-bit) the wide ones; inverse passes are priced with the one inverse rate.  mod_switch: + Ciphertext::switch_down of
@@ -210,6 +213,13 @@ def mul_relin_work(n, L, K, rates, col_ext, col_down, narrow=True, mod_switch=Fa
         # fused key switch of c2 (all L x L digit transforms) + two accumulator sets of L x L Shoup MACs
         "key_switch_fused": [(L * L * b, fq), (2 * L * L * n, rates["shoup_mac"])],
     }
+    if f64:   # round 6: the L ciphertext rows (all below 2^50) on the FP64 kernels; the K - L extension rows as before
+        ff, fi, fm, fmac = rates["f64_fwd_butterfly"], rates["f64_inv_butterfly"], rates["f64_mulmod"], rates["f64_mac"]
+        work["ntt_fwd"] = [(4 * (K - L) * b, fw), (2 * L * b, ff)]
+        work["ntt_inv"] = [(4 * L * b, fi)]
+        work["tensor_intt"] = [(2 * (K - L) * n, rates["tensor_mul"]), ((K - L) * n, rates["tensor_mac2"]), (3 * (K - L) * b, iv),
+                               (4 * L * n, fm), (3 * L * b, fi)]       # 2 single + 1 double product = 4 exact products per coefficient
+        work["key_switch_fused"] = [(L * L * b, ff), (2 * L * L * n, fmac)]
     if col_ext:
         work["scale_extend"] = [(4 * n, col_ext)]                # 4 operand polynomials, one column per coefficient
         work["scale_down"] = [(3 * n, col_down)]                 # 3 tensor slots
@@ -267,16 +277,18 @@ def binding_ceilings(other, rates, c2_value, n, L, K):
         ns, Ls, Ks = st["degree"], st["moduli"], st["mul_basis_rows"]
         ce, cd = st["scaler_cols_per_s"]
         ids, tag = st["ids"], "stock%d_" % ns
-        ks = ideal_seconds(key_switch_work(ns, Ls, rates))
+        f64 = bool(st.get("f64"))
+        ks = ideal_seconds(key_switch_work(ns, Ls, rates, f64=f64))
         for idn, rows in (("relinearize", 2 * Ls + Ls * Ls + 4 * Ls), ("rotate_columns", 2 * Ls + Ls * Ls + 3 * Ls)):
             if idn in ids and "batch_ops_per_s" in ids[idn]:
                 out[tag + idn] = ceiling_entry(ids[idn]["batch_ops_per_s"], rows * 8 * ns, ks)
         if "mul_and_relin" in ids and "batch_ops_per_s" in ids["mul_and_relin"]:
             out[tag + "mul_and_relin"] = ceiling_entry(ids["mul_and_relin"]["batch_ops_per_s"], stage_model_rows(Ls, Ks, Ls) * 8 * ns,
-                                                       ideal_seconds(mul_relin_work(ns, Ls, Ks, rates, ce, cd)))
+                                                       ideal_seconds(mul_relin_work(ns, Ls, Ks, rates, ce, cd, f64=f64)))
     out["note"] = ("ops_per_s: this run; frac_hbm: SURVEY 8(d) stage-model bytes x ops/s over 8 TB/s; frac_int_issue: ops/s x (the "
-                   "op's butterflies, MACs, tensor products and scaler columns at this process's register-resident rates); "
-                   "binding: the lower ceiling; lifts, final reductions, loads / stores are not priced")
+                   "op's butterflies, MACs, tensor products and scaler columns at this process's register-resident rates; stock "
+                   "sets, round 6: their rows below 2^50 at the FP64-FMA kernels' rates, i.e. the issue ceiling of the "
+                   "instructions they really run); binding: the lower ceiling; lifts, final reductions, loads / stores are not priced")
     return out
 
 
@@ -302,7 +314,8 @@ def int_issue_roofline(fhe, dev, prof, n, L, K, batch, steps, pipeline_step=None
     th.start()
     rates = {k: fhe.ubench_int(k, 0.03, dev) for k in ("mad_u64_u32", "mul_lo_u32", "mul_hi_u32", "shoup_lazy",
                                                         "fwd_butterfly", "fwd_butterfly_narrow", "inv_butterfly",
-                                                        "shoup_mac", "tensor_mul", "tensor_mac2")}
+                                                        "shoup_mac", "tensor_mul", "tensor_mac2", "f64_fma", "f64_mulmod",
+                                                        "f64_fwd_butterfly", "f64_inv_butterfly", "f64_mac")}
     col_ext = col_down = None
     if par is not None:
         col_ext = fhe.ubench_scaler(par.extender(0), 0.03)
@@ -960,7 +973,7 @@ def reference_default_128(fhe, torch, cpu_ms=None, sets=(4096, 8192, 16384)):
         stage = stage_model_rows(L, K, L) * 8 * n
         ids["mul_and_relin"]["stage_model_bytes_per_op"] = stage
         ids["mul_and_relin"]["frac"] = round(stage * ids["mul_and_relin"]["batch_ops_per_s"] / 1e9 / HBM_PEAK_GBS, 4)
-        out[f"n={n}/log(q)={logq}"] = dict(degree=n, moduli=len(q), mul_basis_rows=K, plaintext=t, ids=ids,
+        out[f"n={n}/log(q)={logq}"] = dict(degree=n, moduli=len(q), mul_basis_rows=K, plaintext=t, ids=ids, f64=fhe.get_f64(),
                                            scaler_cols_per_s=[fhe.ubench_scaler(par.extender(0), 0.03),
                                                               fhe.ubench_scaler(par.down_scaler(0), 0.03)])
         del par, ctx, ksk, rk, ek, plain, mul, mul2, mctx

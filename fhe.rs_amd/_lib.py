@@ -158,6 +158,8 @@ SIGNATURES = {
     "fhe_prof_count": (sz, []),
     "fhe_prof_get": (i32, [sz, C.c_char_p, sz, u64p, C.POINTER(C.c_double)]),
     "fhe_prof_get_symbol": (i32, [sz, C.c_char_p, sz]),
+    "fhe_engine_set_f64": (None, [i32]),
+    "fhe_engine_get_f64": (i32, []),
 }
 
 _lib = None

@@ -1061,6 +1061,16 @@ def device_count():
     return _lib.lib().fhe_device_count()
 
 
+# ---- execution options ------------------------------------------------------------------------------
+def set_f64(on=True):
+    """fhe_engine_set_f64: rows whose moduli are all below 2^50 take the FP64-FMA kernels (default) or the integer ones."""
+    _lib.lib().fhe_engine_set_f64(1 if on else 0)
+
+
+def get_f64():
+    return bool(_lib.lib().fhe_engine_get_f64())
+
+
 # ---- profiling ---------------------------------------------------------------------------------
 def prof_enable(on=True):
     _lib.lib().fhe_prof_enable(1 if on else 0)

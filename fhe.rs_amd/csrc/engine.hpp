@@ -58,6 +58,14 @@ inline bool debug_sync() {
     static const bool on = FHE_LAB_FLAG("SYNC");
     return on;
 }
+// The F64 kernels for moduli below 2^50 (round 6) are the product default.  fhe_engine_set_f64(0) sends every launch to
+// the integer kernels instead -- an execution option like fhe_ksk_set_mode (same results either way; tests run both, A/B
+// timings flip it inside one process).  Read once per launch.
+inline std::atomic<bool> &f64_enabled_flag() {
+    static std::atomic<bool> on{true};
+    return on;
+}
+inline bool f64_disabled() { return !f64_enabled_flag().load(std::memory_order_relaxed); }
 // compute units of a device (persistent launches size their grids with it)
 inline int device_cus(int device) {
 #if defined(FHE_HOST_EMULATION)
@@ -554,7 +562,23 @@ struct Ctx {
     // device tables (owned by root; children alias them)
     DevBuf<DevMod> d_mods;
     DevBuf<k::u64x2> d_tw, d_itw, d_ninv, d_inv_last, d_pow2;
+    // Round 6: the F64 twins of d_tw / d_itw / d_ninv -- {w, w / p} as doubles, same indexing -- for the rows whose
+    // modulus is below 2^50 (zq_f64.hpp; rows of wider moduli are left zero and never read: a launch takes the F64
+    // kernels only when every one of its rows qualifies, f64_class below).  Empty when no modulus qualifies.
+    DevBuf<k::u64x2> d_tw_f, d_itw_f, d_ninv_f;
 
+    const k::u64x2 *dtw_f() const { return root->d_tw_f.p; }
+    const k::u64x2 *ditw_f() const { return root->d_itw_f.p; }
+    const k::u64x2 *dninv_f() const { return root->d_ninv_f.p; }
+    // The F64 class HR of the moduli [first, first + rows) of the ROOT's list: 5 when all are below 2^48, 4 below 2^49,
+    // 3 below 2^50, 0 when one of them is wider (integer kernels).  The kernels are instantiated for these three.
+    int f64_class(size_t first, size_t rows) const {
+        if (!root->d_tw_f.p || rows == 0 || f64_disabled()) return 0;
+        u64 mx = 0;
+        for (size_t i = first; i < first + rows; i++) mx = std::max(mx, root->moduli[i]);
+        if (mx >> 50) return 0;
+        return (mx >> 49) ? 3 : (mx >> 48) ? 4 : 5;
+    }
     const DevMod *dmods() const { return root->d_mods.p; }
     const k::u64x2 *dtw() const { return root->d_tw.p; }
     const k::u64x2 *ditw() const { return root->d_itw.p; }
@@ -675,6 +699,31 @@ inline std::unique_ptr<Ctx> ctx_create(int device, size_t degree, const std::vec
         c->d_tw.upload(tw);
         c->d_itw.upload(itw);
         c->d_ninv.upload(ninv);
+        // F64 twins for moduli below 2^50 (host doubles: conversion exact, division correctly rounded)
+        bool any_f64 = false;
+        for (size_t i = 0; i < c->L; i++) any_f64 = any_f64 || (moduli[i] >> 50) == 0;
+        if (any_f64) {
+            auto bits = [](double d) {
+                u64 u;
+                std::memcpy(&u, &d, sizeof(u));
+                return u;
+            };
+            std::vector<k::u64x2> twf(c->L * degree, k::u64x2{0, 0}), itwf(c->L * degree, k::u64x2{0, 0}), ninvf(2 * c->L, k::u64x2{0, 0});
+            for (size_t i = 0; i < c->L; i++) {
+                if (moduli[i] >> 50) continue;
+                const double pd = (double)moduli[i];
+                auto pair = [&](u64 w) { return k::u64x2{bits((double)w), bits((double)w / pd)}; };
+                for (size_t j = 0; j < degree; j++) {
+                    twf[i * degree + j] = pair(tw[i * degree + j].x);
+                    itwf[i * degree + j] = pair(itw[i * degree + j].x);
+                }
+                ninvf[2 * i] = pair(ninv[2 * i].x);
+                ninvf[2 * i + 1] = pair(ninv[2 * i + 1].x);
+            }
+            c->d_tw_f.upload(twf);
+            c->d_itw_f.upload(itwf);
+            c->d_ninv_f.upload(ninvf);
+        }
         std::vector<k::u64x2> pow2(c->L);
         for (size_t i = 0; i < c->L; i++) {
             const u64 two64 = (u64)((((u128)1) << 64) % moduli[i]);
@@ -748,6 +797,32 @@ inline void launch_ntt_lds(const char *name, uint32_t logm, unsigned grid, hipSt
 #undef FHE_NTT_CASE
 }
 
+// The F64 instances of ntt_kernel (whole rows of 4096 / 8192 / 16384 points, every modulus of the launch below 2^50:
+// Ctx::f64_class): false when the launch does not qualify and takes the integer kernels.
+template <bool INV, bool GATHER>
+inline bool launch_ntt_f64(const Ctx &c, const char *name, int hr, uint32_t logn, unsigned grid, hipStream_t s, const u64 *in,
+                           u64 *out, const k::RowMap &map) {
+    if (!hr || logn < 12 || logn > 14) return false;
+    const size_t lds = k::lds_words(1u << logn) * sizeof(u64);
+    const k::u64x2 *tw = INV ? c.ditw_f() : c.dtw_f();
+#define FHE_NTT_F64(LM, HR)                                                                                            \
+    do {                                                                                                               \
+        allow_big_lds((k::ntt_kernel<INV, LM, false, 1, GATHER, HR>), lds);                                            \
+        FHE_LAUNCH(name, (k::ntt_kernel<INV, LM, false, 1, GATHER, HR>), dim3(grid), dim3(k::ntt_threads_c(LM)), lds, s, in, \
+                   out, map, c.dmods(), tw, c.dninv_f(), logn);                                                        \
+    } while (0)
+#define FHE_NTT_F64_HR(LM)                      \
+    case LM:                                    \
+        if (hr == 3) FHE_NTT_F64(LM, 3);        \
+        else if (hr == 4) FHE_NTT_F64(LM, 4);   \
+        else FHE_NTT_F64(LM, 5);                \
+        break;
+    switch (logn) { FHE_NTT_F64_HR(12) FHE_NTT_F64_HR(13) FHE_NTT_F64_HR(14) }
+#undef FHE_NTT_F64_HR
+#undef FHE_NTT_F64
+    return true;
+}
+
 // Forward / inverse NTT of `npolys * map.rows` residue rows.  N <= 16384: one LDS-resident
 // kernel.  N = 32768 / 65536: G0 global radix stages + LDS kernel on 8192-point sub-blocks.
 inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::RowMap map, size_t npolys,
@@ -756,7 +831,10 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
     const uint32_t logn = (uint32_t)c.logn;
     const unsigned rows_total = (unsigned)(npolys * map.rows);
     if (logn <= 14) {
+        // every modulus of the launch below 2^50: the FP64-FMA instances (round 6)
+        const int hr = c.f64_class((size_t)((int32_t)map.row_begin + map.mod_offset), map.rows);
         if (!inverse) {
+            if (launch_ntt_f64<false, false>(c, "ntt_fwd_f64", hr, logn, rows_total, s, in, out, map)) return;
             // every modulus of the launch below 2^60: the transform without per-stage conditional subtractions
             bool narrow = !FHE_LAB_FLAG("NO_NARROW");
             for (uint32_t r = 0; r < map.rows; r++)
@@ -773,6 +851,9 @@ inline void launch_ntt(const Ctx &c, bool inverse, const u64 *in, u64 *out, k::R
             bool narrow = !FHE_LAB_FLAG("NO_NARROW");
             for (uint32_t r = 0; r < map.rows; r++)
                 narrow = narrow && (c.root->moduli[(size_t)((int32_t)(map.row_begin + r) + map.mod_offset)] >> 60) == 0;
+            if (map.subst_exp ? launch_ntt_f64<true, true>(c, "ntt_inv_f64", hr, logn, rows_total, s, in, out, map)
+                               : launch_ntt_f64<true, false>(c, "ntt_inv_f64", hr, logn, rows_total, s, in, out, map))
+                return;
             if (map.subst_exp) {   // the source rows are read through the substitution x -> x^subst_exp (galois_apply)
                 if (narrow)
                     launch_ntt_lds<true, true, true>("ntt_inv", logn, rows_total, s, in, out, map, c.dmods(), c.ditw(), c.dninv(), logn);
@@ -854,11 +935,28 @@ inline k::RowMap full_map(const Ctx &c, size_t rows_in_poly) {
 }
 
 inline void launch_tensor_intt_rows(const Ctx &e, const k::TensorSrc &ts, u64 *out, size_t nb, uint32_t row_begin,
-                                    uint32_t lrows, bool narrow, hipStream_t s, bool reverse) {
+                                    uint32_t lrows, bool narrow, hipStream_t s, bool reverse, int f64_hr = 0) {
     const uint32_t logn = (uint32_t)e.logn, logm = logn <= 14 ? logn : 13;
     const size_t lds = k::lds_words(1u << logm) * sizeof(u64);
     // 8 (row, pair, sub-block) combinations x 3 slots per group
     const unsigned groups = (unsigned)(((((size_t)lrows * nb) << (logn - logm)) + 7) / 8);
+    if (f64_hr && logn >= 12 && logn <= 14) {   // round 6: rows below 2^50 on the F64 instances
+#define FHE_TI_F64(LM, HR)                                                                                          \
+    allow_big_lds((k::tensor_intt_kernel<LM, false, false, HR>), lds);                                              \
+    FHE_LAUNCH("tensor_intt_f64", (k::tensor_intt_kernel<LM, false, false, HR>), dim3(groups * 24),                 \
+               dim3(k::ntt_threads_c(LM)), lds, s, ts, out, e.dmods(), e.ditw_f(), e.dninv_f(), (uint32_t)e.L,      \
+               (uint32_t)nb, logn, row_begin, lrows, reverse ? 1u : 0u);
+#define FHE_TI_F64_HR(LM)                               \
+    case LM:                                            \
+        if (f64_hr == 3) { FHE_TI_F64(LM, 3) }          \
+        else if (f64_hr == 4) { FHE_TI_F64(LM, 4) }     \
+        else { FHE_TI_F64(LM, 5) }                      \
+        break;
+        switch (logn) { FHE_TI_F64_HR(12) FHE_TI_F64_HR(13) FHE_TI_F64_HR(14) }
+#undef FHE_TI_F64_HR
+#undef FHE_TI_F64
+        return;
+    }
 #define FHE_TI_LAUNCH(LM, SUB, NRW)                                                                              \
     allow_big_lds((k::tensor_intt_kernel<LM, SUB, NRW>), lds);                                                   \
     FHE_LAUNCH((NRW ? "tensor_intt_narrow" : "tensor_intt"), (k::tensor_intt_kernel<LM, SUB, NRW>), dim3(groups * 24), \
@@ -899,19 +997,22 @@ inline void launch_tensor_intt(const Ctx &e, const k::TensorSrc &ts, u64 *out, s
     }
     struct Run {
         uint32_t r0, n;
-        bool narrow;
+        int kind;   // 0: general passes, 1: moduli below 2^60 (narrow passes), 2: below 2^50 (round 6: the F64 instances)
     };
     std::vector<Run> runs;
+    const bool f64_rows = allow && e.logn >= 12 && e.logn <= 14 && e.root->d_tw_f.p && !f64_disabled();
+    auto kind_of = [&](uint32_t r) { return !allow ? 0 : (f64_rows && (e.moduli[r] >> 50) == 0) ? 2 : (e.moduli[r] >> 60) == 0 ? 1 : 0; };
     uint32_t r0 = 0;
     while (r0 < e.L) {
-        const bool nr = allow && (e.moduli[r0] >> 60) == 0;
+        const int kd = kind_of(r0);
         uint32_t r1 = r0 + 1;
-        while (r1 < e.L && (allow && (e.moduli[r1] >> 60) == 0) == nr) r1++;
-        runs.push_back(Run{r0, r1 - r0, nr});
+        while (r1 < e.L && kind_of(r1) == kd) r1++;
+        runs.push_back(Run{r0, r1 - r0, kd});
         r0 = r1;
     }
     if (reverse) std::reverse(runs.begin(), runs.end());
-    for (const Run &r : runs) launch_tensor_intt_rows(e, ts, out, nb, r.r0, r.n, r.narrow, s, reverse);
+    for (const Run &r : runs)
+        launch_tensor_intt_rows(e, ts, out, nb, r.r0, r.n, r.kind == 1, s, reverse, r.kind == 2 ? e.f64_class(r.r0, r.n) : 0);
     const uint32_t logn = (uint32_t)e.logn;
     if (logn > 14) {  // the global inverse stages finish every row
         const uint32_t logm = 13;
@@ -1315,6 +1416,10 @@ struct Ksk {
     }
     uint32_t digit_arg() const { return (uint32_t)log_base | (lift_mode() << 8); }
     DevBuf<u64> c0, c0s, c1, c1s;  // [ndigits][Lk][N]
+    // Round 6: the key's F64 twins -- bit patterns of the doubles {k, k / q_j} -- when every key modulus is below 2^50
+    // and the digits are RNS rows (ksk_fill_f64; empty otherwise): what ks_fused_kernel's F64 instances read in place
+    // of (c0, c0s, c1, c1s).
+    DevBuf<u64> c0f, c0pf, c1f, c1pf;
     // Execution options of this handle (fhe_ksk_set_mode; read once per call, like Mul's):
     //   mode      KS_AUTO: the engine picks per shape and launch (ks_use_unfused, key_switch_polys); KS_FUSED: ks_fused_kernel
     //             (rows larger than LDS: on 16384-point parts); KS_FUSED_SUB: rows larger than LDS on 8192-point sub-blocks
@@ -1326,6 +1431,32 @@ struct Ksk {
     std::atomic<size_t> w_budget{0};
 };
 enum : int { KS_AUTO = 0, KS_FUSED = 1, KS_UNFUSED = 2, KS_UNFUSED_SUB = 3, KS_FUSED_SUB = 4 };
+
+// host key words [ndigits][Lk][N] (canonical, checked by the caller) -> the F64 twins on the device
+inline void ksk_fill_f64(Ksk &k_, const u64 *h0, const u64 *h1) {
+    const Ctx &kc = *k_.ksk_ctx;
+    if (k_.log_base != 0 || kc.device < 0 || !kc.root->d_tw_f.p) return;
+    for (u64 q : kc.moduli)
+        if (q >> 50) return;
+    const size_t count = k_.ndigits * kc.L * kc.n;
+    std::vector<u64> f(count), pf(count);
+    auto fill = [&](const u64 *h, DevBuf<u64> &df, DevBuf<u64> &dpf) {
+        for (size_t i = 0; i < k_.ndigits; i++)
+            for (size_t r = 0; r < kc.L; r++) {
+                const double pd = (double)kc.moduli[r];
+                for (size_t j = 0; j < kc.n; j++) {
+                    const size_t x = (i * kc.L + r) * kc.n + j;
+                    const double kd = (double)h[x], kp = kd / pd;
+                    std::memcpy(&f[x], &kd, 8);
+                    std::memcpy(&pf[x], &kp, 8);
+                }
+            }
+        df.upload(f);
+        dpf.upload(pf);
+    };
+    fill(h0, k_.c0f, k_.c0pf);
+    fill(h1, k_.c1f, k_.c1pf);
+}
 
 inline void ksk_validate(const Ctx &ct_ctx, const Ctx &ksk_ctx, size_t ndigits, size_t log_base) {
     require(ct_ctx.n == ksk_ctx.n, E_DEGREE_MISMATCH, "DegreeMismatch");
@@ -1376,6 +1507,34 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     // round 3 that instance spilled 52 B; it no longer does, and measured again at C3 in round 4 it changes nothing --
     // relinearise of 512: 4.09 / 4.18 / 4.18 ms against 4.17 / 4.14 / 4.13, profiles/r04_ks14_rns_ab.jsonl.)
     const bool rns = (LOGN == 12 || LOGN == 13) && k_.digit_arg() == (1u << 8);
+    // Round 6: every key modulus below 2^50 and RNS digits -> the F64 instances (no lift: any residue row of the basis is
+    // a representative under every key modulus, whatever the widths)
+    if constexpr (LOGN >= 12 && LOGN <= 14) {
+        const int hr = (k_.c0f.p && k_.log_base == 0) ? kc.f64_class(0, kc.L) : 0;
+        if (hr) {
+#define FHE_KS_F64_G(GMV, GALV, HR)                                                                                    \
+    allow_big_lds((k::ks_fused_kernel<LOGN, false, GMV, 0, true, 0, GALV, HR>), lds);                                  \
+    FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, GMV, 0, true, 0, GALV, HR>), dim3(ks_grid),    \
+               dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0f.p,       \
+               k_.c0pf.p, k_.c1f.p, k_.c1pf.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,           \
+               k_.digit_arg(), xhat, xhat_stride, (uint32_t)(npolys * kc.L), gal)
+#define FHE_KS_F64(HR)                                                                                                 \
+    do {                                                                                                               \
+        constexpr int GMV = LOGN == 14 ? k::GM_MIXED : k::KS_GMAX;                                                     \
+        if (gal) {                                                                                                     \
+            FHE_KS_F64_G(GMV, true, HR);                                                                               \
+        } else {                                                                                                       \
+            FHE_KS_F64_G(GMV, false, HR);                                                                              \
+        }                                                                                                              \
+    } while (0)
+            if (hr == 3) FHE_KS_F64(3);
+            else if (hr == 4) FHE_KS_F64(4);
+            else FHE_KS_F64(5);
+#undef FHE_KS_F64
+#undef FHE_KS_F64_G
+            return;
+        }
+    }
 #define FHE_KS_LAUNCH_G(NW, GMV, RNS, GALV)                                                                           \
     allow_big_lds((k::ks_fused_kernel<LOGN, NW, GMV, 0, RNS, 0, GALV>), lds);                                         \
     FHE_LAUNCH("key_switch_fused", (k::ks_fused_kernel<LOGN, NW, GMV, 0, RNS, 0, GALV>), dim3(ks_grid),               \
@@ -1565,6 +1724,20 @@ inline void launch_ks_ntt(const Ksk &k_, bool narrow, bool rns, unsigned grid, h
     FHE_LAUNCH("ks_digit_ntt", (k::ks_ntt_kernel<LOGM, G0, NW, RNS>), dim3(grid + egrid), dim3(k::ntt_threads_c(LOGM)), \
                lds, s, p, p_stride, w, kc.dmods(), kc.dtw(), (uint32_t)k_.ndigits, j0, jg, k_.digit_arg(), skip_own,   \
                erows, estride, enr, (uint32_t)grid)
+    // Round 6: RNS digits under key moduli that are all below 2^50 -> the F64 stage A (whole-row tiles of 4096 ... 16384
+    // points; W in canonical words, so stage B is unchanged)
+    if constexpr (G0 == 0 && LOGM >= 12 && LOGM <= 14) {
+        const int hr = k_.log_base == 0 ? kc.f64_class(0, kc.L) : 0;
+#define FHE_KSN_F64(HR)                                                                                                 \
+    allow_big_lds((k::ks_ntt_kernel<LOGM, 0, false, true, HR>), lds);                                                   \
+    FHE_LAUNCH("ks_digit_ntt_f64", (k::ks_ntt_kernel<LOGM, 0, false, true, HR>), dim3(grid + egrid),                    \
+               dim3(k::ntt_threads_c(LOGM)), lds, s, p, p_stride, w, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, j0,  \
+               jg, k_.digit_arg(), skip_own, erows, estride, enr, (uint32_t)grid)
+        if (hr == 3) { FHE_KSN_F64(3); return; }
+        if (hr == 4) { FHE_KSN_F64(4); return; }
+        if (hr == 5) { FHE_KSN_F64(5); return; }
+#undef FHE_KSN_F64
+    }
     if constexpr (LOGM >= 12) {
         if (rns) {
             if (narrow) { FHE_KSN(true, true); } else { FHE_KSN(false, true); }

@@ -934,6 +934,7 @@ fhe_status fhe_ksk_create(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, size_t 
             auto v = shoup_of(c1, c1_shoup);
             up(h->k->c1s, v.data());
         }
+        ksk_fill_f64(*h->k, c0, c1);
         *out = h.release();
     });
 }
@@ -969,6 +970,7 @@ fhe_status fhe_ksk_create_dev(const fhe_ctx *ct_ctx, const fhe_ctx *ksk_ctx, siz
         h->k->c1.upload(h1);
         h->k->c0s.upload(s0);
         h->k->c1s.upload(s1);
+        ksk_fill_f64(*h->k, h0.data(), h1.data());
         *out = h.release();
     });
 }
@@ -1767,6 +1769,8 @@ fhe_status fhe_ubench_copy(int device, size_t bytes, double min_seconds, double 
         *bytes_per_s = ub::run_copy(device, bytes, min_seconds);
     });
 }
+void fhe_engine_set_f64(int on) { f64_enabled_flag().store(on != 0, std::memory_order_relaxed); }
+int fhe_engine_get_f64(void) { return f64_enabled_flag().load(std::memory_order_relaxed) ? 1 : 0; }
 void fhe_prof_enable(int on) { Profiler::get().enabled = on != 0; }
 void fhe_prof_reset(void) {
     try {

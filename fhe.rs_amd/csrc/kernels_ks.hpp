@@ -37,7 +37,12 @@ constexpr int ks_min_waves(int logn, int tt) { return (logn == 14 && tt == 512) 
 // GAL (round 5): the instance GaloisKey::relinearize launches -- see `gal` below.  A template flag, not a runtime branch:
 // with the gathers behind `if (gal)` EVERY instance spilled (72-96 B of scratch at N = 8192, 532-548 B at N = 16384, whose
 // digit loop sits at 124 of 128 VGPRs); the relinearisation / multiply instances are the round-4 kernels, bit for bit.
-template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false, int G0 = 0, bool GAL = false>
+// F64 = HR > 0 (round 6): every key modulus below 2^(53 - HR) (the reference's stock parameter sets: 36-49 bits): the digit
+// transforms and both multiply-accumulates run on doubles holding integers (zq_f64.hpp).  Then `tw` is the key context's
+// F64 twiddle table and k0 / k0s / k1 / k1s are the key's F64 twins ({k, k / p} as doubles, Ksk::c0f ...); a digit row of
+// another modulus of the basis IS a representative under this one -- there is no lift at all.  RNS digits, whole-row tiles
+// (G0 = 0), TT = 0.  The integer instances (F64 = 0) are the round-5 kernels bit for bit (tests/test_isa_guards.py).
+template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false, int G0 = 0, bool GAL = false, int F64 = 0>
 __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT))
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,
                     u64 out_poly_stride, const u64 *__restrict__ addend0, const u64 *__restrict__ addend1,
@@ -55,6 +60,17 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
     constexpr int NS = 1 << G0;
     static_assert(G0 == 0 || (G0 <= 2 && !ks_acc1_in_lds_tt(LOGN, TT) && tile_chunks_c(LOGN, ks_threads_tt(LOGN, TT)) >= 2),
                   "the folded first stages are written for the register-accumulator form (N = 16384 tiles)");
+    static_assert(F64 == 0 || (RNS && G0 == 0 && TT == 0 && !NARROW && tile_chunks_c(LOGN, ks_threads_tt(LOGN, TT)) >= 1),
+                  "the F64 instances: RNS digits, whole-row tiles");
+    // F64 bounds (units: zq_f64.hpp).  The transform leaves values below VB; they are reduced before the products when that
+    // buys accumulator room (HR = 3, 4); a term is then below PB, the caller's own Ntt row (canonical) gives one below
+    // POWN, and F64_CAP digits fit an accumulator together with a canonical addend before it must be reduced.
+    constexpr int F64_VB = F64 ? f64_fwd_out_bound(LOGN, F64 ? F64 : 3) : 0;
+    constexpr bool F64_REDV = F64 > 0 && F64 < 5;
+    constexpr int F64_PB = F64 ? f64_product_bound(F64_REDV ? F64_REDUCED : F64_VB, F64 ? F64 : 3) : 1;
+    constexpr int F64_POWN = F64 ? f64_product_bound(F64_ONE, F64 ? F64 : 3) : 1;
+    constexpr int F64_CAP = F64 ? (f64_limit(F64 ? F64 : 3) - F64_ONE - F64_POWN - F64_REDUCED) / F64_PB : 1;
+    static_assert(F64 == 0 || F64_CAP >= 8, "accumulator room");
     constexpr int CH = tile_chunks_c(LOGN, T);
     constexpr int NE = CH > 0 ? 2 * CH : 1;  // coefficients owned by a thread
     // GM: radix (log2) of the LDS passes.  8 everywhere but N = 16384, whose 1024 threads hold both accumulator sets in
@@ -84,7 +100,8 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
     const uint32_t b = to_sgpr(bj / lk), j = bj - b * lk;
     const DevMod md = mods[j];
     const u64 p = md.p, p2 = md.p2;
-    const PM pm = make_pm(md);
+    const PM pm = F64 ? make_pm_f64(md) : make_pm(md);
+    const PF pf = pf_of(pm);                  // (F64 instances only)
     const u64x2 *twr = tw + (u64)j * NROW;
     const u64 suboff = (u64)sub * N;          // this half inside a row (0 when the tile is the row)
     // N = 8192: 1024 threads cap a thread at 128 VGPRs, which 2 x 16 accumulators plus a radix-8
@@ -140,6 +157,20 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                     v = reinterpret_cast<const u64x2 *>(xr)[ci];
                 }
                 const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
+                if constexpr (F64 > 0) {
+                    const double vx = f64_from_u64(v.x), vy = f64_from_u64(v.y);
+                    acc0[2 * c] = bits_of_f64(mulmod_f64(vx, f64_of_bits(q0.x), f64_of_bits(q0s.x), pf.p));
+                    acc0[2 * c + 1] = bits_of_f64(mulmod_f64(vy, f64_of_bits(q0.y), f64_of_bits(q0s.y), pf.p));
+                    const u64x2 af{bits_of_f64(mulmod_f64(vx, f64_of_bits(q1.x), f64_of_bits(q1s.x), pf.p)),
+                                   bits_of_f64(mulmod_f64(vy, f64_of_bits(q1.y), f64_of_bits(q1s.y), pf.p))};
+                    if constexpr (ACC1_LDS) {
+                        acc1_lds[ci] = af;
+                    } else {
+                        acc1[ACC1_LDS ? 0 : 2 * c] = af.x;
+                        acc1[ACC1_LDS ? 0 : 2 * c + 1] = af.y;
+                    }
+                    continue;
+                }
                 acc0[2 * c] = mul_shoup_lazy_n(v.x, q0.x, q0s.x, pm.np);        // below 2p, like every accumulator value
                 acc0[2 * c + 1] = mul_shoup_lazy_n(v.y, q0.y, q0s.y, pm.np);
                 const u64x2 a{mul_shoup_lazy_n(v.x, q1.x, q1s.x, pm.np), mul_shoup_lazy_n(v.y, q1.y, q1s.y, pm.np)};
@@ -171,6 +202,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
             for (int c = 0; c < CH; c++) pre[c] = first[c * T + tid0];
         }
     }
+    uint32_t f64_terms = 1;   // (F64 instances: terms an accumulator holds since it was last reduced; the own row counts)
     for (uint32_t ii = 0; ii < nloop; ii++) {
         const uint32_t i = digit_of(ii);
         const uint32_t tid = opaque(tid0);
@@ -179,7 +211,14 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
         // RNS instances: one conditional subtraction per coefficient.  The generic lambda keeps the shift, the mask
         // and three uniform branches PER ELEMENT (round 3, from the ISA).
         if constexpr (PREFETCH) {
-            if constexpr (rns_fast) {
+            if constexpr (F64 > 0) {   // (a residue of another modulus of the basis is a representative as it is)
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    const uint32_t e = 2 * (c * T + tid);
+                    lds[padi(e)] = bits_of_f64(f64_from_u64(pre[c].x));
+                    lds[padi(e + 1)] = bits_of_f64(f64_from_u64(pre[c].y));
+                }
+            } else if constexpr (rns_fast) {
 #pragma unroll
                 for (int c = 0; c < CH; c++) {
                     const uint32_t e = 2 * (c * T + tid);
@@ -288,6 +327,8 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                     }
                     sched_fence();
                 }
+            } else if constexpr (F64 > 0) {
+                tile_to_lds<CH, N, T>(lds, src, tid, [](u64 v) { return bits_of_f64(f64_from_u64(v)); });
             } else if constexpr (rns_fast) {
                 tile_to_lds<CH, N, T>(lds, src, tid, [&](u64 v) { return csub_n(v, p, pm.np); });
             } else {
@@ -313,7 +354,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
             // transform, so their L2 latency is spent waiting for the other waves, not after them
             constexpr bool KPF = PREFETCH && CH >= 2;
             // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
-            ntt_fwd_lds<LOGN, T, GM, FHE_KS_TWPF && LOGN == 13, !KPF, (NARROW ? (G0 ? 4 : 1) : 0), NoSrc, KS_LATE>(lds, twr, NS + sub, pm, tid);
+            ntt_fwd_lds<LOGN, T, GM, FHE_KS_TWPF && LOGN == 13, !KPF, (F64 ? -F64 : NARROW ? (G0 ? 4 : 1) : 0), NoSrc, KS_LATE>(lds, twr, NS + sub, pm, tid);
             FHE_TSK(7);
             // (all four chunks prefetched -- 118 VGPRs, no scratch: no change; three: 2 % slower.  ABBA runs in
             // profiles/r02_ks_kpf_ab.txt: the key words' latency is not what the MAC waits for)
@@ -338,6 +379,28 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                 } else {
                     q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
                 }
+                if constexpr (F64 > 0) {
+                    double fx = f64_of_bits(lds[padi(2 * ci)]), fy = f64_of_bits(lds[padi(2 * ci + 1)]);
+                    if constexpr (F64_REDV) fx = reduce_f64(fx, pf), fy = reduce_f64(fy, pf);
+                    // (block-uniform) every F64_CAP terms the accumulators are brought back below p / 2
+                    const bool fold_acc = f64_terms >= (uint32_t)F64_CAP;
+                    auto mac = [&](u64 acc, double v, u64 kk, u64 kp) {
+                        double a = f64_of_bits(acc);
+                        if (fold_acc) a = reduce_f64(a, pf);
+                        return bits_of_f64(mulmod_add_f64(a, v, f64_of_bits(kk), f64_of_bits(kp), pf.p));
+                    };
+                    acc0[2 * c] = mac(acc0[2 * c], fx, q0.x, q0s.x);
+                    acc0[2 * c + 1] = mac(acc0[2 * c + 1], fy, q0.y, q0s.y);
+                    if constexpr (ACC1_LDS) {
+                        u64x2 a = acc1_lds[ci];
+                        a.x = mac(a.x, fx, q1.x, q1s.x);
+                        a.y = mac(a.y, fy, q1.y, q1s.y);
+                        acc1_lds[ci] = a;
+                    } else {
+                        acc1[ACC1_LDS ? 0 : 2 * c] = mac(acc1[ACC1_LDS ? 0 : 2 * c], fx, q1.x, q1s.x);
+                        acc1[ACC1_LDS ? 0 : 2 * c + 1] = mac(acc1[ACC1_LDS ? 0 : 2 * c + 1], fy, q1.y, q1s.y);
+                    }
+                } else {
                 const u64 vx = lds[padi(2 * ci)], vy = lds[padi(2 * ci + 1)];  // < 4p: Shoup accepts any u64
                 acc0[2 * c] = csub_n(mul_shoup_lazy_add_n(acc0[2 * c], vx, q0.x, q0s.x, pm.np), p2, pm.np2);
                 acc0[2 * c + 1] = csub_n(mul_shoup_lazy_add_n(acc0[2 * c + 1], vy, q0.y, q0s.y, pm.np), p2, pm.np2);
@@ -350,6 +413,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                     acc1[2 * c] = csub_n(mul_shoup_lazy_add_n(acc1[2 * c], vx, q1.x, q1s.x, pm.np), p2, pm.np2);
                     acc1[2 * c + 1] = csub_n(mul_shoup_lazy_add_n(acc1[2 * c + 1], vy, q1.y, q1s.y, pm.np), p2, pm.np2);
                 }
+                }
                 if (c & 1) sched_fence();  // at most two chunks of key loads (32 VGPRs) in flight
             }
         } else {
@@ -360,6 +424,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
             acc1[0] = csub_n(mul_shoup_lazy_add_n(acc1[0], v, k1[koff + tid], k1s[koff + tid], pm.np), p2, pm.np2);
             }
         }
+        if constexpr (F64 > 0) f64_terms = f64_terms >= (uint32_t)F64_CAP ? 2u : f64_terms + 1;   // (a reduced accumulator counts as one term)
         // (wave-contiguous chunk ownership, which makes this barrier and the one before the MAC wave-local as
         // well, was measured: nothing beyond what the late pass plan already gives)
         FHE_TSK(5);
@@ -396,6 +461,31 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
         for (int c = 0; c < CH; c++) {
             const uint32_t ci = c * T + tid;
             u64x2 r0, r1;
+            if constexpr (F64 > 0) {
+                // accumulator (+ canonical addend, added as a double: the sum stays below 2^53) -> canonical word
+                const u64x2 af = ACC1_LDS ? acc1_lds[ci] : u64x2{acc1[ACC1_LDS ? 0 : 2 * c], acc1[ACC1_LDS ? 0 : 2 * c + 1]};
+                double f0x = f64_of_bits(acc0[2 * c]), f0y = f64_of_bits(acc0[2 * c + 1]);
+                double f1x = f64_of_bits(af.x), f1y = f64_of_bits(af.y);
+                if (d0) {
+                    u64x2 a;
+                    if constexpr (GAL) {
+                        const u64 *arow = addend0 + aoff - suboff;
+                        const uint32_t d = (uint32_t)suboff + 2 * ci;
+                        a.x = arow[galois_src_index(d, gal, LOGN + G0)];
+                        a.y = arow[galois_src_index(d + 1, gal, LOGN + G0)];
+                    } else {
+                        a = d0[ci];
+                    }
+                    f0x += f64_from_u64(a.x), f0y += f64_from_u64(a.y);
+                }
+                if (d1) {
+                    const u64x2 a = d1[ci];
+                    f1x += f64_from_u64(a.x), f1y += f64_from_u64(a.y);
+                }
+                o0[ci] = u64x2{to_u64_canonical(f0x, pf), to_u64_canonical(f0y, pf)};
+                o1[ci] = u64x2{to_u64_canonical(f1x, pf), to_u64_canonical(f1y, pf)};
+                continue;
+            }
             r0.x = csub_n(acc0[2 * c], p, pm.np);
             r0.y = csub_n(acc0[2 * c + 1], p, pm.np);
             const u64x2 a1 = ACC1_LDS ? acc1_lds[ci] : u64x2{acc1[ACC1_LDS ? 0 : 2 * c], acc1[ACC1_LDS ? 0 : 2 * c + 1]};
@@ -627,7 +717,9 @@ template <int V>
 struct KsLiftMode {
     static constexpr int value = V;
 };
-template <int LOGM, int G0, bool NARROW, bool RNS>
+// F64 = HR > 0 (round 6; whole-row tiles, RNS digits, every key modulus below 2^(53 - HR)): the transforms run on doubles
+// (`tw` is then the key context's F64 table); no lift; W receives canonical words, which is what stage B takes.
+template <int LOGM, int G0, bool NARROW, bool RNS, int F64 = 0>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     ks_ntt_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ w, const DevMod *__restrict__ mods,
                   const u64x2 *__restrict__ tw, uint32_t ndigits, uint32_t j0, uint32_t jg, uint32_t digit_arg,
@@ -653,6 +745,13 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
             const u64 p2 = md.p2;
             u64 *row = extra + (u64)ep * extra_poly_stride + (u64)r * N;
             const u64x2 *twr = tw + (u64)r * N;
+            if constexpr (F64 > 0) {
+                const PM pmf = make_pm_f64(md);
+                const PF pf = pf_of(pmf);
+                ntt_fwd_lds<LOGM, T, GMAX, true, true, -F64>(lds, twr, 1, pmf, tid, [&](uint32_t idx, uint32_t) { return bits_of_f64(f64_from_u64(row[idx])); });
+                lds_to_tile<CH, M, T>(lds, row, tid, [&](u64 v) { return to_u64_canonical(f64_of_bits(v), pf); });
+                return;
+            }
             ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? 1 : 0)>(lds, twr, 1, pm, tid, [&](uint32_t idx, uint32_t) { return row[idx]; });
             if constexpr (NARROW) {   // below 16p -> canonical
                 const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
@@ -678,6 +777,14 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     const uint32_t sh = i * digit_shift_bits;
     const u64 mask = digit_shift_bits ? ((1ull << digit_shift_bits) - 1) : ~0ull;
     const u64 *src = pin + (u64)b * src_poly_stride + (digit_shift_bits ? 0 : (u64)i * N) + (G0 ? 0 : (u64)sub * M);
+    if constexpr (F64 > 0) {
+        static_assert(F64 == 0 || (G0 == 0 && RNS && !NARROW), "the F64 instances: whole-row tiles, RNS digits");
+        const PM pmf = make_pm_f64(md);
+        const PF pf = pf_of(pmf);
+        ntt_fwd_lds<LOGM, T, GMAX, true, true, -F64>(lds, twr, NS + sub, pmf, tid, [&](uint32_t idx, uint32_t) { return bits_of_f64(f64_from_u64(src[idx])); });
+        lds_to_tile<CH, M, T>(lds, w + (u64)rowb * N + (u64)sub * M, tid, [&](u64 v) { return to_u64_canonical(f64_of_bits(v), pf); });
+        return;
+    }
     // The lift mode is a compile-time constant of the transform's loader (three uniform branches around the whole
     // transform, below).  Round 5: as a run-time test inside the loader it put a branch diamond behind every one of the
     // first pass's sixteen global loads, and the compiler then waited for each load before issuing the next (global

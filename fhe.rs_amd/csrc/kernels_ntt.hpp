@@ -21,7 +21,9 @@ namespace k {
 // GATHER (inverse only, round 5): the tile is read through the Ntt-domain substitution map.subst_exp (galois_src_index):
 // GaloisKey::relinearize's `substitute(c1)` followed by the inverse transform (F/bfv/keys/galois_key.rs:66-70) in one pass --
 // per-lane 8-byte gathers inside one row (L2 hits after the first touch) instead of a permutation kernel's write + re-read.
-template <bool INVERSE, int LOGM, bool NARROW = false, int FWD_B0 = 1, bool GATHER = false>
+// F64 = HR > 0 (round 6; whole rows only, every modulus of the launch below 2^(53 - HR)): the passes run on doubles
+// (zq_f64.hpp) -- `tw` / `ninv` are then the context's F64 tables; canonical u64 words in and out, as always.
+template <bool INVERSE, int LOGM, bool NARROW = false, int FWD_B0 = 1, bool GATHER = false, int F64 = 0>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     ntt_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, RowMap map, const DevMod *__restrict__ mods,
                const u64x2 *__restrict__ tw, const u64x2 *__restrict__ ninv, uint32_t logn) {
@@ -46,7 +48,30 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     u64 *dst = out + (u64)poly * map.dst_poly_stride + (u64)r * n + (u64)sub * M;
     const u64x2 *twr = tw + (u64)mi * n;
 
-    if constexpr (!INVERSE) {
+    if constexpr (F64 > 0) {
+        const PM pmf = make_pm_f64(md);
+        const PF pf = pf_of(pmf);
+        auto to_f = [](u64 v) { return bits_of_f64(f64_from_u64(v)); };
+        auto to_c = [&](u64 v) { return to_u64_canonical(f64_of_bits(v), pf); };
+        if constexpr (!INVERSE) {
+            ntt_fwd_lds<LOGM, T, GMAX, true, true, -F64>(lds, twr, nsub + sub, pmf, tid, [&](uint32_t i, uint32_t) { return to_f(load_last<(FHE_PIPE_NT & 2) != 0>(src + i)); });
+            lds_to_tile<CH, M, T>(lds, dst, tid, to_c);
+        } else {
+            InvTwFirst<LOGM, T> tw0;
+            inv_tw_load(tw0, twr, logn, sub, tid);
+            if constexpr (GATHER) {
+                const u64 *row = src - (u64)sub * M;
+                const uint32_t e = map.subst_exp;
+#pragma unroll 8
+                for (uint32_t i = tid; i < (uint32_t)M; i += T) lds[padi(i)] = to_f(row[galois_src_index(sub * M + i, e, logn)]);
+            } else {
+                tile_to_lds<CH, M, T, (FHE_PIPE_NT & 4) != 0>(lds, src, tid, to_f);
+            }
+            FHE_BARRIER();
+            ntt_inv_lds<LOGM, T, 0, 0, false, F64>(lds, twr, logn, sub, pmf, tid, true, ninv[2 * mi], ninv[2 * mi + 1], tw0);
+            lds_to_tile<CH, M, T>(lds, dst, tid, to_c);
+        }
+    } else if constexpr (!INVERSE) {
         // the first pass reads its groups straight from global memory (no tile staging)
         ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? FWD_B0 : 0)>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) { return load_last<(FHE_PIPE_NT & 2) != 0>(src + i); });
         if constexpr (NARROW) {  // < 16p -> canonical
@@ -105,7 +130,9 @@ struct TensorSrc {
 // A launch covers the rows [row_begin, row_begin + lrows) of the nrows-row extended basis; NARROW (all of them
 // below 2^60) selects the inverse passes with tracked bounds (inv_pass): the ciphertext primes of the extended
 // basis are 60-bit, the extension primes 62-bit, so bfv_mul issues one launch for each group.
-template <int LOGM, bool SUB = false, bool NARROW = false>
+// F64 = HR > 0 (round 6; whole rows, every modulus of the launch below 2^(53 - HR)): the products and the inverse passes
+// on doubles (zq_f64.hpp mulmod2_f64: no precomputed quotient, q from h / p); `itw` / `ninv` are the F64 tables.
+template <int LOGM, bool SUB = false, bool NARROW = false, int F64 = 0>
 __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     tensor_intt_kernel(TensorSrc ts, u64 *__restrict__ out, const DevMod *__restrict__ mods,
                        const u64x2 *__restrict__ itw, const u64x2 *__restrict__ ninv, uint32_t nrows, uint32_t nb,
@@ -132,7 +159,7 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     const uint32_t b = to_sgpr(rowb / lrows), r = row_begin + (rowb - b * lrows);
     const DevMod md = mods[r];
     const u64 p = md.p;
-    const PM pm = make_pm(md);
+    const PM pm = F64 ? make_pm_f64(md) : make_pm(md);
     const u64 pk = (u64)nrows << logn;
     const u64 roff = ((u64)r << logn) + (u64)sub * M;  // this tile inside a polynomial
     const u64 *a0, *a1, *b0, *b1;  // rows of c00, c01, c10, c11
@@ -149,6 +176,13 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         b1 = b0 + pk;
     }
     auto prod = [&](u64 x00, u64 x01, u64 x10, u64 x11) -> u64 {
+        if constexpr (F64 > 0) {   // (each product below 0.875 p, the double product below 1.75 p: F64_BIN0 = 2 F64_ONE)
+            const PF pf = pf_of(pm);
+            if (slot == 0) return bits_of_f64(mulmod2_f64(f64_from_u64(x00), f64_from_u64(x10), pf));
+            if (slot == 2) return bits_of_f64(mulmod2_f64(f64_from_u64(x01), f64_from_u64(x11), pf));
+            return bits_of_f64(mulmod2_f64(f64_from_u64(x00), f64_from_u64(x11), pf) +
+                               mulmod2_f64(f64_from_u64(x01), f64_from_u64(x10), pf));
+        }
         // (results stay below 2p: the inverse transform's first pass takes that range)
         if (slot == 0) return mul_mod_lazy(x00, x10, md);
         if (slot == 2) return mul_mod_lazy(x01, x11, md);
@@ -181,6 +215,12 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
                     inv_tw_load(tw0, twr, logn, sub, tid);
                 }
                 const uint32_t i = 2 * (c * T + tid);
+                if constexpr (F64 > 0) {
+                    const PF pf = pf_of(pm);
+                    lds[padi(i)] = bits_of_f64(mulmod2_f64(f64_from_u64(va[c].x), f64_from_u64(vb[c].x), pf));
+                    lds[padi(i + 1)] = bits_of_f64(mulmod2_f64(f64_from_u64(va[c].y), f64_from_u64(vb[c].y), pf));
+                    continue;
+                }
                 lds[padi(i)] = mul_mod_lazy(va[c].x, vb[c].x, md);
                 lds[padi(i + 1)] = mul_mod_lazy(va[c].y, vb[c].y, md);
             }
@@ -218,6 +258,13 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
     u64 *dst = out + ((u64)slot * nb + b) * pk + roff;
     // (a block-uniform branch between the narrow and the general inverse passes inside one kernel was measured:
     // 128 VGPRs, spills and twice the code -- 2 % slower; hence one launch per row group)
+    if constexpr (F64 > 0) {
+        static_assert(F64 == 0 || (!SUB && !NARROW), "the F64 instances: whole rows");
+        const PF pf = pf_of(pm);
+        ntt_inv_lds<LOGM, T, 0, 0, false, F64, 2 * F64_ONE>(lds, twr, logn, sub, pm, tid, true, ninv[2 * r], ninv[2 * r + 1], tw0);
+        lds_to_tile<CH, M, T>(lds, dst, tid, [&](u64 v) { return to_u64_canonical(f64_of_bits(v), pf); });
+        return;
+    }
     ntt_inv_lds<LOGM, T, 0, 0, NARROW>(lds, twr, logn, sub, pm, tid, !SUB, ninv[2 * r], ninv[2 * r + 1], tw0);
     if constexpr (SUB)
         lds_to_tile<CH, M, T>(lds, dst, tid, [](u64 v) { return v; });  // < 2p, the global pass finishes

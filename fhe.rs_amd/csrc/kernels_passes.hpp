@@ -2,6 +2,7 @@
 // helpers: the building blocks of the NTT, tensor+iNTT and key-switch kernels.
 #pragma once
 #include "kernels_common.hpp"
+#include "zq_f64.hpp"
 
 namespace fhe {
 namespace k {
@@ -72,6 +73,10 @@ __device__ __forceinline__ void fwd_tw_load(FwdTw<G, LOGM, S0, T> &tw_regs, cons
 // own right before use (fewer live registers).
 // NARROW = b0 > 0: moduli below 2^60 and input to stage 0 below b0*p (1: canonical) --
 // fwd_butterfly_narrow (zq_dev.hpp); values are below 16p on exit instead of 4p.
+// NARROW = -HR < 0 (round 6): the F64 form for launches whose moduli are all below 2^(53 - HR) (zq_f64.hpp).  The tile
+// holds the bit patterns of doubles (signed representatives), `tw` is the context's F64 twiddle table ({w, w / p} as
+// doubles, same indexing), pm carries {p, 1 / p} (make_pm_f64); input to stage 0 below 2^(53 - HR) in magnitude
+// (canonical residues, or digit rows of another modulus of the launch); values leave below f64_fwd_out_bound().
 // NT > 1: the same pass on NT tiles that lie `tile_words` apart in LDS (the key switch transforms two digits
 // under one modulus at once): addresses and twiddles are formed once and serve every tile.
 template <int G, int LOGM, int S0, int T, bool PRE, int NARROW = 0, class Src = NoSrc, int NT = 1, bool WLX = false>
@@ -129,7 +134,13 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
 #pragma unroll
                 for (uint32_t j = 0; j < half; j++) {
                     const uint32_t a = blk * 2 * half + j;
-                    if constexpr (NARROW > 0)
+                    if constexpr (NARROW < 0) {
+                        const PF pf = pf_of(pm);
+                        double xa = f64_of_bits(x[a]), xb = f64_of_bits(x[a + half]);
+                        if (f64_fwd_reduces(S0 + u, -NARROW)) xa = reduce_f64(xa, pf), xb = reduce_f64(xb, pf);
+                        fwd_butterfly_f64(xa, xb, f64_of_bits(wv.x), f64_of_bits(wv.y), pf.p);
+                        x[a] = bits_of_f64(xa), x[a + half] = bits_of_f64(xb);
+                    } else if constexpr (NARROW > 0)
                         fwd_butterfly_narrow<UNIFORM>(x[a], x[a + half], wv.x, wv.y, pm, fwd_narrow_corrects(S0 + u, NARROW));
                     else
                         fwd_butterfly<UNIFORM>(x[a], x[a + half], wv.x, wv.y, pm);
@@ -294,7 +305,10 @@ __device__ __forceinline__ u64 small_multiple(const PM &pm, int k) {
     if (k & 16) r += pm.p2 << 3;
     return r;
 }
-template <int G, int LOGM, int V0, int T, bool NARROW = false, bool WLX = false, int BIN = 2, int BOUT = 2>
+// F64 = HR > 0 (round 6): the F64 form (see fwd_pass; zq_f64.hpp).  BIN / BOUT are then bounds in 1/1024ths of
+// 2^(53 - HR): every register's bound is tracked through the unrolled stages as for NARROW, a register is reduced
+// (reduce_f64, three operations) only where a sum would leave 2^53, and values travel between passes below BOUT.
+template <int G, int LOGM, int V0, int T, bool NARROW = false, bool WLX = false, int BIN = 2, int BOUT = 2, int F64 = 0>
 __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
                                          const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv,
                                          const InvTw<G, LOGM, V0, T> &tw_regs) {
@@ -345,7 +359,29 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
 #pragma unroll
                 for (uint32_t j = 0; j < (1u << u); j++) {
                     const uint32_t a = blk * (2u << u) + j, b = a + (1u << u);
-                    if constexpr (NARROW) {
+                    if constexpr (F64 > 0) {
+                        const PF pf = pf_of(pm);
+                        double xa = f64_of_bits(x[a]), xb = f64_of_bits(x[b]);
+                        // keep xa + xb and xa - xb below 2^53: reduce the larger operand (then the other) if needed
+#pragma unroll
+                        for (int it = 0; it < 2; it++)
+                            if (bnd[a] + bnd[b] >= f64_limit(F64)) {
+                                if (bnd[a] >= bnd[b]) xa = reduce_f64(xa, pf), bnd[a] = F64_REDUCED;
+                                else xb = reduce_f64(xb, pf), bnd[b] = F64_REDUCED;
+                            }
+                        const double d = xa - xb, sm = xa + xb;
+                        if (V0 + G == LOGM && u == G - 1 && fold) {
+                            xa = mulmod_f64(sm, f64_of_bits(ninv.x), f64_of_bits(ninv.y), pf.p);
+                            xb = mulmod_f64(d, f64_of_bits(zninv.x), f64_of_bits(zninv.y), pf.p);
+                        } else {
+                            xa = sm;
+                            xb = mulmod_f64(d, f64_of_bits(zv.x), f64_of_bits(zv.y), pf.p);
+                        }
+                        const int sum = bnd[a] + bnd[b];
+                        bnd[a] = sum;   // (kept independent of the run-time `fold`: conservative for the folded last stage)
+                        bnd[b] = f64_product_bound(sum, F64);
+                        x[a] = bits_of_f64(xa), x[b] = bits_of_f64(xb);
+                    } else if constexpr (NARROW) {
                         fit16(x[a], bnd[a], x[b], bnd[b]);
                         const u64 t = x[a], y = x[b];
                         const u64 diff = small_multiple(pm, bnd[b]) + t - y;   // (a compile-time multiple of the uniform p)
@@ -376,7 +412,14 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
                 }
             }
         }
-        if constexpr (NARROW) {  // the next pass (or the epilogue / the global pass) expects values below BOUT * p
+        if constexpr (F64 > 0) {
+            if (!(V0 + G == LOGM && fold)) {
+                const PF pf = pf_of(pm);
+#pragma unroll
+                for (uint32_t e = 0; e < R; e++)
+                    if (bnd[e] > BOUT) x[e] = bits_of_f64(reduce_f64(f64_of_bits(x[e]), pf));
+            }
+        } else if constexpr (NARROW) {  // the next pass (or the epilogue / the global pass) expects values below BOUT * p
             if (!(V0 + G == LOGM && fold)) {
 #pragma unroll
                 for (uint32_t e = 0; e < R; e++) {
@@ -410,7 +453,11 @@ constexpr bool inv_wl_after(int logm, int pass) {   // exchange between inverse 
 }
 template <int LOGM, int T>
 using InvTwFirst = InvTw<inv_plan_g<LOGM, 0>(), LOGM, 0, T>;
-template <int LOGM, int T, int PASS = 0, int V0 = 0, bool NARROW = false, class W>
+// values between F64 inverse passes: below a quarter of 2^53 (two more doublings fit before the next reduction)
+constexpr int f64_inv_mid(int HR) { return f64_limit(HR) / 4; }
+// F64_BIN0: bound of the tile the first F64 pass reads (canonical residues: F64_ONE; the tensor kernel's double products:
+// twice that)
+template <int LOGM, int T, int PASS = 0, int V0 = 0, bool NARROW = false, int F64 = 0, int F64_BIN0 = F64_ONE, class W>
 __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ itw, uint32_t logn, uint32_t sub,
                                             const PM pm, uint32_t tid, bool fold, u64x2 ninv, u64x2 zninv,
                                             const W &tw_regs) {
@@ -418,6 +465,10 @@ __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ 
     constexpr bool WLX = inv_wl_after(LOGM, PASS) || inv_wl_after(LOGM, PASS - 1);
     static_assert(!WLX || T % 64 == 0, "wave-local exchanges need whole 64-lane waves");
     constexpr bool LAST = PASS + 1 == plan_np(LOGM, GMAX);
+    if constexpr (F64 > 0)
+        inv_pass<G, LOGM, V0, T, false, WLX, (PASS == 0 ? F64_BIN0 : f64_inv_mid(F64)), f64_inv_mid(F64), F64>(
+            lds, itw, logn, sub, pm, tid, fold, ninv, zninv, tw_regs);
+    else
     inv_pass<G, LOGM, V0, T, NARROW, WLX, (PASS == 0 ? 2 : INV_NARROW_MID), (LAST ? 2 : INV_NARROW_MID)>(
         lds, itw, logn, sub, pm, tid, fold, ninv, zninv, tw_regs);
     if constexpr (PASS + 1 < plan_np(LOGM, GMAX)) {
@@ -429,7 +480,7 @@ __device__ __forceinline__ void ntt_inv_lds(u64 *lds, const u64x2 *__restrict__ 
             wave_sync();
         else
             FHE_BARRIER();
-        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G, NARROW>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, next);
+        ntt_inv_lds<LOGM, T, PASS + 1, V0 + G, NARROW, F64, F64_BIN0>(lds, itw, logn, sub, pm, tid, fold, ninv, zninv, next);
     } else {
         FHE_BARRIER();
     }

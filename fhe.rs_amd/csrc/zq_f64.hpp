@@ -18,10 +18,11 @@
 // Bounds (p < 2^(53-H), H >= 3; |x| = a p, 0 <= w < p, wp = RN(w / p)):
 //   * x * wp carries two roundings: |x wp - x w / p| <= |x| 2^-52 (1 + 2^-53) =: eps <= a 2^(1-H);
 //     q = rint(.) is within 0.5 + eps of the true quotient, so |r| <= (0.5 + eps) p.
-//   * exactness of fma(-q, p, h): h - q p = r - l with |l| <= ulp(h) / 2 <= |x| p 2^-53 <= a p 2^-H... in integers:
-//     |h - q p| <= (0.5 + eps) p + a p 2^-H p / p  -- with a <= 2^(H-1) both terms are below p, so |h - q p| < 2 p < 2^53:
-//     an integer of that size is representable, the fma is exact, and so is the final + l.
-//   * callers keep a <= 2^(H-1) (|x| < 2^52): eps <= 1, |r| <= 1.5 p; with a <= 2^(H-2): |r| <= p; a <= 1: |r| < 0.51 p.
+//   * exactness of fma(-q, p, h): h - q p = r - l with |l| <= ulp(h) / 2 <= |x| w 2^-53 < |x| p 2^-53.  For |x| < 2^53:
+//     eps < 2, |r| < 2.5 p, |l| < p, so |h - q p| < 3.5 p < 2^52: an integer of that size is representable, the fma does
+//     not round, and neither does the final + l (two integers whose sum is below 2^52).
+//   * so the one invariant is REPRESENTABILITY: every value stays an integer below 2^53 in magnitude; the lazy product
+//     of y is then below (0.5 + |y| 2^-52) p.  f64_fwd_bound() below tracks it.
 // reduce_f64 (x - p rint(x / p), three operations) brings any |x| < 2^52 to |r| <= 0.5 p + |x| 2^-52 p.
 // f64_bound() tracks `a` through the stages of a transform at compile time, as fwd_narrow_bound() does for the
 // integer narrow butterflies, and says where a reduction has to sit.
@@ -114,20 +115,56 @@ FHE_HD void inv_butterfly_f64(double &x, double &y, double z, double zp, double 
     y = mulmod_f64(d, z, zp, p);
 }
 
-// Bound tracking, in units of p, for p < 2^(53 - H): representatives must stay below 2^(H-1) p = 2^52 where they enter a
-// product.  Forward: a' = a + 0.5 + a 2^(1-H) per stage; f64_fwd_reduce(stage) says whether the values are reduced
-// (to 0.5 p) before that stage.  Computed in 1/1024ths to stay in integers.
-constexpr int f64_fwd_step(int a1024, int H) { return a1024 + 512 + ((a1024 * 2) >> H) + 1; }
-constexpr int f64_fwd_bound(int stage, int H, int a0_1024 = 1024) {
-    int a = a0_1024;
+// A modulus as the F64 passes carry it: the kernels' PM record (four 64-bit words in scalar registers) holds the bit
+// patterns of p and 1/p as doubles in its first two words, so that the pass templates keep one signature.
+FHE_HD double f64_of_bits(u64 v) {
+    union {
+        u64 u;
+        double d;
+    } c;
+    c.u = v;
+    return c.d;
+}
+FHE_HD u64 bits_of_f64(double d) {
+    union {
+        u64 u;
+        double d;
+    } c;
+    c.d = d;
+    return c.u;
+}
+FHE_HD PM make_pm_f64(const DevMod &m) {
+    const double p = (double)m.p;          // exact: p < 2^50
+    return PM{bits_of_f64(p), bits_of_f64(1.0 / p), 0, 0};
+}
+FHE_HD PF pf_of(const PM &pm) { return PF{f64_of_bits(pm.p), f64_of_bits(pm.p2)}; }
+
+// Bound tracking for a launch whose moduli are all below 2^(53 - HR) (HR = 3: 50-bit primes, 4: 49-bit, 5: 48-bit and
+// less).  Bounds are ABSOLUTE, in units of U = 2^(53 - HR) / 1024: a digit row lifted to another modulus of the launch is
+// simply a representative below 1024 U, whatever the ratio of the two moduli.  Representatives must stay below
+// 2^53 = 2^HR * 1024 U.  A lazy product of y is below (0.5 + |y| 2^-52) p < (512 + (|y| / U) 2^(1 - HR)) U.
+constexpr int F64_ONE = 1024;
+constexpr int f64_limit(int HR) { return F64_ONE << HR; }
+constexpr int f64_product_bound(int y, int HR) { return 512 + ((2 * y) >> HR) + 2; }      // (+2: rounding of this model)
+constexpr int F64_REDUCED = 520;   // after reduce_f64: 0.5 p + |x| 2^-52 p, far below 520 / 1024
+// forward (Cooley-Tukey) stages: every value of a stage shares one bound; a' = a + product_bound(a)
+constexpr int f64_fwd_step(int a, int HR) { return a + f64_product_bound(a, HR); }
+constexpr int f64_fwd_bound(int stage, int HR, int a0 = F64_ONE) {   // bound BEFORE `stage` (after its reduction, if any)
+    int a = a0;
     for (int s = 0; s < stage; s++) {
-        if (f64_fwd_step(a, H) > (1024 << (H - 1))) a = 513;   // reduce first
-        a = f64_fwd_step(a, H);
+        if (f64_fwd_step(a, HR) >= f64_limit(HR)) a = F64_REDUCED;
+        a = f64_fwd_step(a, HR);
     }
     return a;
 }
-constexpr bool f64_fwd_reduces(int stage, int H, int a0_1024 = 1024) {
-    return f64_fwd_step(f64_fwd_bound(stage, H, a0_1024), H) > (1024 << (H - 1));
+constexpr bool f64_fwd_reduces(int stage, int HR, int a0 = F64_ONE) {   // are the values reduced before `stage`?
+    return f64_fwd_step(f64_fwd_bound(stage, HR, a0), HR) >= f64_limit(HR);
 }
+constexpr int f64_fwd_out_bound(int stages, int HR, int a0 = F64_ONE) {   // bound after the last of `stages` stages
+    const int a = f64_fwd_bound(stages - 1, HR, a0);
+    return f64_fwd_step(f64_fwd_reduces(stages - 1, HR, a0) ? F64_REDUCED : a, HR);
+}
+static_assert(f64_fwd_out_bound(16, 5) < f64_limit(5), "48-bit moduli: no reduction inside a forward transform up to N = 65536");
+static_assert(!f64_fwd_reduces(15, 5) && f64_fwd_reduces(5, 3) && !f64_fwd_reduces(4, 3) && f64_fwd_reduces(11, 4) && !f64_fwd_reduces(10, 4), "forward reduction schedule");
 
 }  // namespace fhe

@@ -509,6 +509,12 @@ fhe_status fhe_ubench_scaler(const fhe_scaler *scaler, double min_seconds, doubl
 /* The box's own streaming rate: a 16-byte-per-lane copy of `bytes` bytes with streaming loads / stores (the path's
  * element-wise kernels are made of the same accesses); *bytes_per_s = read + write bytes per second. */
 fhe_status fhe_ubench_copy(int device, size_t bytes, double min_seconds, double *bytes_per_s);
+/* Execution option (round 6): rows whose moduli are all below 2^50 -- every modulus of the reference's stock parameter sets,
+ * F/bfv/parameters.rs:222-251 -- run their transforms and key-switch accumulations on the FP64 FMA pipe (exact arithmetic on
+ * doubles holding integers, csrc/zq_f64.hpp); on = 0 sends them to the integer kernels like every wider modulus.  Results
+ * are bit-identical either way (canonical residues are a function of the inputs); default on; process-wide, read per launch. */
+void fhe_engine_set_f64(int on);
+int fhe_engine_get_f64(void);
 /* Per-kernel HIP-event timing (events carried by the launches, on the launching stream).  One entry per (launch label,
  * kernel symbol): fhe_prof_get gives the entry's label -- several entries share a label when several instantiations of a
  * kernel template run under it; sum them for the family -- and fhe_prof_get_symbol the kernel's demangled symbol, the

@@ -103,13 +103,43 @@ pub fn default_device() -> i32 {
     std::env::var("FHE_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0)
 }
 
+thread_local! {
+    /// Depth of `with_native` scopes on this thread (see `enabled`).
+    static FORCE_NATIVE: std::cell::Cell<u32> = const { std::cell::Cell::new(0) };
+}
+
+/// Runs `f` with the patched crates on their NATIVE (CPU) path on the calling thread, whatever the process-wide
+/// switch says, and restores the previous state afterwards (also when `f` panics).  This is what lets ONE test
+/// process compute a value twice -- once through fhe.rs's own code, once through the engine -- and compare the two
+/// bit for bit (`crates/*/tests/hip_parity.rs`, patches 17 / 18): the only way psi, the seeded sampler and every
+/// composite operation can be pinned against the reference itself.  Nests; affects this thread only.
+pub fn with_native<R>(f: impl FnOnce() -> R) -> R {
+    struct Restore;
+    impl Drop for Restore {
+        fn drop(&mut self) { FORCE_NATIVE.with(|c| c.set(c.get() - 1)); }
+    }
+    FORCE_NATIVE.with(|c| c.set(c.get() + 1));
+    let _restore = Restore;
+    f()
+}
+
+/// Is the calling thread inside a `with_native` scope?
+pub fn native_forced() -> bool { FORCE_NATIVE.with(|c| c.get() > 0) }
+
 /// Whether the patched crates forward to the engine at all: the `hip` cargo feature compiles the forwarding in, this
-/// decides at run time (once per process).  False when `FHE_HIP_DISABLE` is set or no HIP device is visible, so a binary
-/// built with the feature still runs -- on the native CPU path -- on a machine without a GPU.
+/// decides at run time.  False when `FHE_HIP_DISABLE` is set or no HIP device is visible (both read once per process),
+/// so a binary built with the feature still runs -- on the native CPU path -- on a machine without a GPU; and false
+/// inside `with_native` on the calling thread.
 pub fn enabled() -> bool {
     static ON: OnceLock<bool> = OnceLock::new();
-    *ON.get_or_init(|| std::env::var_os("FHE_HIP_DISABLE").is_none() && unsafe { ffi::fhe_device_count() } > 0)
+    !native_forced() && *ON.get_or_init(|| std::env::var_os("FHE_HIP_DISABLE").is_none() && unsafe { ffi::fhe_device_count() } > 0)
 }
+
+/// Execution option of the engine (`fhe_engine_set_f64`): rows whose moduli are all below 2^50 -- every modulus of
+/// `BfvParameters::default_parameters_128` -- run on the FP64-FMA kernels (default) or on the integer kernels.  Results are
+/// bit-identical either way; the parity tests run both.
+pub fn set_f64_kernels(on: bool) { unsafe { ffi::fhe_engine_set_f64(on as std::os::raw::c_int) } }
+pub fn f64_kernels() -> bool { unsafe { ffi::fhe_engine_get_f64() != 0 } }
 
 /// The six tables of one `NttOperator` per modulus (ntt/native.rs:16-26), flattened `[nmoduli][degree]`.
 /// The host passes its own so that psi -- drawn from ChaCha8 in the reference -- is the same on both sides.

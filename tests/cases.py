@@ -1180,3 +1180,107 @@ def case_scaler_many_wide_moduli(fhe, dev, n=16, counts=(9, 24, 40), factors=((3
             got = x.back(sc.scale(x.to(np.stack([arr(p) for p in polys])), ntt=False))
             for i, p in enumerate(polys):
                 assert np.array_equal(got[i], arr(osc.scale(p))), (cnt, num, den, i)
+
+
+# ------------------------------------------------------------------------------------------------ round 6: F64 kernels
+def _f64_labels(fhe, fn):
+    """Runs fn() with the library's launch profiler on; returns (result, set of launch labels)."""
+    fhe.prof_reset()
+    fhe.prof_enable(True)
+    try:
+        out = fn()
+    finally:
+        fhe.prof_enable(False)
+    return out, set(fhe.prof_report())
+
+
+def case_f64_ntt(fhe, dev, n, sizes=(50, 50, 49, 48, 44, 36), seed=11):
+    """Moduli below 2^50 take the FP64-FMA instances of ntt_kernel (csrc/zq_f64.hpp; whole rows of 4096 ... 16384 points):
+    forward and inverse transforms against the C oracle's butterflies (M/ntt/native.rs:142-233), on random residues and
+    on the word patterns where a lost rounding would show (0, 1, p - 1, alternating), per launch class (a basis with a
+    50-bit prime runs class 3, 49-bit class 4, the rest class 5); the same calls with the F64 option off (integer narrow
+    kernels) give the same words, and the profiler says which kernels really ran."""
+    from fhe_oracle import bfv as obfv, coracle
+    from fhe_oracle.rq import Context as OCtx
+    x = Xfer(dev)
+    rng = np.random.default_rng(seed + n)
+    assert fhe.get_f64()
+    for group in ([s for s in sizes], [s for s in sizes if s <= 49], [s for s in sizes if s <= 48]):
+        q = obfv.generate_moduli(group, n)
+        cc = coracle.CCtx(OCtx(q, n))
+        c = fhe.Context(q, n)
+        qa = np.array(q, dtype=np.uint64)[:, None]
+        rand = np.stack([rng.integers(0, m, size=n, dtype=np.uint64) for m in q])
+        alt = np.where(np.arange(n)[None, :] % 2 == 0, qa - 1, 0).astype(np.uint64)
+        polys = np.stack([rand, np.broadcast_to(qa - 1, (len(q), n)).copy(), alt, np.ones((len(q), n), dtype=np.uint64),
+                          np.zeros((len(q), n), dtype=np.uint64)])
+        want = np.stack([cc.poly_ntt_forward(p) for p in polys])
+        f, labels = _f64_labels(fhe, lambda: x.back(c.ntt_forward(x.to(polys))))
+        assert np.array_equal(f, want), (n, group)
+        assert "ntt_fwd_f64" in labels and "ntt_fwd" not in labels, labels
+        b, labels = _f64_labels(fhe, lambda: x.back(c.ntt_backward(x.to(f))))
+        assert np.array_equal(b, polys), (n, group)
+        assert "ntt_inv_f64" in labels and "ntt_inv" not in labels, labels
+        fhe.set_f64(False)
+        try:
+            f2, labels = _f64_labels(fhe, lambda: x.back(c.ntt_forward(x.to(polys))))
+            assert np.array_equal(f2, want) and "ntt_fwd" in labels and "ntt_fwd_f64" not in labels, labels
+            assert np.array_equal(x.back(c.ntt_backward(x.to(f2))), polys)
+        finally:
+            fhe.set_f64(True)
+    # one modulus of 51 bits in the launch: integer kernels for the whole launch
+    q = obfv.generate_moduli([51, 44], n)
+    c = fhe.Context(q, n)
+    p = np.stack([rng.integers(0, m, size=n, dtype=np.uint64) for m in q])[None]
+    f, labels = _f64_labels(fhe, lambda: x.back(c.ntt_forward(x.to(p))))
+    assert "ntt_fwd" in labels and "ntt_fwd_f64" not in labels
+    assert np.array_equal(x.back(c.ntt_backward(x.to(f))), p)
+
+
+def case_f64_key_switch(fhe, dev, n, sizes, batch=2, seed=0xF4E5F640, exps=(3,), mode=1):
+    """The fused key switch's F64 instances (every key modulus below 2^50, RNS digits): key_switch of arbitrary digit rows,
+    relinearisation (own Ntt row + both addends) and Galois rotations (gathering loader) against the C oracle
+    (F/bfv/keys/key_switching_key.rs:241-320, relinearization_key.rs:69-102, galois_key.rs:63-123), forced FUSED so that
+    small batches reach it; then the same with the F64 option off.  `sizes` with more than ~10 moduli of 50 bits walk the
+    accumulator fold.  mode = 2 (KS_UNFUSED): stage A's F64 instances (ks_ntt_kernel), stage B unchanged."""
+    from fhe_oracle import bfv as obfv, coracle
+    from fhe_oracle.rq import Context as OCtx
+    import full_size
+    x = Xfer(dev)
+    q = obfv.generate_moduli(list(sizes), n)
+    L = len(q)
+    cc = coracle.CCtx(OCtx(q, n))
+    ck = full_size.host_key(cc, seed, L)
+    c0 = np.stack([cc.synth_poly(seed, 0, 8 + 2 * i) for i in range(L)])
+    c1 = np.stack([cc.synth_poly(seed, 0, 9 + 2 * i) for i in range(L)])
+    ctx = fhe.Context(q, n)
+    ksk = fhe.KeySwitchingKey(ctx, ctx, c0, c1).set_mode(mode)      # 1: KS_FUSED, 2: KS_UNFUSED
+    lab_f64, lab_int = ("key_switch_fused_f64", "key_switch_fused") if mode == 1 else ("ks_digit_ntt_f64", "ks_digit_ntt")
+    p = np.stack([np.stack([cc.synth_poly(seed, i, 0)]) for i in range(batch)])[:, 0]     # [batch][L][N], residues < q_i
+    # extremes in the first polynomial: q_i - 1 everywhere in row 0, zeros in the last row
+    p[0, 0, :] = np.uint64(q[0] - 1)
+    p[0, L - 1, :] = 0
+    ct3 = np.stack([np.stack([cc.synth_poly(seed, i, part) for part in range(3)]) for i in range(batch)])
+    rk = fhe.RelinearizationKey(ksk)
+    for f64 in (True, False):
+        fhe.set_f64(f64)
+        try:
+            (g0, g1), labels = _f64_labels(fhe, lambda: ksk.key_switch(x.to(p)))
+            g0, g1 = x.back(g0), x.back(g1)
+            assert (lab_f64 in labels) == f64 and (lab_int in labels) == (not f64), (labels, f64)
+            for i in range(batch):
+                w0, w1 = ck.key_switch(p[i])
+                assert np.array_equal(g0[i], w0) and np.array_equal(g1[i], w1), (n, sizes, f64, i)
+            got, labels = _f64_labels(fhe, lambda: x.back(rk.relinearizes(x.to(ct3))))
+            assert (lab_f64 in labels) == f64, (labels, f64)
+            for i in range(batch):
+                k0, k1 = ck.key_switch(cc.poly_ntt_backward(ct3[i, 2]))
+                want = np.stack([cc.poly_add(ct3[i, 0], k0), cc.poly_add(ct3[i, 1], k1)])
+                assert np.array_equal(got[i], want), (n, sizes, f64, "relinearize", i)
+            for e in exps:
+                r, labels = _f64_labels(fhe, lambda: x.back(fhe.GaloisKey(ksk, e).relinearize(x.to(ct3[:, :2].copy()))))
+                assert (lab_f64 in labels) == f64, (labels, f64)
+                for i in range(batch):
+                    assert np.array_equal(r[i], ck.galois_relinearize(e, ct3[i, :2])), (n, sizes, f64, "rotate", e, i)
+        finally:
+            fhe.set_f64(True)

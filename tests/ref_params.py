@@ -79,6 +79,14 @@ def synth_key(cc, seed, slot, ndigits=None):
     return c0, c1, ck
 
 
+FORCE_KS_MODE = None     # tests set this to run every key switch of the checks below in one strategy (fhe_ksk_set_mode)
+
+
+def _ksk(fhe, ctx, c0, c1):
+    k = fhe.KeySwitchingKey(ctx, ctx, c0, c1)
+    return k.set_mode(FORCE_KS_MODE) if FORCE_KS_MODE else k
+
+
 def params(fhe, n):
     par = fhe.BfvParameters(n, plaintext_modulus(n), moduli=DEFAULT_128[n])
     assert par.moduli == DEFAULT_128[n]
@@ -97,7 +105,7 @@ def check_mul(fhe, dev, n, relin, mod_switch=False, batch=2, lvl=0, seed_off=0, 
     rk, ck = None, None
     if relin:
         c0, c1, ck = synth_key(cb, seed, lvl)
-        rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1))
+        rk = fhe.RelinearizationKey(_ksk(fhe, ctx, c0, c1))
     m = fhe.Multiplicator.default(par, rk, lvl, mod_switch)
     if relin:
         assert m.basis() == o["mul"].moduli
@@ -126,13 +134,13 @@ def check_relin_rotate(fhe, dev, n, batch=2, digest=None):
     ctx = params(fhe, n).context_at_level(0)
     seed = SEED + n + 1
     c0, c1, ck = synth_key(cc, seed, 0)
-    rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1))
+    rk = fhe.RelinearizationKey(_ksk(fhe, ctx, c0, c1))
     ct3 = np.stack([synth_ct(cc, seed, i, 0, 3) for i in range(batch)])
     got = x.back(rk.relinearizes(x.to(ct3)))
     gks, cks = [], {}
     for slot, e in ((1, 2 * n - 1), (2, 3)):
         g0, g1, gk = synth_key(cc, seed, slot)
-        gks.append(fhe.GaloisKey(fhe.KeySwitchingKey(ctx, ctx, g0, g1), e))
+        gks.append(fhe.GaloisKey(_ksk(fhe, ctx, g0, g1), e))
         cks[e] = gk
     ek = fhe.EvaluationKey(n, gks)
     ct2 = np.ascontiguousarray(ct3[:, :2])
@@ -167,7 +175,7 @@ def check_inner_sum(fhe, dev, n, batch=1, digest=None):
     gks, cks = [], {}
     for slot, e in enumerate(seq):
         g0, g1, gk = synth_key(cc, seed, slot)
-        gks.append(fhe.GaloisKey(fhe.KeySwitchingKey(ctx, ctx, g0, g1), e))
+        gks.append(fhe.GaloisKey(_ksk(fhe, ctx, g0, g1), e))
         cks[e] = gk
     ek = fhe.EvaluationKey(n, gks)
     cts = np.stack([synth_ct(cc, seed, b, 0, 2) for b in range(batch)])
@@ -193,7 +201,7 @@ def check_expand(fhe, dev, n, size=16, digest=None):
     for l in range(lv):
         e = (n >> l) + 1
         g0, g1, gk = synth_key(cc, seed, l)
-        gks.append(fhe.GaloisKey(fhe.KeySwitchingKey(ctx, ctx, g0, g1), e))
+        gks.append(fhe.GaloisKey(_ksk(fhe, ctx, g0, g1), e))
         cks[e] = gk
     ek = fhe.EvaluationKey(n, gks)
     ct = synth_ct(cc, seed, 0, 0, 2)
@@ -255,7 +263,7 @@ def check_mul2(fhe, dev, n, batch=2, digest=None):
     dn = fhe.Scaler(mctx, ctx, s["t"], s["P"])
     seed = SEED + n + 4
     c0, c1, ck = synth_key(cb, seed, 0)
-    rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1))
+    rk = fhe.RelinearizationKey(_ksk(fhe, ctx, c0, c1))
     m = fhe.Multiplicator(el, er, dn, rk)
     lhs = np.stack([synth_ct(cb, seed, i, 0, 2) for i in range(batch)])
     rhs = np.stack([synth_ct(cb, seed, i, 2, 2) for i in range(batch)])
@@ -280,7 +288,7 @@ def check_chain(fhe, dev, n, batch=2, digest=None):
         cb = o["cb"]
         ctx = par.context_at_level(lvl)
         c0, c1, ck = synth_key(cb, seed, lvl)
-        rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, c0, c1))
+        rk = fhe.RelinearizationKey(_ksk(fhe, ctx, c0, c1))
         m = fhe.Multiplicator.default(par, rk, lvl, True)
         assert m.basis() == o["mul"].moduli, lvl
         cm = coracle.CMul(o["cb"], o["cm"], o["cel"], o["cel"], o["cdn"], ck, True)

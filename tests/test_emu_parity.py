@@ -451,3 +451,46 @@ def test_galois_folded_substitution_rows(fhe, n, mode):
         got = fhe.GaloisKey(ksk, e).relinearize(ct)
         for b in range(2):
             assert np.array_equal(np.asarray(got[b]), ck.galois_relinearize(e, ct[b])), (n, mode, e, b)
+
+
+# ---- round 6: the FP64-FMA instances for moduli below 2^50 (csrc/zq_f64.hpp); range traps active in this build ----
+def test_f64_ntt(fhe):
+    cases.case_f64_ntt(fhe, False, 4096)
+
+
+def test_f64_ntt_n16384(fhe):
+    cases.case_f64_ntt(fhe, False, 16384, sizes=(50, 49, 48))
+
+
+@pytest.mark.parametrize("n,sizes", [(4096, (36, 36, 37)), (8192, (43, 43, 44, 44, 44)), (4096, (50, 50, 49, 48)),
+                                     (16384, (48, 49, 49))])
+def test_f64_key_switch(fhe, n, sizes):
+    """The reference's stock n = 4096 / 8192 widths (parameters.rs:222-242), a 50-bit basis and a 16384-point tile."""
+    cases.case_f64_key_switch(fhe, False, n, sizes, exps=(3, 2 * n - 1) if n == 4096 else (3,))
+
+
+def test_f64_key_switch_accumulator_fold(fhe):
+    """Twelve 50-bit moduli: more digits than an F64 accumulator holds before it is reduced (class 3: nine terms)."""
+    cases.case_f64_key_switch(fhe, False, 4096, (50,) * 12, batch=1, exps=())
+
+
+@pytest.mark.parametrize("n,sizes", [(4096, (36, 36, 37)), (8192, (43, 43, 44, 44, 44)), (4096, (50, 49, 48))])
+def test_f64_key_switch_unfused(fhe, n, sizes):
+    """KS_UNFUSED: stage A (ks_ntt_kernel) on its F64 instances, W in canonical words, stage B unchanged."""
+    cases.case_f64_key_switch(fhe, False, n, sizes, mode=2)
+
+
+def test_f64_multiply_stock_sets(fhe):
+    """The reference's stock n = 4096 set through Multiplicator::multiply with every F64 kernel on the way (the
+    ciphertext rows' transforms, the key switch, the forward transform riding on the unfused stage A), then with the option
+    off: same words (C oracle)."""
+    import ref_params
+    for f64 in (True, False):
+        fhe.set_f64(f64)
+        try:
+            for mode in (1, 2):
+                ref_params.FORCE_KS_MODE = mode
+                ref_params.check_mul(fhe, False, 4096, relin=True, batch=2)
+        finally:
+            ref_params.FORCE_KS_MODE = None
+            fhe.set_f64(True)

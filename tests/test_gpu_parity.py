@@ -992,3 +992,69 @@ def test_measurement_aids(fhe):
     st = fhe.workspace_pool_stats(0)
     assert set(st) == {"scratch_reserved_bytes", "scratch_used_bytes", "buffers_reserved_bytes", "buffers_used_bytes"}
     assert fhe.workspace_pool_stats(99)["scratch_reserved_bytes"] == 0
+
+
+# ---- round 6: the FP64-FMA instances for moduli below 2^50 (csrc/zq_f64.hpp) ----------------------------------------
+@pytest.mark.parametrize("n", [4096, 8192, 16384])
+def test_f64_ntt(fhe, n):
+    """Forward / inverse transforms on the F64 instances (launch classes 3 / 4 / 5) against the C oracle, the integer
+    kernels on the same inputs, and the profiler's word on which kernels ran."""
+    cases.case_f64_ntt(fhe, True, n)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("n,sizes", [(4096, (36, 36, 37)), (8192, (43, 43, 44, 44, 44)), (4096, (50, 50, 49, 48)),
+                                     (16384, (48, 48, 48, 49, 49, 49, 49, 49, 49)), (8192, (27, 36, 43, 44, 48, 49, 50))])
+def test_f64_key_switch(fhe, n, sizes, mode):
+    """The key switch on its F64 instances -- fused (mode 1) and stage A of the unfused form (mode 2) -- with the
+    reference's stock widths (parameters.rs:222-251), a 50-bit basis, and every width of VERDICT r05 #3's list in one
+    basis; key_switch, relinearise, two rotations, against the C oracle, then with the option off."""
+    cases.case_f64_key_switch(fhe, True, n, sizes, batch=3, exps=(3, 2 * n - 1), mode=mode)
+
+
+def test_f64_key_switch_accumulator_fold(fhe):
+    """Sixteen 50-bit moduli: more digits than an F64 accumulator holds before it is reduced (class 3: nine terms)."""
+    cases.case_f64_key_switch(fhe, True, 4096, (50,) * 16, batch=2, exps=(3,))
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_stock_sets_on_the_integer_kernels(fhe, n):
+    """The stock sets run on the F64 kernels by default (every other test of this file); with fhe_engine_set_f64(0) they
+    take the integer narrow kernels as in rounds 1-5: every bench ID again, both key-switch strategies."""
+    import ref_params
+    fhe.set_f64(False)
+    try:
+        for mode in (1, 2):
+            ref_params.FORCE_KS_MODE = mode
+            ref_params.check_all(fhe, True, n, batch=2, expand_size=4, inner_sum=(mode == 1))
+    finally:
+        ref_params.FORCE_KS_MODE = None
+        fhe.set_f64(True)
+
+
+def test_f64_multiply_uses_every_f64_kernel(fhe):
+    """Multiplicator::multiply on the stock n = 8192 set at a batch that fills the device: the launch labels of one call
+    are the F64 instances for every narrow-row kernel (inverse / forward transforms of the ciphertext rows, the tensor's
+    narrow run, the fused key switch) and the integer kernels only for the 62-bit extension rows and the scalers."""
+    import ref_params
+    par = ref_params.params(fhe, 8192)
+    ctx = par.context_at_level(0)
+    kk = ctx.synth_uniform(5, 0, 8, 2 * ctx.nmoduli, 1)[0].reshape(ctx.nmoduli, 2, ctx.nmoduli, ctx.degree)
+    rk = fhe.RelinearizationKey(fhe.KeySwitchingKey(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous()))
+    m = fhe.Multiplicator.default(par, rk, 0)
+    a, b = ctx.synth_uniform(5, 0, 0, 2, 256), ctx.synth_uniform(5, 0, 2, 2, 256)
+    want = m.multiply(a, b).clone()
+    fhe.prof_reset()
+    fhe.prof_enable(True)
+    got = m.multiply(a, b)
+    fhe.prof_enable(False)
+    labels = set(fhe.prof_report())
+    assert {"ntt_inv_f64", "ntt_fwd_f64", "tensor_intt_f64", "key_switch_fused_f64"} <= labels, labels
+    assert "key_switch_fused" not in labels and "tensor_intt_narrow" not in labels and "ntt_inv" not in labels, labels
+    import torch
+    assert torch.equal(got, want)
+    fhe.set_f64(False)
+    try:
+        assert torch.equal(m.multiply(a, b), want)
+    finally:
+        fhe.set_f64(True)

@@ -672,6 +672,273 @@ pub(crate) fn hip_error(e: fhe_math_hip::HipError) -> Error {
 ]
 
 
+# New files (patches 17 / 18, round 6): integration tests that run the native path and the engine in ONE process
+# (fhe_math_hip::with_native) and compare them bit for bit -- public API only, behind the `hip` feature.
+FHE_MATH_PARITY_TEST = r'''//! Native-versus-engine parity of `fhe-math`, inside ONE process: every value is computed twice -- once through this
+//! crate's own CPU code (`fhe_math_hip::with_native`), once through the `hip` feature's forwarding to libfhe_hip.so --
+//! and compared bit for bit.  This is the test that pins, against fhe.rs itself, what no other check in the engine's
+//! repository can: the NTT tables (psi is drawn from a seeded ChaCha8 stream here and re-derived by the engine when a
+//! context is built WITHOUT host tables), the seeded sampler behind `Poly::random_from_seed`, and the RNS scaler.
+//!
+//!     cargo test -p fhe-math --features hip --test hip_parity -- --test-threads 1
+//!
+//! Needs an AMD GPU and libfhe_hip.so (FHE_HIP_LIB_DIR).  Skips (passes vacuously, saying so) when no device is visible.
+#![cfg(feature = "hip")]
+
+use fhe_math::rns::ScalingFactor;
+use fhe_math::rq::{scaler::Scaler, Context, Ntt, Poly, PowerBasis, SubstitutionExponent};
+use num_bigint::BigUint;
+use rand::rng;
+use std::sync::Arc;
+
+/// The moduli of `BfvParameters::default_parameters_128(20)` (36 ... 49 bits: the engine's FP64 kernels) and a
+/// 62-bit basis (its integer kernels).
+const BASES: &[(usize, &[u64])] = &[
+    (4096, &[0xffffee001, 0xffffc4001, 0x1ffffe0001]),
+    (8192, &[0x7fffffd8001, 0x7fffffc8001, 0xfffffffc001, 0xffffff6c001, 0xfffffebc001]),
+    (16384, &[0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001, 0x1ffffffee8001,
+              0x1ffffffea0001, 0x1ffffffe88001, 0x1ffffffe48001]),
+    (8192, &[4611686018326724609, 4611686018309947393, 4611686018282684417, 4611686018257518593]),
+];
+
+fn device_present() -> bool {
+    if fhe_math_hip::enabled() {
+        return true;
+    }
+    eprintln!("hip_parity: no HIP device visible (or FHE_HIP_DISABLE set) -- nothing compared");
+    false
+}
+
+/// `f` on the native path and on the engine, with the FP64 kernels on and off: three results that must be equal.
+fn both<T: PartialEq + std::fmt::Debug>(what: &str, f: impl Fn() -> T) {
+    let native = fhe_math_hip::with_native(&f);
+    for f64_kernels in [true, false] {
+        fhe_math_hip::set_f64_kernels(f64_kernels);
+        assert!(!fhe_math_hip::native_forced());
+        assert_eq!(f(), native, "{what}: engine (f64 kernels: {f64_kernels}) differs from the native path");
+    }
+    fhe_math_hip::set_f64_kernels(true);
+}
+
+#[test]
+fn ntt_round_trips_and_psi() {
+    if !device_present() {
+        return;
+    }
+    for (degree, moduli) in BASES {
+        let ctx = Context::new_arc(moduli, *degree).unwrap();
+        let p = Poly::<PowerBasis>::random(&ctx, &mut rng());
+        // forward transform: the engine uses THIS context's tables (uploaded by `hip_handle`), so equality here pins the
+        // butterflies; the table-free context below pins psi itself
+        both("PowerBasis -> Ntt", || p.clone().into_ntt());
+        let q = p.clone().into_ntt();
+        both("Ntt -> PowerBasis", || q.clone().into_power_basis());
+        // psi: a device context built WITHOUT host tables derives its own psi (the engine's restatement of
+        // NttOperator::new); its forward transform must equal this crate's
+        let own = fhe_math_hip::HipCtx::new(fhe_math_hip::default_device(), *degree, moduli, None).unwrap();
+        let mut words = p.coefficients().as_slice().unwrap().to_vec();
+        own.ntt_forward(&mut words).unwrap();
+        let native = fhe_math_hip::with_native(|| p.clone().into_ntt());
+        assert_eq!(words.as_slice(), native.coefficients().as_slice().unwrap(), "psi / table derivation, degree {degree}");
+    }
+}
+
+#[test]
+fn element_wise_operators() {
+    if !device_present() {
+        return;
+    }
+    for (degree, moduli) in BASES {
+        let ctx = Context::new_arc(moduli, *degree).unwrap();
+        let a = Poly::<Ntt>::random(&ctx, &mut rng());
+        let b = Poly::<Ntt>::random(&ctx, &mut rng());
+        both("+=", || { let mut x = a.clone(); x += &b; x });
+        both("-=", || { let mut x = a.clone(); x -= &b; x });
+        both("*=", || { let mut x = a.clone(); x *= &b; x });
+        both("neg", || -&a);
+    }
+}
+
+#[test]
+fn substitute_and_switch_down() {
+    if !device_present() {
+        return;
+    }
+    for (degree, moduli) in BASES {
+        let ctx = Context::new_arc(moduli, *degree).unwrap();
+        let p = Poly::<PowerBasis>::random(&ctx, &mut rng());
+        let q = p.clone().into_ntt();
+        for e in [3usize, 2 * degree - 1, degree + 1] {
+            let exp = SubstitutionExponent::new(&ctx, e).unwrap();
+            both("substitute (PowerBasis)", || p.substitute(&exp).unwrap());
+            both("substitute (Ntt)", || q.substitute(&exp).unwrap());
+        }
+        both("switch_down", || { let mut x = p.clone(); x.switch_down().unwrap(); x });
+    }
+}
+
+#[test]
+fn scaler_scale() {
+    if !device_present() {
+        return;
+    }
+    for (degree, moduli) in BASES {
+        let from = Context::new_arc(moduli, *degree).unwrap();
+        let to = Context::new_arc(&moduli[..moduli.len() - 1], *degree).unwrap();
+        let p = Poly::<PowerBasis>::random(&from, &mut rng());
+        for (num, den) in [(1u64, 1u64), (1153, 46116860181065), (3, 7)] {
+            let scaler = Scaler::new(&from, &to, ScalingFactor::new(&BigUint::from(num), &BigUint::from(den))).unwrap();
+            both("Scaler::scale (PowerBasis)", || p.scale(&scaler).unwrap());
+            let q = p.clone().into_ntt();
+            both("Scaler::scale (Ntt)", || q.scale(&scaler).unwrap());
+        }
+    }
+}
+
+#[test]
+fn random_from_seed_is_the_reference_sampler() {
+    // The engine expands seeded polynomials on the device (SHA-256 -> ChaCha8 -> rejection sampling); this compares its
+    // stream with rand_chacha's, i.e. with `Poly::random_from_seed` on the native path.
+    if !device_present() {
+        return;
+    }
+    for (degree, moduli) in BASES {
+        let ctx = Context::new_arc(moduli, *degree).unwrap();
+        for s in 0u8..4 {
+            let seed = [s.wrapping_mul(37).wrapping_add(1); 32];
+            both("random_from_seed", || Poly::<Ntt>::random_from_seed(&ctx, seed));
+        }
+    }
+    let _ = Arc::new(());
+}
+'''
+
+FHE_PARITY_TEST = r'''//! Native-versus-engine parity of `fhe` (BFV), inside ONE process: every hot-path Criterion ID of benches/bfv.rs
+//! (relinearize, rotate_rows, rotate_columns, inner_sum, expand_*, mul, square, mul_then_relinearize, mul_and_relin,
+//! mul_and_relin_2), `Ciphertext::switch_down` / `switch_to_level`, on `default_parameters_128(20)` and on a six-modulus
+//! 62-bit set -- computed once through this crate's own CPU code (`fhe_math_hip::with_native`) and once through the `hip`
+//! feature's forwarding to libfhe_hip.so (FP64 kernels on and off), compared bit for bit.
+//!
+//!     cargo test -p fhe --features hip --test hip_parity -- --test-threads 1
+//!
+//! Needs an AMD GPU and libfhe_hip.so (FHE_HIP_LIB_DIR).  Skips (passes vacuously, saying so) when no device is visible.
+#![cfg(feature = "hip")]
+
+use fhe::bfv::{
+    BfvParameters, BfvParametersBuilder, Ciphertext, Encoding, EvaluationKeyBuilder, Multiplicator, Plaintext,
+    RelinearizationKey, SecretKey,
+};
+use fhe_math::rns::{RnsContext, ScalingFactor};
+use fhe_math::zq::primes::generate_prime;
+use fhe_traits::{FheEncoder, FheEncrypter};
+use num_bigint::BigUint;
+use rand::rng;
+use std::sync::Arc;
+
+fn device_present() -> bool {
+    if fhe_math_hip::enabled() {
+        return true;
+    }
+    eprintln!("hip_parity: no HIP device visible (or FHE_HIP_DISABLE set) -- nothing compared");
+    false
+}
+
+fn parameter_sets() -> Vec<Arc<BfvParameters>> {
+    let mut sets: Vec<Arc<BfvParameters>> = BfvParameters::default_parameters_128(20).unwrap().collect();
+    sets.retain(|p| p.moduli().len() > 1 && p.degree() <= 16384);
+    sets.push(BfvParametersBuilder::new().set_degree(16).set_plaintext_modulus(1153).set_moduli_sizes(&[62usize; 6]).build_arc().unwrap());
+    sets
+}
+
+/// `f` on the native path and on the engine, with the FP64 kernels on and off: three results that must be equal.
+fn both<T: PartialEq + std::fmt::Debug>(what: &str, f: impl Fn() -> T) -> T {
+    let native = fhe_math_hip::with_native(&f);
+    for f64_kernels in [true, false] {
+        fhe_math_hip::set_f64_kernels(f64_kernels);
+        assert_eq!(f(), native, "{what}: engine (f64 kernels: {f64_kernels}) differs from the native path");
+    }
+    fhe_math_hip::set_f64_kernels(true);
+    native
+}
+
+#[test]
+fn every_bench_id_matches_the_native_path() {
+    if !device_present() {
+        return;
+    }
+    let mut rng = rng();
+    for par in parameter_sets() {
+        let tag = format!("n={}/moduli={}", par.degree(), par.moduli().len());
+        // keys and inputs are made ONCE (on the native path: key generation is out of the engine's scope)
+        let (sk, rk, ek, c1, c2) = fhe_math_hip::with_native(|| {
+            let sk = SecretKey::random(&par, &mut rng);
+            let rk = RelinearizationKey::new(&sk, &mut rng).unwrap();
+            let ek = EvaluationKeyBuilder::new(&sk).unwrap()
+                .enable_inner_sum().unwrap()
+                .enable_row_rotation().unwrap()
+                .enable_column_rotation(1).unwrap()
+                .enable_expansion(4usize.min(par.degree().ilog2() as usize)).unwrap()
+                .build(&mut rng).unwrap();
+            let pt1 = Plaintext::try_encode(&(1..16u64).collect::<Vec<u64>>(), Encoding::simd(), &par).unwrap();
+            let pt2 = Plaintext::try_encode(&(3..39u64).map(|v| v % 16).collect::<Vec<u64>>(), Encoding::simd(), &par).unwrap();
+            let c1: Ciphertext = sk.try_encrypt(&pt1, &mut rng).unwrap();
+            let c2: Ciphertext = sk.try_encrypt(&pt2, &mut rng).unwrap();
+            (sk, rk, ek, c1, c2)
+        });
+        let _ = &sk;
+        both(&format!("{tag} add_ct"), || &c1 + &c2);
+        both(&format!("{tag} sub_ct"), || &c1 - &c2);
+        both(&format!("{tag} neg"), || -&c1);
+        let c3 = both(&format!("{tag} mul"), || &c1 * &c2);
+        both(&format!("{tag} square"), || &c1 * &c1);
+        both(&format!("{tag} relinearize"), || { let mut x = c3.clone(); rk.relinearizes(&mut x).unwrap(); x });
+        both(&format!("{tag} mul_then_relinearize"), || { let mut x = &c1 * &c2; rk.relinearizes(&mut x).unwrap(); x });
+        both(&format!("{tag} rotate_rows"), || ek.rotates_rows(&c1).unwrap());
+        both(&format!("{tag} rotate_columns"), || ek.rotates_columns_by(&c1, 1).unwrap());
+        both(&format!("{tag} inner_sum"), || ek.computes_inner_sum(&c1).unwrap());
+        for i in 1..=4usize.min(par.degree().ilog2() as usize) {
+            both(&format!("{tag} expand_{i}"), || ek.expands(&c1, 1 << i).unwrap());
+        }
+        let multiplicator = Multiplicator::default(&rk).unwrap();
+        both(&format!("{tag} mul_and_relin"), || multiplicator.multiply(&c1, &c2).unwrap());
+        // benches/bfv.rs:257-286: the second strategy
+        let q = par.moduli_sizes().iter().sum::<usize>();
+        let nmoduli = q.div_ceil(62);
+        let mut extended_basis = par.moduli().to_vec();
+        let mut upper_bound = u64::MAX >> 2;
+        while extended_basis.len() != nmoduli + par.moduli().len() {
+            upper_bound = generate_prime(62, 2 * par.degree() as u64, upper_bound).unwrap();
+            if !extended_basis.contains(&upper_bound) {
+                extended_basis.push(upper_bound)
+            }
+        }
+        let rns_q = RnsContext::new(&extended_basis[..par.moduli().len()]).unwrap();
+        let rns_p = RnsContext::new(&extended_basis[par.moduli().len()..]).unwrap();
+        let mut second = Multiplicator::new(
+            ScalingFactor::one(),
+            ScalingFactor::new(rns_p.modulus(), rns_q.modulus()),
+            &extended_basis,
+            ScalingFactor::new(&BigUint::from(par.plaintext()), rns_p.modulus()),
+            &par,
+        ).unwrap();
+        second.enable_relinearization(&rk).unwrap();
+        both(&format!("{tag} mul_and_relin_2"), || second.multiply(&c1, &c2).unwrap());
+        // modulus switching (Ciphertext::switch_down, switch_to_level) and the multiplicator that ends with it
+        both(&format!("{tag} switch_down"), || { let mut x = c1.clone(); x.switch_down().unwrap(); x });
+        both(&format!("{tag} switch_to_level"), || { let mut x = c1.clone(); x.switch_to_level(x.max_switchable_level()).unwrap(); x });
+        let mut switching = Multiplicator::default(&rk).unwrap();
+        switching.enable_mod_switching().unwrap();
+        both(&format!("{tag} mul_and_relin + mod switch"), || switching.multiply(&c1, &c2).unwrap());
+    }
+}
+'''
+
+NEW_FILES = [
+    ("17-fhe-math-hip-parity-tests", "crates/fhe-math/tests/hip_parity.rs", FHE_MATH_PARITY_TEST),
+    ("18-fhe-hip-parity-tests", "crates/fhe/tests/hip_parity.rs", FHE_PARITY_TEST),
+]
+
+
 def apply(text, edits, path):
     lines = text.split("\n")
     for edit in edits:
@@ -713,6 +980,13 @@ def main():
         diff = difflib.unified_diff(src.split("\n"), dst.split("\n"), "a/" + rel, "b/" + rel, n=1, lineterm="")
         open(os.path.join(OUT, name + ".patch"), "w").write("\n".join(diff) + "\n")
         print(name, "ok")
+    for name, rel, content in NEW_FILES:
+        if os.path.exists(os.path.join(REF, rel)):
+            raise SystemExit(f"{rel} exists in the reference: a new-file patch would overwrite it")
+        body = content.rstrip("\n").split("\n")
+        diff = ["--- /dev/null", "+++ b/" + rel, "@@ -0,0 +1,%d @@" % len(body)] + ["+" + l for l in body]
+        open(os.path.join(OUT, name + ".patch"), "w").write("\n".join(diff) + "\n")
+        print(name, "ok (new file)")
 
 
 if __name__ == "__main__":

@@ -54,8 +54,18 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         auto to_f = [](u64 v) { return bits_of_f64(f64_from_u64(v)); };
         auto to_c = [&](u64 v) { return to_u64_canonical(f64_of_bits(v), pf); };
         if constexpr (!INVERSE) {
-            ntt_fwd_lds<LOGM, T, GMAX, true, true, -F64>(lds, twr, nsub + sub, pmf, tid, [&](uint32_t i, uint32_t) { return to_f(load_last<(FHE_PIPE_NT & 2) != 0>(src + i)); });
-            lds_to_tile<CH, M, T>(lds, dst, tid, to_c);
+            auto ld = [&](uint32_t i, uint32_t) { return to_f(load_last<(FHE_PIPE_NT & 2) != 0>(src + i)); };
+            if constexpr (FHE_FWD_DIRECT_STORE && plan_np(LOGM, GMAX) > 1) {
+                constexpr int GL = fwd_plan_g<LOGM, GMAX, plan_np(LOGM, GMAX) - 1, false>();
+                ntt_fwd_lds<LOGM, T, GMAX, true, true, -F64, decltype(ld), false, 1>(lds, twr, nsub + sub, pmf, tid, ld, 0, [&](uint32_t base, const u64 (&x)[1 << GL]) {
+                    u64x2 *d2 = reinterpret_cast<u64x2 *>(dst + base);
+#pragma unroll
+                    for (int e = 0; e < (1 << GL); e += 2) d2[e / 2] = u64x2{to_c(x[e]), to_c(x[e + 1])};
+                });
+            } else {
+                ntt_fwd_lds<LOGM, T, GMAX, true, true, -F64>(lds, twr, nsub + sub, pmf, tid, ld);
+                lds_to_tile<CH, M, T>(lds, dst, tid, to_c);
+            }
         } else {
             InvTwFirst<LOGM, T> tw0;
             inv_tw_load(tw0, twr, logn, sub, tid);
@@ -73,6 +83,21 @@ __global__ void __launch_bounds__(ntt_threads_c(LOGM), 4)
         }
     } else if constexpr (!INVERSE) {
         // the first pass reads its groups straight from global memory (no tile staging)
+        if constexpr (FHE_FWD_DIRECT_STORE && plan_np(LOGM, GMAX) > 1) {
+            constexpr int GL = fwd_plan_g<LOGM, GMAX, plan_np(LOGM, GMAX) - 1, false>();
+            auto ld = [&](uint32_t i, uint32_t) { return load_last<(FHE_PIPE_NT & 2) != 0>(src + i); };
+            const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;
+            auto canon = [&](u64 v) {
+                if constexpr (NARROW) v = csub_n(csub_n(v, p8, np8), p4, np4);   // < 16p -> < 4p
+                return csub_n(csub_n(v, p2, pm.np2), p, pm.np);
+            };
+            ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? FWD_B0 : 0), decltype(ld), false, 1>(lds, twr, nsub + sub, pm, tid, ld, 0, [&](uint32_t base, const u64 (&x)[1 << GL]) {
+                u64x2 *d2 = reinterpret_cast<u64x2 *>(dst + base);
+#pragma unroll
+                for (int e = 0; e < (1 << GL); e += 2) d2[e / 2] = u64x2{canon(x[e]), canon(x[e + 1])};
+            });
+            return;
+        }
         ntt_fwd_lds<LOGM, T, GMAX, true, true, (NARROW ? FWD_B0 : 0)>(lds, twr, nsub + sub, pm, tid, [&](uint32_t i, uint32_t) { return load_last<(FHE_PIPE_NT & 2) != 0>(src + i); });
         if constexpr (NARROW) {  // < 16p -> canonical
             const u64 p4 = p2 << 1, p8 = p2 << 2, np4 = pm.np2 << 1, np8 = pm.np2 << 2;

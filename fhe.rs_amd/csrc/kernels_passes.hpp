@@ -79,11 +79,16 @@ __device__ __forceinline__ void fwd_tw_load(FwdTw<G, LOGM, S0, T> &tw_regs, cons
 // (canonical residues, or digit rows of another modulus of the launch); values leave below f64_fwd_out_bound().
 // NT > 1: the same pass on NT tiles that lie `tile_words` apart in LDS (the key switch transforms two digits
 // under one modulus at once): addresses and twiddles are formed once and serve every tile.
-template <int G, int LOGM, int S0, int T, bool PRE, int NARROW = 0, class Src = NoSrc, int NT = 1, bool WLX = false>
+// `Dst` (last pass only, lab knob FHE_FWD_DIRECT_STORE): a functor (first index, x[]) that takes the group's 2^G
+// CONSECUTIVE results straight from the registers (the stride-1 pass: lo_bits == 0) instead of the tile.
+template <int G, int LOGM, int S0, int T, bool PRE, int NARROW = 0, class Src = NoSrc, int NT = 1, bool WLX = false,
+          class Dst = NoSrc>
 __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
                                          uint32_t tid, const FwdTw<G, LOGM, S0, T> &tw_regs, Src src = Src{},
-                                         uint32_t tile_words = 0) {
+                                         uint32_t tile_words = 0, Dst dst = Dst{}) {
     constexpr bool DIRECT = !std::is_same<Src, NoSrc>::value;
+    constexpr bool DIRECT_OUT = !std::is_same<Dst, NoSrc>::value;
+    static_assert(!DIRECT_OUT || (S0 + G == LOGM && NT == 1), "direct stores: the last (stride-1) pass of one tile");
     constexpr uint32_t R = 1u << G;
     constexpr uint32_t lo_bits = LOGM - S0 - G;
     constexpr uint32_t ngroups = 1u << (LOGM - G);
@@ -147,8 +152,12 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
                 }
             }
         }
+        if constexpr (DIRECT_OUT) {
+            dst(base, x);
+        } else {
 #pragma unroll
         for (uint32_t e = 0; e < R; e++) g[padi(e << lo_bits)] = x[e];
+        }
         if constexpr (NT > 1) sched_fence();   // one tile's group in registers at a time
         }
     }
@@ -200,13 +209,17 @@ constexpr bool fwd_wl_after(int logm, int gm, bool late, int pass) {
 // TWPF: fetch the next pass's per-lane twiddles before the barrier (costs their registers across
 // it: the key-switch kernels, which also hold accumulators, leave it off).
 // FSYNC = false: the caller places the barrier after the last pass itself (it has loads to issue first).
-template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, int NARROW, int PASS, int S0, bool LATE, int NT, class W, class Src>
+template <int LOGM, int T, int GM, bool TWPF, bool FSYNC, int NARROW, int PASS, int S0, bool LATE, int NT, class W, class Src,
+          class Dst = NoSrc>
 __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
-                                                uint32_t tid, const W &tw_regs, Src src, uint32_t tile_words) {
+                                                uint32_t tid, const W &tw_regs, Src src, uint32_t tile_words, Dst dst = Dst{}) {
     constexpr int G = fwd_plan_g<LOGM, GM, PASS, LATE>();
+    constexpr bool OUT = !std::is_same<Dst, NoSrc>::value && PASS + 1 == fwd_np(LOGM, GM);   // this pass stores to `dst`
     constexpr bool WLX = fwd_wl_after(LOGM, GM, LATE, PASS) || fwd_wl_after(LOGM, GM, LATE, PASS - 1);
     static_assert(!WLX || T % 64 == 0, "wave-local exchanges need whole 64-lane waves");
-    if constexpr (PASS == 0)
+    if constexpr (OUT && PASS != 0)
+        fwd_pass<G, LOGM, S0, T, TWPF, NARROW, NoSrc, NT, WLX, Dst>(lds, tw, kbase, pm, tid, tw_regs, NoSrc{}, tile_words, dst);
+    else if constexpr (PASS == 0)
         fwd_pass<G, LOGM, S0, T, TWPF, NARROW, Src, NT, WLX>(lds, tw, kbase, pm, tid, tw_regs, src, tile_words);   // (Src != NoSrc: reads `src`, not LDS)
     else
         fwd_pass<G, LOGM, S0, T, TWPF, NARROW, NoSrc, NT, WLX>(lds, tw, kbase, pm, tid, tw_regs, NoSrc{}, tile_words);
@@ -223,19 +236,20 @@ __device__ __forceinline__ void ntt_fwd_lds_rec(u64 *lds, const u64x2 *__restric
             FHE_BARRIER();
         FHE_TS(9 + 2 * PASS);
         ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, PASS + 1, S0 + G, LATE, NT>(lds, tw, kbase, pm, tid, next, NoSrc{},
-                                                                                      tile_words);
+                                                                                      tile_words, dst);
     } else {
-        if constexpr (FSYNC) FHE_BARRIER();
+        if constexpr (FSYNC && !OUT) FHE_BARRIER();
     }
 }
 template <int LOGM, int T, int GM = GMAX, bool TWPF = true, bool FSYNC = true, int NARROW = 0, class Src = NoSrc,
-          bool LATE = false, int NT = 1>
+          bool LATE = false, int NT = 1, class Dst = NoSrc>
 __device__ __forceinline__ void ntt_fwd_lds(u64 *lds, const u64x2 *__restrict__ tw, uint32_t kbase, const PM pm,
-                                            uint32_t tid, Src src = Src{}, uint32_t tile_words = 0) {
+                                            uint32_t tid, Src src = Src{}, uint32_t tile_words = 0, Dst dst = Dst{}) {
     constexpr int G = fwd_plan_g<LOGM, GM, 0, LATE>();
+    static_assert(std::is_same<Dst, NoSrc>::value || fwd_np(LOGM, GM) > 1, "direct stores need a pass of their own");
     FwdTw<G, LOGM, 0, T> first;
     if constexpr (TWPF) fwd_tw_load(first, tw, kbase, tid);
-    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, 0, 0, LATE, NT>(lds, tw, kbase, pm, tid, first, src, tile_words);
+    ntt_fwd_lds_rec<LOGM, T, GM, TWPF, FSYNC, NARROW, 0, 0, LATE, NT>(lds, tw, kbase, pm, tid, first, src, tile_words, dst);
 }
 
 // ---------------------------------------------------------------- inverse passes ----

@@ -14,7 +14,7 @@
     defined(FHE_KS_EXPERIMENTS) || defined(FHE_PHASE_TIMING) || defined(FHE_LDS_PAD) || defined(FHE_NO_WAVE_SYNC) || \
     defined(FHE_DIAG_NO_SGPR_ASM) || defined(FHE_KS_HALF13) || defined(FHE_KS_SPLIT_XCD) || defined(FHE_STREAM_NT) || \
     defined(FHE_MUL_DIRFLAGS) || defined(FHE_MUL_MERGED_EXT) || defined(FHE_PIPE_NT) || \
-    defined(FHE_KS_HALF15)
+    defined(FHE_KS_HALF15) || defined(FHE_FWD_DIRECT_STORE)
 #error "kernel-variant macros are lab-only: add -DFHE_LAB (the release build pins every knob, see knobs.hpp)"
 #endif
 #endif
@@ -33,6 +33,12 @@
 // for v_add3_u32, so 4 + 1 of the former cost what 4 + 2 of the latter do; at N = 16384 the key switch spills (C3 -2.5 %).
 #ifndef FHE_MAD_CROSS
 #define FHE_MAD_CROSS 0
+#endif
+// Forward transform (ntt_kernel): the last (stride-1) pass stores its canonical results straight from the registers --
+// 2^G consecutive coefficients per thread, 16-byte stores at a 64-byte lane stride -- instead of one more trip through the
+// tile (LDS write, barrier, coalesced read-back).  Round 6 (VERDICT r05 #4a), measured: see profiles/r06_fwd_direct_store_ab.jsonl.
+#ifndef FHE_FWD_DIRECT_STORE
+#define FHE_FWD_DIRECT_STORE 0
 #endif
 // Narrow (< 2^60) butterflies take the Shoup quotient from three partial products (zq_dev.hpp).
 #ifndef FHE_APPROX_SHOUP

@@ -1527,6 +1527,24 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
             FHE_KS_F64_G(GMV, false, HR);                                                                              \
         }                                                                                                              \
     } while (0)
+#if defined(FHE_LAB)
+            if constexpr (LOGN == 13) {
+                // FHE_LAB_KS13_F64_T512 = 1: 512 threads x 16 coefficients, both accumulator sets in registers, tile-only LDS
+                // (two workgroups per CU), radix-8 passes while the twiddles are scalar and radix-4 after (124 VGPRs, no
+                // scratch; radix-8 throughout spills 52 B, radix-16 204 B) -- round 6 A/B, profiles/r06_ks13_f64_t512_ab.jsonl
+                static const int t512 = FHE_LAB_INT("KS13_F64_T512", 0);
+                if (t512 && !gal && hr == 5) {
+                    const size_t lds2 = k::lds_words(1u << LOGN) * sizeof(u64);
+                    const unsigned grid2 = (unsigned)(npolys * kc.L);
+                    allow_big_lds((k::ks_fused_kernel<LOGN, false, k::GM_MIXED, 512, true, 0, false, 5>), lds2);
+                    FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, k::GM_MIXED, 512, true, 0, false, 5>),
+                               dim3(grid2), dim3(512), lds2, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0f.p,
+                               k_.c0pf.p, k_.c1f.p, k_.c1pf.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
+                               k_.digit_arg(), xhat, xhat_stride, grid2, gal);
+                    return;
+                }
+            }
+#endif
             if (hr == 3) FHE_KS_F64(3);
             else if (hr == 4) FHE_KS_F64(4);
             else FHE_KS_F64(5);

@@ -60,13 +60,14 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
     constexpr int NS = 1 << G0;
     static_assert(G0 == 0 || (G0 <= 2 && !ks_acc1_in_lds_tt(LOGN, TT) && tile_chunks_c(LOGN, ks_threads_tt(LOGN, TT)) >= 2),
                   "the folded first stages are written for the register-accumulator form (N = 16384 tiles)");
-    static_assert(F64 == 0 || (RNS && G0 == 0 && TT == 0 && !NARROW && tile_chunks_c(LOGN, ks_threads_tt(LOGN, TT)) >= 1),
+    static_assert(F64 == 0 || (RNS && G0 == 0 && !NARROW && tile_chunks_c(LOGN, ks_threads_tt(LOGN, TT)) >= 1),
                   "the F64 instances: RNS digits, whole-row tiles");
     // F64 bounds (units: zq_f64.hpp).  The transform leaves values below VB; they are reduced before the products when that
     // buys accumulator room (HR = 3, 4); a term is then below PB, the caller's own Ntt row (canonical) gives one below
     // POWN, and F64_CAP digits fit an accumulator together with a canonical addend before it must be reduced.
     constexpr int F64_VB = F64 ? f64_fwd_out_bound(LOGN, F64 ? F64 : 3) : 0;
-    constexpr bool F64_REDV = F64 > 0 && F64 < 5;
+    // (reduce the transformed values first only when the accumulators would otherwise hold fewer than sixteen terms)
+    constexpr bool F64_REDV = F64 > 0 && (f64_limit(F64 ? F64 : 3) - 2 * F64_ONE - F64_REDUCED) / f64_product_bound(F64_VB, F64 ? F64 : 3) < 16;
     constexpr int F64_PB = F64 ? f64_product_bound(F64_REDV ? F64_REDUCED : F64_VB, F64 ? F64 : 3) : 1;
     constexpr int F64_POWN = F64 ? f64_product_bound(F64_ONE, F64 ? F64 : 3) : 1;
     constexpr int F64_CAP = F64 ? (f64_limit(F64 ? F64 : 3) - F64_ONE - F64_POWN - F64_REDUCED) / F64_PB : 1;

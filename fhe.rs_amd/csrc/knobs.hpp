@@ -36,7 +36,10 @@
 #endif
 // Forward transform (ntt_kernel): the last (stride-1) pass stores its canonical results straight from the registers --
 // 2^G consecutive coefficients per thread, 16-byte stores at a 64-byte lane stride -- instead of one more trip through the
-// tile (LDS write, barrier, coalesced read-back).  Round 6 (VERDICT r05 #4a), measured: see profiles/r06_fwd_direct_store_ab.jsonl.
+// tile (LDS write, barrier, coalesced read-back).  Round 6 (VERDICT r05 #4a), measured (profiles/r06_fwd_direct_store_ab_rejected.jsonl, same box, alternating lab builds): 60-bit
+// rows 0.3594 -> 0.3661 ms per 8,192 row transforms (+1.9 %), 62-bit rows unchanged, the F64 instances 0.334 -> 0.375 ms (+12 %),
+// C2 multiply -0.2 %: the 64-byte lane stride makes four partial-line stores of what the tile read-back writes as one full line
+// per lane pair; the saved LDS round trip does not pay for it.  Off.
 #ifndef FHE_FWD_DIRECT_STORE
 #define FHE_FWD_DIRECT_STORE 0
 #endif

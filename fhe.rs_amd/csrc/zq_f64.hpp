@@ -93,11 +93,16 @@ FHE_HD double mulmod2_f64(double a, double b, const PF &m) {
 }
 // |x| < 2^52 -> |r| <= 0.5 p (1 + 2^-40)
 FHE_HD double reduce_f64(double x, const PF &m) { return f64_fma(-f64_rint(x * m.ip), m.p, x); }
-// any representative with |x| < 2^52 -> the canonical residue in [0, p) as a u64 word
+// any representative (|x| < 2^53) -> the canonical residue in [0, p) as a u64 word.  reduce_f64 leaves |r| <= 0.5 p + 8
+// (the quotient estimate x * (1/p) is within |x / p| 2^-52 of the true quotient -- a few ulps more if 1/p itself is not
+// correctly rounded -- and r = x - q p is exact), so ONE conditional add of p makes it canonical: r < 0 gives r + p in
+// [0.5 p - 8, p), r >= 0 is at most 0.5 p + 8 < p.
 FHE_HD u64 to_u64_canonical(double x, const PF &m) {
-    double r = reduce_f64(x, m);          // |r| <= ~0.5 p
-    r = r < 0.0 ? r + m.p : r;            // [0, p]: r == p cannot happen (r + p < p when r < 0), r == -0.0 stays 0
-    r = r >= m.p ? r - m.p : r;           // (the reduction's own rounding slack: r slightly above 0.5 p is still below p)
+    double r = reduce_f64(x, m);
+    r = r < 0.0 ? r + m.p : r;            // (-0.0 stays 0)
+#if defined(FHE_HOST_EMULATION)
+    if (!(r >= 0.0 && r < m.p)) __builtin_trap();
+#endif
     return f64_to_u64(r);
 }
 

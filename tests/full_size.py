@@ -235,6 +235,13 @@ def random_shape(idx, big=False):
     (N = 32768 / 65536, up to five moduli, up to three ciphertexts) -- the sub-block / part forms of every kernel."""
     import random
     rng = random.Random(0xC0FFEE + idx)
+    if big == "f64":
+        # round 6: shapes that take the FP64-FMA kernels (whole rows of 4096 ... 16384 points, every modulus below 2^50),
+        # widths from VERDICT r05 #3's list and the launch-class boundaries (48 / 49 / 50 bits), up to twelve digits
+        n = 1 << rng.randrange(12, 15)
+        L = rng.randrange(1, 13 if n == 4096 else 8)
+        sizes = [rng.choice([27, 30, 36, 40, 43, 44, 47, 48, 49, 50]) for _ in range(L)]
+        return n, sizes, rng.randrange(1, 5)
     if big:
         n = 1 << rng.randrange(15, 17)
         L = rng.randrange(1, 6)

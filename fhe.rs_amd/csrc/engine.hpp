@@ -1531,7 +1531,10 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
             if constexpr (LOGN == 13) {
                 // FHE_LAB_KS13_F64_T512 = 1: 512 threads x 16 coefficients, both accumulator sets in registers, tile-only LDS
                 // (two workgroups per CU), radix-8 passes while the twiddles are scalar and radix-4 after (124 VGPRs, no
-                // scratch; radix-8 throughout spills 52 B, radix-16 204 B) -- round 6 A/B, profiles/r06_ks13_f64_t512_ab.jsonl
+                // scratch; radix-8 throughout spills 52 B, radix-16 204 B).  Round 6 A/B (profiles/r06_ks13_f64_t512_ab_rejected.jsonl, one lab
+                // build, alternating processes, same digest): relinearise of 1,024 1.149 -> 1.176 ms, of 256 0.305 -> 0.314 -- slower,
+                // as the integer form of this cut was in round 3: two more passes and their LDS traffic cost what the second
+                // resident workgroup hides.  Lab only
                 static const int t512 = FHE_LAB_INT("KS13_F64_T512", 0);
                 if (t512 && !gal && hr == 5) {
                     const size_t lds2 = k::lds_words(1u << LOGN) * sizeof(u64);

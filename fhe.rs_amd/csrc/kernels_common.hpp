@@ -115,8 +115,11 @@ FHE_HD uint32_t galois_src_index(uint32_t d, uint32_t e, uint32_t logn) {
 // patterns; built, bit-exact, and measured in a drift-cancelling ABBA run: every kernel within +-1 %
 // (profiles/r02_lds_pad_ab.txt).  LDS time is not on these kernels' critical path; this layout (2 KiB smaller per
 // tile) stays and the alternative is not carried in the source.
-FHE_HD uint32_t padi(uint32_t i) { return i + (i >> 4); }
-FHE_HD uint32_t lds_words(uint32_t n) { return n + (n >> 4) + 2; }
+// Round 6: with the F64 instances the arithmetic of a pass shrank by a third and LDS time came closer to the critical path, so
+// the alternative layout is back as a lab knob (FHE_LDS_PAD=1: i + 3 (i >> 5); per-element offsets of a group stay additive,
+// (base mod 32) + (offset mod 32) < 32 by the same argument as below).  Measured again: profiles/r06_lds_pad_ab.jsonl.
+FHE_HD uint32_t padi(uint32_t i) { return FHE_LDS_PAD ? i + 3 * (i >> 5) : i + (i >> 4); }
+FHE_HD uint32_t lds_words(uint32_t n) { return FHE_LDS_PAD ? n + 3 * (n >> 5) + 4 : n + (n >> 4) + 2; }
 
 constexpr int GMAX = 4;  // radix-16: up to four butterfly stages per LDS round trip
 

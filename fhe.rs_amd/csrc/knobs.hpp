@@ -43,6 +43,11 @@
 #ifndef FHE_FWD_DIRECT_STORE
 #define FHE_FWD_DIRECT_STORE 0
 #endif
+// LDS tile padding (kernels_common.hpp padi): 0 = one extra word every 16 (two-way conflicted in every pass pattern, 2 KiB
+// smaller per tile), 1 = three extra words every 32 (conflict-free in seven of the nine patterns, tools/lds_pad_search.py).
+#ifndef FHE_LDS_PAD
+#define FHE_LDS_PAD 0
+#endif
 // Narrow (< 2^60) butterflies take the Shoup quotient from three partial products (zq_dev.hpp).
 #ifndef FHE_APPROX_SHOUP
 #define FHE_APPROX_SHOUP 1

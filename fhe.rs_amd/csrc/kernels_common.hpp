@@ -117,7 +117,8 @@ FHE_HD uint32_t galois_src_index(uint32_t d, uint32_t e, uint32_t logn) {
 // tile) stays and the alternative is not carried in the source.
 // Round 6: with the F64 instances the arithmetic of a pass shrank by a third and LDS time came closer to the critical path, so
 // the alternative layout is back as a lab knob (FHE_LDS_PAD=1: i + 3 (i >> 5); per-element offsets of a group stay additive,
-// (base mod 32) + (offset mod 32) < 32 by the same argument as below).  Measured again: profiles/r06_lds_pad_ab.jsonl.
+// (base mod 32) + (offset mod 32) < 32 by the same argument as below).  Measured again (profiles/r06_lds_pad_ab_rejected.jsonl, two lab builds alternating three times, same digest): transforms on 60-bit / 62-bit / F64
+// rows, the stock and C2 multiplies, C3 relinearise -- every cell within -2.9 ... +2.4 %, medians within 1 %: still not on the critical path.  Off.
 FHE_HD uint32_t padi(uint32_t i) { return FHE_LDS_PAD ? i + 3 * (i >> 5) : i + (i >> 4); }
 FHE_HD uint32_t lds_words(uint32_t n) { return FHE_LDS_PAD ? n + 3 * (n >> 5) + 4 : n + (n >> 4) + 2; }
 

@@ -381,8 +381,14 @@ def case_scaler_extend_and_constants_api(fhe, dev, n=16):
         assert err.code == -7
 
 
+PARAM_SIZES = None     # round 6: tests set this to run the parameter-set cases below on other modulus widths (the F64 kernels)
+
+
 def _params(fhe, nmod, n, dev_needed=True):
-    opar = obfv.BfvParameters.default_arc(nmod, n)
+    if PARAM_SIZES is not None:
+        opar = obfv.BfvParameters(n, 1153 if n <= 64 else fhe.generate_prime(20, 2 * n, (1 << 20) - 1), moduli_sizes=list(PARAM_SIZES)[:nmod])
+    else:
+        opar = obfv.BfvParameters.default_arc(nmod, n)
     par = fhe.BfvParameters(n, opar.plaintext, moduli=opar.moduli)
     return opar, par
 

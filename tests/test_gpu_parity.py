@@ -1062,3 +1062,48 @@ def test_f64_multiply_uses_every_f64_kernel(fhe):
         assert torch.equal(m.multiply(a, b), want)
     finally:
         fhe.set_f64(True)
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_f64_callers_match_the_integer_kernels(fhe, n):
+    """The callers either side of the path on an F64-eligible basis (the stock sets' moduli): RGSW external product, oblivious
+    expansion, inner sum, rotations by several steps and decryption run their transforms and key switches on the F64
+    instances; every output must equal, word for word, what the integer kernels give on the same inputs (those are tied
+    to the oracle by the small-size cases of this file and by the stock-set checks of tests/ref_params.py)."""
+    import torch
+    import ref_params
+    par = ref_params.params(fhe, n)
+    ctx = par.context_at_level(0)
+    L = ctx.nmoduli
+
+    def key(seed):
+        kk = ctx.synth_uniform(seed, 0, 8, 2 * L, 1)[0].reshape(L, 2, L, n)
+        return fhe.KeySwitchingKey(ctx, ctx, kk[:, 0].contiguous(), kk[:, 1].contiguous())
+    ksk, ksk2 = key(31), key(32)
+    ct = ctx.synth_uniform(31, 0, 0, 2, 24)
+    s_ntt = ctx.synth_uniform(31, 77, 0, 1, 1)[0, 0].contiguous()
+    seq, i = [], 1
+    while i < n // 2:
+        seq.append(pow(3, i, 2 * n))
+        i *= 2
+    seq.append(2 * n - 1)
+    levels = 4
+    ek = fhe.EvaluationKey(n, [fhe.GaloisKey(ksk, e) for e in set(seq + [(n >> lv) + 1 for lv in range(levels)])])
+    rgsw = fhe.RGSWCiphertext(ksk, ksk2)
+
+    def run():
+        return [rgsw.external_product(ct).clone(), ek.computes_inner_sum(ct).clone(), ek.expands(ct[:3].contiguous(), 1 << levels).clone(),
+                ek.rotates_columns_by(ct, 1).clone(), ek.rotates_rows(ct).clone(), par.decrypt(s_ntt, ct, 0).clone()]
+    fhe.prof_reset()
+    fhe.prof_enable(True)
+    got = run()
+    fhe.prof_enable(False)
+    labels = set(fhe.prof_report())
+    assert "ntt_inv_f64" in labels and ("key_switch_fused_f64" in labels or "ks_digit_ntt_f64" in labels), labels
+    fhe.set_f64(False)
+    try:
+        want = run()
+    finally:
+        fhe.set_f64(True)
+    for g, w, name in zip(got, want, ("rgsw", "inner_sum", "expand", "rotate_columns", "rotate_rows", "decrypt")):
+        assert torch.equal(g, w), (n, name)

@@ -1416,10 +1416,10 @@ struct Ksk {
     }
     uint32_t digit_arg() const { return (uint32_t)log_base | (lift_mode() << 8); }
     DevBuf<u64> c0, c0s, c1, c1s;  // [ndigits][Lk][N]
-    // Round 6: the key's F64 twins -- bit patterns of the doubles {k, k / q_j} -- when every key modulus is below 2^50
-    // and the digits are RNS rows (ksk_fill_f64; empty otherwise): what ks_fused_kernel's F64 instances read in place
-    // of (c0, c0s, c1, c1s).
-    DevBuf<u64> c0f, c0pf, c1f, c1pf;
+    // Round 6: the key words as doubles (bit patterns) when every key modulus is below 2^50 and the digits are RNS rows
+    // (ksk_fill_f64; empty otherwise): what ks_fused_kernel's F64 instances read in place of (c0, c0s, c1, c1s) -- 16 bytes
+    // per coefficient and digit instead of 32: their accumulate takes its quotient from h / p, so no k / q_j twin exists.
+    DevBuf<u64> c0f, c1f;
     // Execution options of this handle (fhe_ksk_set_mode; read once per call, like Mul's):
     //   mode      KS_AUTO: the engine picks per shape and launch (ks_use_unfused, key_switch_polys); KS_FUSED: ks_fused_kernel
     //             (rows larger than LDS: on 16384-point parts); KS_FUSED_SUB: rows larger than LDS on 8192-point sub-blocks
@@ -1439,23 +1439,16 @@ inline void ksk_fill_f64(Ksk &k_, const u64 *h0, const u64 *h1) {
     for (u64 q : kc.moduli)
         if (q >> 50) return;
     const size_t count = k_.ndigits * kc.L * kc.n;
-    std::vector<u64> f(count), pf(count);
-    auto fill = [&](const u64 *h, DevBuf<u64> &df, DevBuf<u64> &dpf) {
-        for (size_t i = 0; i < k_.ndigits; i++)
-            for (size_t r = 0; r < kc.L; r++) {
-                const double pd = (double)kc.moduli[r];
-                for (size_t j = 0; j < kc.n; j++) {
-                    const size_t x = (i * kc.L + r) * kc.n + j;
-                    const double kd = (double)h[x], kp = kd / pd;
-                    std::memcpy(&f[x], &kd, 8);
-                    std::memcpy(&pf[x], &kp, 8);
-                }
-            }
+    std::vector<u64> f(count);
+    auto fill = [&](const u64 *h, DevBuf<u64> &df) {
+        for (size_t x = 0; x < count; x++) {
+            const double kd = (double)h[x];     // exact: canonical key words are below 2^50 here
+            std::memcpy(&f[x], &kd, 8);
+        }
         df.upload(f);
-        dpf.upload(pf);
     };
-    fill(h0, k_.c0f, k_.c0pf);
-    fill(h1, k_.c1f, k_.c1pf);
+    fill(h0, k_.c0f);
+    fill(h1, k_.c1f);
 }
 
 inline void ksk_validate(const Ctx &ct_ctx, const Ctx &ksk_ctx, size_t ndigits, size_t log_base) {
@@ -1516,11 +1509,11 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     allow_big_lds((k::ks_fused_kernel<LOGN, false, GMV, 0, true, 0, GALV, HR>), lds);                                  \
     FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, GMV, 0, true, 0, GALV, HR>), dim3(ks_grid),    \
                dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0f.p,       \
-               k_.c0pf.p, k_.c1f.p, k_.c1pf.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,           \
+               k_.c0f.p, k_.c1f.p, k_.c1f.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,             \
                k_.digit_arg(), xhat, xhat_stride, (uint32_t)(npolys * kc.L), gal)
 #define FHE_KS_F64(HR)                                                                                                 \
     do {                                                                                                               \
-        constexpr int GMV = LOGN == 14 ? k::GM_MIXED : k::KS_GMAX;                                                     \
+        constexpr int GMV = k::KS_GMAX;   /* radix-8 passes at every size: one-word twiddles leave the N = 16384 tile room */ \
         if (gal) {                                                                                                     \
             FHE_KS_F64_G(GMV, true, HR);                                                                               \
         } else {                                                                                                       \
@@ -1542,7 +1535,7 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
                     allow_big_lds((k::ks_fused_kernel<LOGN, false, k::GM_MIXED, 512, true, 0, false, 5>), lds2);
                     FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, k::GM_MIXED, 512, true, 0, false, 5>),
                                dim3(grid2), dim3(512), lds2, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0f.p,
-                               k_.c0pf.p, k_.c1f.p, k_.c1pf.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
+                               k_.c0f.p, k_.c1f.p, k_.c1f.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
                                k_.digit_arg(), xhat, xhat_stride, grid2, gal);
                     return;
                 }

@@ -39,7 +39,8 @@ constexpr int ks_min_waves(int logn, int tt) { return (logn == 14 && tt == 512) 
 // digit loop sits at 124 of 128 VGPRs); the relinearisation / multiply instances are the round-4 kernels, bit for bit.
 // F64 = HR > 0 (round 6): every key modulus below 2^(53 - HR) (the reference's stock parameter sets: 36-49 bits): the digit
 // transforms and both multiply-accumulates run on doubles holding integers (zq_f64.hpp).  Then `tw` is the key context's
-// F64 twiddle table and k0 / k0s / k1 / k1s are the key's F64 twins ({k, k / p} as doubles, Ksk::c0f ...); a digit row of
+// F64 twiddle table and k0 / k1 are the key words as doubles (Ksk::c0f, c1f; k0s / k1s are not read: the accumulate takes its
+// quotient from h / p, which halves the key bytes pulled through L2); a digit row of
 // another modulus of the basis IS a representative under this one -- there is no lift at all.  RNS digits, whole-row tiles
 // (G0 = 0), TT = 0.  The integer instances (F64 = 0) are the round-5 kernels bit for bit (tests/test_isa_guards.py).
 template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false, int G0 = 0, bool GAL = false, int F64 = 0>
@@ -67,9 +68,10 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
     // POWN, and F64_CAP digits fit an accumulator together with a canonical addend before it must be reduced.
     constexpr int F64_VB = F64 ? f64_fwd_out_bound(LOGN, F64 ? F64 : 3) : 0;
     // (reduce the transformed values first only when the accumulators would otherwise hold fewer than sixteen terms)
-    constexpr bool F64_REDV = F64 > 0 && (f64_limit(F64 ? F64 : 3) - 2 * F64_ONE - F64_REDUCED) / f64_product_bound(F64_VB, F64 ? F64 : 3) < 16;
-    constexpr int F64_PB = F64 ? f64_product_bound(F64_REDV ? F64_REDUCED : F64_VB, F64 ? F64 : 3) : 1;
-    constexpr int F64_POWN = F64 ? f64_product_bound(F64_ONE, F64 ? F64 : 3) : 1;
+    // (products by key words take their quotient from h / p -- mulmod2_add_f64: no k / p twin is read)
+    constexpr bool F64_REDV = F64 > 0 && (f64_limit(F64 ? F64 : 3) - 2 * F64_ONE - F64_REDUCED) / f64_product_bound2(F64_VB, F64 ? F64 : 3) < 16;
+    constexpr int F64_PB = F64 ? f64_product_bound2(F64_REDV ? F64_REDUCED : F64_VB, F64 ? F64 : 3) : 1;
+    constexpr int F64_POWN = F64 ? f64_product_bound2(F64_ONE, F64 ? F64 : 3) : 1;
     constexpr int F64_CAP = F64 ? (f64_limit(F64 ? F64 : 3) - F64_ONE - F64_POWN - F64_REDUCED) / F64_PB : 1;
     static_assert(F64 == 0 || F64_CAP >= 8, "accumulator room");
     constexpr int CH = tile_chunks_c(LOGN, T);
@@ -160,10 +162,10 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                 const u64x2 q0 = a0[ci], q0s = a0s[ci], q1 = a1[ci], q1s = a1s[ci];
                 if constexpr (F64 > 0) {
                     const double vx = f64_from_u64(v.x), vy = f64_from_u64(v.y);
-                    acc0[2 * c] = bits_of_f64(mulmod_f64(vx, f64_of_bits(q0.x), f64_of_bits(q0s.x), pf.p));
-                    acc0[2 * c + 1] = bits_of_f64(mulmod_f64(vy, f64_of_bits(q0.y), f64_of_bits(q0s.y), pf.p));
-                    const u64x2 af{bits_of_f64(mulmod_f64(vx, f64_of_bits(q1.x), f64_of_bits(q1s.x), pf.p)),
-                                   bits_of_f64(mulmod_f64(vy, f64_of_bits(q1.y), f64_of_bits(q1s.y), pf.p))};
+                    acc0[2 * c] = bits_of_f64(mulmod2_add_f64(0.0, vx, f64_of_bits(q0.x), pf));
+                    acc0[2 * c + 1] = bits_of_f64(mulmod2_add_f64(0.0, vy, f64_of_bits(q0.y), pf));
+                    const u64x2 af{bits_of_f64(mulmod2_add_f64(0.0, vx, f64_of_bits(q1.x), pf)),
+                                   bits_of_f64(mulmod2_add_f64(0.0, vy, f64_of_bits(q1.y), pf))};
                     if constexpr (ACC1_LDS) {
                         acc1_lds[ci] = af;
                     } else {
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
             // transform, so their L2 latency is spent waiting for the other waves, not after them
             constexpr bool KPF = PREFETCH && CH >= 2;
             // (twiddle prefetch measured: no gain here; NARROW: values < 16p on exit, fine for the Shoup MAC)
-            ntt_fwd_lds<LOGN, T, GM, FHE_KS_TWPF && LOGN == 13, !KPF, (F64 ? -F64 : NARROW ? (G0 ? 4 : 1) : 0), NoSrc, KS_LATE>(lds, twr, NS + sub, pm, tid);
+            ntt_fwd_lds<LOGN, T, GM, FHE_KS_TWPF && LOGN == 13, !KPF, (F64 ? -(F64 | 8) : NARROW ? (G0 ? 4 : 1) : 0), NoSrc, KS_LATE>(lds, twr, NS + sub, pm, tid);
             FHE_TSK(7);
             // (all four chunks prefetched -- 118 VGPRs, no scratch: no change; three: 2 % slower.  ABBA runs in
             // profiles/r02_ks_kpf_ab.txt: the key words' latency is not what the MAC waits for)
@@ -385,21 +387,21 @@ __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT
                     if constexpr (F64_REDV) fx = reduce_f64(fx, pf), fy = reduce_f64(fy, pf);
                     // (block-uniform) every F64_CAP terms the accumulators are brought back below p / 2
                     const bool fold_acc = f64_terms >= (uint32_t)F64_CAP;
-                    auto mac = [&](u64 acc, double v, u64 kk, u64 kp) {
+                    auto mac = [&](u64 acc, double v, u64 kk) {
                         double a = f64_of_bits(acc);
                         if (fold_acc) a = reduce_f64(a, pf);
-                        return bits_of_f64(mulmod_add_f64(a, v, f64_of_bits(kk), f64_of_bits(kp), pf.p));
+                        return bits_of_f64(mulmod2_add_f64(a, v, f64_of_bits(kk), pf));
                     };
-                    acc0[2 * c] = mac(acc0[2 * c], fx, q0.x, q0s.x);
-                    acc0[2 * c + 1] = mac(acc0[2 * c + 1], fy, q0.y, q0s.y);
+                    acc0[2 * c] = mac(acc0[2 * c], fx, q0.x);
+                    acc0[2 * c + 1] = mac(acc0[2 * c + 1], fy, q0.y);
                     if constexpr (ACC1_LDS) {
                         u64x2 a = acc1_lds[ci];
-                        a.x = mac(a.x, fx, q1.x, q1s.x);
-                        a.y = mac(a.y, fy, q1.y, q1s.y);
+                        a.x = mac(a.x, fx, q1.x);
+                        a.y = mac(a.y, fy, q1.y);
                         acc1_lds[ci] = a;
                     } else {
-                        acc1[ACC1_LDS ? 0 : 2 * c] = mac(acc1[ACC1_LDS ? 0 : 2 * c], fx, q1.x, q1s.x);
-                        acc1[ACC1_LDS ? 0 : 2 * c + 1] = mac(acc1[ACC1_LDS ? 0 : 2 * c + 1], fy, q1.y, q1s.y);
+                        acc1[ACC1_LDS ? 0 : 2 * c] = mac(acc1[ACC1_LDS ? 0 : 2 * c], fx, q1.x);
+                        acc1[ACC1_LDS ? 0 : 2 * c + 1] = mac(acc1[ACC1_LDS ? 0 : 2 * c + 1], fy, q1.y);
                     }
                 } else {
                 const u64 vx = lds[padi(2 * ci)], vy = lds[padi(2 * ci + 1)];  // < 4p: Shoup accepts any u64

@@ -74,8 +74,8 @@ __device__ __forceinline__ void fwd_tw_load(FwdTw<G, LOGM, S0, T> &tw_regs, cons
 // NARROW = b0 > 0: moduli below 2^60 and input to stage 0 below b0*p (1: canonical) --
 // fwd_butterfly_narrow (zq_dev.hpp); values are below 16p on exit instead of 4p.
 // NARROW = -HR < 0 (round 6): the F64 form for launches whose moduli are all below 2^(53 - HR) (zq_f64.hpp).  The tile
-// holds the bit patterns of doubles (signed representatives), `tw` is the context's F64 twiddle table ({w, w / p} as
-// doubles, same indexing), pm carries {p, 1 / p} (make_pm_f64); input to stage 0 below 2^(53 - HR) in magnitude
+// holds the bit patterns of doubles (signed representatives), `tw` is the context's F64 twiddle table (w as a double in the
+// first word of each pair and w / p in the second, same indexing; -NARROW & 8: per-lane twiddles are read as one word), pm carries {p, 1 / p} (make_pm_f64); input to stage 0 below 2^(53 - HR) in magnitude
 // (canonical residues, or digit rows of another modulus of the launch); values leave below f64_fwd_out_bound().
 // NT > 1: the same pass on NT tiles that lie `tile_words` apart in LDS (the key switch transforms two digits
 // under one modulus at once): addresses and twiddles are formed once and serve every tile.
@@ -140,10 +140,18 @@ __device__ __forceinline__ void fwd_pass(u64 *lds, const u64x2 *__restrict__ tw,
                 for (uint32_t j = 0; j < half; j++) {
                     const uint32_t a = blk * 2 * half + j;
                     if constexpr (NARROW < 0) {
+                        // -NARROW = HR | (8: per-lane twiddles are read as ONE word).  The one-word form (quotient from
+                        // h (1/p)) is for the key switch, whose accumulators leave no registers for {w, w/p} pairs: it lets the
+                        // N = 16384 tile run radix-8 passes throughout (stock n = 16384 relinearise -19 %).  Register-resident it is
+                        // 8 % slower than the {w, w/p} form, which the transforms proper keep in every pass
+                        // (profiles/r06_f64_one_word_ab.jsonl).
+                        constexpr int HRV = (-NARROW) & 7;
+                        constexpr bool ONE_WORD = ((-NARROW) & 8) != 0;
                         const PF pf = pf_of(pm);
                         double xa = f64_of_bits(x[a]), xb = f64_of_bits(x[a + half]);
-                        if (f64_fwd_reduces(S0 + u, -NARROW)) xa = reduce_f64(xa, pf), xb = reduce_f64(xb, pf);
-                        fwd_butterfly_f64(xa, xb, f64_of_bits(wv.x), f64_of_bits(wv.y), pf.p);
+                        if (f64_fwd_reduces(S0 + u, HRV)) xa = reduce_f64(xa, pf), xb = reduce_f64(xb, pf);
+                        if constexpr (UNIFORM || !ONE_WORD) fwd_butterfly_wp_f64(xa, xb, f64_of_bits(wv.x), f64_of_bits(wv.y), pf);
+                        else fwd_butterfly_f64(xa, xb, f64_of_bits(wv.x), pf);
                         x[a] = bits_of_f64(xa), x[a + half] = bits_of_f64(xb);
                     } else if constexpr (NARROW > 0)
                         fwd_butterfly_narrow<UNIFORM>(x[a], x[a + half], wv.x, wv.y, pm, fwd_narrow_corrects(S0 + u, NARROW));
@@ -385,7 +393,7 @@ __device__ __forceinline__ void inv_pass(u64 *lds, const u64x2 *__restrict__ itw
                             }
                         const double d = xa - xb, sm = xa + xb;
                         if (V0 + G == LOGM && u == G - 1 && fold) {
-                            xa = mulmod_f64(sm, f64_of_bits(ninv.x), f64_of_bits(ninv.y), pf.p);
+                            xa = mulmod_f64(sm, f64_of_bits(ninv.x), f64_of_bits(ninv.y), pf.p);     // (N^-1 pairs: wave-uniform)
                             xb = mulmod_f64(d, f64_of_bits(zninv.x), f64_of_bits(zninv.y), pf.p);
                         } else {
                             xa = sm;

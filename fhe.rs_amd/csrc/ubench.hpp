@@ -27,10 +27,10 @@ enum Kind : int {
     // round 6: the FP64-FMA alternative for moduli below 2^50 (zq_f64.hpp), priced before it is built
     F64_FMA = 10,      // v_fma_f64, a dependent chain per lane
     F64_RNDNE = 11,    // v_rndne_f64 (+ one v_add_f64 that keeps the chain alive)
-    F64_MULMOD = 12,   // mulmod_f64: one exact lazy modular product, precomputed w / p
+    F64_MULMOD = 12,   // mulmod_f64: one exact lazy modular product, precomputed w / p (scalar twiddles)
     F64_FWD = 13,      // fwd_butterfly_f64 + the amortised reduction (both outputs reduced every fourth stage)
     F64_INV = 14,      // inv_butterfly_f64 + the sum reduced every second stage
-    F64_MAC = 15,      // the key switch's accumulate on doubles: acc += v k (lazy), acc reduced every eighth term
+    F64_MAC = 15,      // the key switch's accumulate on doubles: acc + v k with the quotient from h (1/p) (no k / p twin), reduced every eighth term
     NKINDS = 16
 };
 constexpr int ILP = 8, ITERS = 2048;
@@ -121,16 +121,20 @@ __global__ void __launch_bounds__(256) ubench_f64_kernel(u64 *out, u64 seed, dou
             if (KIND == F64_RNDNE) x[i] = f64_rint(x[i]) + y[i];
             if (KIND == F64_MULMOD) x[i] = mulmod_f64(x[i], w, wp, m.p);
             if (KIND == F64_FWD) {
-                fwd_butterfly_f64(x[i], y[i], w, wp, m.p);
+                fwd_butterfly_wp_f64(x[i], y[i], w, wp, m);
                 if ((it & 3) == 3) x[i] = reduce_f64(x[i], m), y[i] = reduce_f64(y[i], m);
             }
             if (KIND == F64_INV) {
-                inv_butterfly_f64(x[i], y[i], w, wp, m.p);
+                inv_butterfly_f64(x[i], y[i], w, wp, m);
                 if (it & 1) x[i] = reduce_f64(x[i], m);
             }
             if (KIND == F64_MAC) {
-                x[i] = mulmod_add_f64(x[i], y[i], w, wp, m.p);
-                if ((it & 7) == 7) x[i] = reduce_f64(x[i], m);
+                // (the product must depend on the chain -- with a loop-invariant y the compiler hoists it and the loop times one
+                // add; round 6's first gate figure for this kind, 6.2 T/s, was that: corrected here)
+                const double acc = y[i];
+                y[i] = x[i];
+                x[i] = mulmod2_add_f64(acc, x[i], w, m);
+                if ((it & 7) == 7) x[i] = reduce_f64(x[i], m), y[i] = reduce_f64(y[i], m);
             }
         }
     }

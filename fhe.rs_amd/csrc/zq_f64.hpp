@@ -91,6 +91,15 @@ FHE_HD double mulmod2_f64(double a, double b, const PF &m) {
     const double q = f64_rint(h * m.ip);
     return f64_fma(-q, m.p, h) + l;
 }
+// acc + x k mod p for a per-lane k with NO precomputed quotient (the key switch's accumulate: dropping k / p halves the key
+// bytes a workgroup pulls through L2 -- 16 instead of 32 per coefficient and digit -- for the same six operations): the quotient
+// estimate h (1/p) carries three roundings, so |x k - q p| <= (0.5 + 3 |x| 2^-53) p; exact for |x| < 2^53 like mulmod_f64.
+FHE_HD double mulmod2_add_f64(double acc, double x, double k, const PF &m) {
+    const double h = x * k;
+    const double l = f64_fma(x, k, -h);
+    const double q = f64_rint(h * m.ip);
+    return (f64_fma(-q, m.p, h) + l) + acc;
+}
 // |x| < 2^52 -> |r| <= 0.5 p (1 + 2^-40)
 FHE_HD double reduce_f64(double x, const PF &m) { return f64_fma(-f64_rint(x * m.ip), m.p, x); }
 // any representative (|x| < 2^53) -> the canonical residue in [0, p) as a u64 word.  reduce_f64 leaves |r| <= 0.5 p + 8
@@ -108,16 +117,28 @@ FHE_HD u64 to_u64_canonical(double x, const PF &m) {
 
 // Harvey-shaped lazy butterflies on signed representatives (M/ntt/native.rs:256-269 / 288-300 compute the same
 // residues): forward (x, y) <- (x + w y, x - w y); the outputs grow by |w y| <= (0.5 + eps) p per stage.
-FHE_HD void fwd_butterfly_f64(double &x, double &y, double w, double wp, double p) {
-    const double t = mulmod_f64(y, w, wp, p);
+// (w: the twiddle as a double; the quotient comes from h (1/p) -- mulmod2_add_f64's form -- so a twiddle is ONE word: the
+// per-lane twiddles of the late passes cost half the registers and half the L2 bytes of a {w, w/p} pair, which is what lets the
+// N = 16384 key switch run radix-8 passes throughout without scratch and takes the forward transform from 110 to 68 VGPRs.)
+FHE_HD void fwd_butterfly_f64(double &x, double &y, double w, const PF &m) {
+    const double t = mulmod2_add_f64(0.0, y, w, m);
     y = x - t;
     x = x + t;
 }
-// inverse (Gentleman-Sande): (x, y) <- (x + y, (x - y) z); the sum doubles per stage, the product is below ~p
-FHE_HD void inv_butterfly_f64(double &x, double &y, double z, double zp, double p) {
+// The same with the quotient from a precomputed w / p (mulmod_f64): for passes whose twiddles are WAVE-UNIFORM -- the pair
+// sits in scalar registers, so the second word costs nothing, and the two multiplies of a product are independent (measured,
+// register resident: 3.59 against 3.31 T butterflies/s; profiles/r06_f64_gate.json vs r06_h_f64_rates.json).
+FHE_HD void fwd_butterfly_wp_f64(double &x, double &y, double w, double wp, const PF &m) {
+    const double t = mulmod_f64(y, w, wp, m.p);
+    y = x - t;
+    x = x + t;
+}
+// inverse (Gentleman-Sande): (x, y) <- (x + y, (x - y) z); the sum doubles per stage, the product is below ~p.  (The inverse
+// passes run in the transform kernels only, which keep {z, z/p} pairs in every pass.)
+FHE_HD void inv_butterfly_f64(double &x, double &y, double z, double zp, const PF &m) {
     const double d = x - y;
     x = x + y;
-    y = mulmod_f64(d, z, zp, p);
+    y = mulmod_f64(d, z, zp, m.p);
 }
 
 // A modulus as the F64 passes carry it: the kernels' PM record (four 64-bit words in scalar registers) holds the bit
@@ -150,7 +171,9 @@ FHE_HD PF pf_of(const PM &pm) { return PF{f64_of_bits(pm.p), f64_of_bits(pm.p2)}
 // 2^53 = 2^HR * 1024 U.  A lazy product of y is below (0.5 + |y| 2^-52) p < (512 + (|y| / U) 2^(1 - HR)) U.
 constexpr int F64_ONE = 1024;
 constexpr int f64_limit(int HR) { return F64_ONE << HR; }
-constexpr int f64_product_bound(int y, int HR) { return 512 + ((2 * y) >> HR) + 2; }      // (+2: rounding of this model)
+// (the kernels take every quotient from h (1/p): |x k - q p| <= (0.5 + 3 |x| 2^-53) p; +2: rounding of this model)
+constexpr int f64_product_bound(int y, int HR) { return 512 + ((3 * y) >> HR) + 2; }
+constexpr int f64_product_bound2(int y, int HR) { return f64_product_bound(y, HR); }
 constexpr int F64_REDUCED = 520;   // after reduce_f64: 0.5 p + |x| 2^-52 p, far below 520 / 1024
 // forward (Cooley-Tukey) stages: every value of a stage shares one bound; a' = a + product_bound(a)
 constexpr int f64_fwd_step(int a, int HR) { return a + f64_product_bound(a, HR); }
@@ -170,6 +193,6 @@ constexpr int f64_fwd_out_bound(int stages, int HR, int a0 = F64_ONE) {   // bou
     return f64_fwd_step(f64_fwd_reduces(stages - 1, HR, a0) ? F64_REDUCED : a, HR);
 }
 static_assert(f64_fwd_out_bound(16, 5) < f64_limit(5), "48-bit moduli: no reduction inside a forward transform up to N = 65536");
-static_assert(!f64_fwd_reduces(15, 5) && f64_fwd_reduces(5, 3) && !f64_fwd_reduces(4, 3) && f64_fwd_reduces(11, 4) && !f64_fwd_reduces(10, 4), "forward reduction schedule");
+static_assert(!f64_fwd_reduces(15, 5) && f64_fwd_reduces(4, 3) && !f64_fwd_reduces(3, 3) && f64_fwd_reduces(9, 4) && !f64_fwd_reduces(8, 4), "forward reduction schedule");
 
 }  // namespace fhe

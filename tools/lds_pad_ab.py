@@ -36,6 +36,22 @@ a, b = ctx.synth_uniform(11, 0, 0, 2, 1024), ctx.synth_uniform(11, 0, 2, 2, 1024
 out["stock8192_relinearize_1024_ms"] = med(lambda: rk.relinearizes(ct3))
 out["stock8192_mul_and_relin_1024_ms"] = med(lambda: mul.multiply(a, b))
 del ct3, a, b, mul, rk
+n16 = 16384
+stock16 = [0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001, 0x1ffffffee8001, 0x1ffffffea0001,
+           0x1ffffffe88001, 0x1ffffffe48001]
+par = fhe.BfvParameters(n16, fhe.generate_prime(20, 2 * n16, (1 << 20) - 1), moduli=stock16)
+ctx = par.context_at_level(0)
+rk = fhe.RelinearizationKey(bench.key_for(fhe, ctx, 12))
+mul = fhe.Multiplicator.default(par, rk, 0)
+ct3 = ctx.synth_uniform(12, 0, 0, 3, 256)
+a, b = ctx.synth_uniform(12, 0, 0, 2, 256), ctx.synth_uniform(12, 0, 2, 2, 256)
+out["stock16384_relinearize_256_ms"] = med(lambda: rk.relinearizes(ct3))
+out["stock16384_mul_and_relin_256_ms"] = med(lambda: mul.multiply(a, b))
+one = ct3[:1].contiguous()
+out["stock16384_relinearize_single_ms"] = med(lambda: rk.relinearizes(one))
+import hashlib
+out["digest_stock16384"] = hashlib.sha256(rk.relinearizes(ct3)[:4].cpu().numpy().tobytes()).hexdigest()[:16]
+del ct3, a, b, mul, rk, one
 par = fhe.BfvParameters(n, fhe.generate_prime(20, 2 * n, 1 << 20), moduli_sizes=[60] * 4)
 ctx = par.context_at_level(0)
 mul = fhe.Multiplicator.default(par, fhe.RelinearizationKey(bench.key_for(fhe, ctx, bench.SEED)), 0).set_streams(1)
@@ -47,6 +63,5 @@ ctx = fhe.Context(fhe.generate_moduli([60] * 8, n3), n3)
 rk = fhe.RelinearizationKey(bench.key_for(fhe, ctx, 0xF4E50003))
 ct3 = ctx.synth_uniform(0xF4E50003, 0, 0, 3, 512)
 out["c3_relinearize_512_ms"] = med(lambda: rk.relinearizes(ct3))
-import hashlib
 out["digest"] = hashlib.sha256(rk.relinearizes(ct3)[:4].cpu().numpy().tobytes()).hexdigest()[:16]
 print(json.dumps(out))

@@ -129,12 +129,12 @@ __global__ void __launch_bounds__(256) ubench_f64_kernel(u64 *out, u64 seed, dou
                 if (it & 1) x[i] = reduce_f64(x[i], m);
             }
             if (KIND == F64_MAC) {
-                // (the product must depend on the chain -- with a loop-invariant y the compiler hoists it and the loop times one
-                // add; round 6's first gate figure for this kind, 6.2 T/s, was that: corrected here)
-                const double acc = y[i];
-                y[i] = x[i];
-                x[i] = mulmod2_add_f64(acc, x[i], w, m);
-                if ((it & 7) == 7) x[i] = reduce_f64(x[i], m), y[i] = reduce_f64(y[i], m);
+                // (the multiplicand changes every iteration -- y + 1, one extra add, counted in -- because with a loop-invariant y
+                // the compiler hoists the product and the loop times one add: round 6's first gate figure for this kind,
+                // 6.2 T/s, was that.  The products are independent of the accumulator chain, as the kernel's are.)
+                y[i] = y[i] + 1.0;
+                x[i] = mulmod2_add_f64(x[i], y[i], w, m);
+                if ((it & 7) == 7) x[i] = reduce_f64(x[i], m);
             }
         }
     }

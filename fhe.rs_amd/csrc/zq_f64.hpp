@@ -11,6 +11,10 @@
 //
 // six full-rate operations for a lazy modular product with a precomputed w/p (the role Shoup's floor(w 2^64 / p)
 // plays in M/zq/mod.rs:224-234), against ~13.7 issue slots for the integer form (profiles/r06_f64_gate.json).
+// Second form, same six operations, NO precomputed quotient: q = rint(h (1/p)) (mulmod2_add_f64) -- the operand is then ONE
+// word.  The fused key switch uses it for its key words and its per-lane twiddles (half the key bytes through L2, half the
+// twiddle registers: the N = 16384 tile runs radix-8 passes throughout); the transforms proper keep {w, w/p} pairs, whose two
+// multiplies are independent (8 % faster register resident).
 // VALUES ARE SIGNED: a residue class is represented by any integer v with |v| < 2^53 congruent to it; canonical
 // [0, p) u64 words are formed only at kernel boundaries (to_u64_canonical), so nothing crosses the C ABI in this form
 // and the outputs -- canonical residues, a function of the inputs -- stay bit-identical to the reference.

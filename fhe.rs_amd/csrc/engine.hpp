@@ -1527,13 +1527,14 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
                 // scratch; radix-8 throughout spills 52 B, radix-16 204 B).  Round 6 A/B (profiles/r06_ks13_f64_t512_ab_rejected.jsonl, one lab
                 // build, alternating processes, same digest): relinearise of 1,024 1.149 -> 1.176 ms, of 256 0.305 -> 0.314 -- slower,
                 // as the integer form of this cut was in round 3: two more passes and their LDS traffic cost what the second
-                // resident workgroup hides.  Lab only
+                // resident workgroup hides.  With the one-word twiddles radix-8 passes fit (126 VGPRs, no scratch): measured again
+                // in that form, profiles/r06_ks13_f64_t512_radix8_ab.jsonl.  Lab only
                 static const int t512 = FHE_LAB_INT("KS13_F64_T512", 0);
                 if (t512 && !gal && hr == 5) {
                     const size_t lds2 = k::lds_words(1u << LOGN) * sizeof(u64);
                     const unsigned grid2 = (unsigned)(npolys * kc.L);
-                    allow_big_lds((k::ks_fused_kernel<LOGN, false, k::GM_MIXED, 512, true, 0, false, 5>), lds2);
-                    FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, k::GM_MIXED, 512, true, 0, false, 5>),
+                    allow_big_lds((k::ks_fused_kernel<LOGN, false, k::KS_GMAX, 512, true, 0, false, 5>), lds2);
+                    FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, k::KS_GMAX, 512, true, 0, false, 5>),
                                dim3(grid2), dim3(512), lds2, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0f.p,
                                k_.c0f.p, k_.c1f.p, k_.c1f.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
                                k_.digit_arg(), xhat, xhat_stride, grid2, gal);

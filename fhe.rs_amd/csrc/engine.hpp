@@ -1505,11 +1505,21 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
     if constexpr (LOGN >= 12 && LOGN <= 14) {
         const int hr = (k_.c0f.p && k_.log_base == 0) ? kc.f64_class(0, kc.L) : 0;
         if (hr) {
+            // Geometry of the F64 instances.  N = 16384: the tile's own 1024 threads x 16 coefficients.  N = 8192 (and 4096 in
+            // the same shape): 512 (256) threads x 16 coefficients, BOTH accumulator sets in registers, tile-only LDS, one
+            // workgroup per item -- TWO (four) workgroups per CU, so one's barriers and LDS round trips hide behind the other's
+            // arithmetic.  Rounds 3 and 6 measured this cut slower with the passes it could afford then (mixed radix-8 /
+            // radix-4: profiles/r03_ks13_t512_rns_ab.txt, r06_ks13_f64_t512_ab_rejected.jsonl); with one-word per-lane twiddles
+            // radix-8 passes fit (126 VGPRs, no scratch) and it is ahead: relinearise of 1,024 at the stock n = 8192 set 1.114
+            // -> 1.032 ms, of 64 0.114 -> 0.106 (profiles/r06_ks13_f64_t512_radix8_ab.jsonl, same digest).
+            constexpr int F64_TT = (LOGN == 13 || (LOGN == 12 && FHE_KS12_F64_T256)) ? (1 << LOGN) / 16 : 0;
+            const size_t lds_f = F64_TT ? k::lds_words(1u << LOGN) * sizeof(u64) : lds;
+            const unsigned grid_f = F64_TT ? (unsigned)(npolys * kc.L) : ks_grid;
 #define FHE_KS_F64_G(GMV, GALV, HR)                                                                                    \
-    allow_big_lds((k::ks_fused_kernel<LOGN, false, GMV, 0, true, 0, GALV, HR>), lds);                                  \
-    FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, GMV, 0, true, 0, GALV, HR>), dim3(ks_grid),    \
-               dim3(k::ks_threads_c(LOGN)), lds, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0f.p,       \
-               k_.c0f.p, k_.c1f.p, k_.c1f.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,             \
+    allow_big_lds((k::ks_fused_kernel<LOGN, false, GMV, F64_TT, true, 0, GALV, HR>), lds_f);                           \
+    FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, GMV, F64_TT, true, 0, GALV, HR>), dim3(grid_f), \
+               dim3(k::ks_threads_tt(LOGN, F64_TT)), lds_f, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride,      \
+               k_.c0f.p, k_.c0f.p, k_.c1f.p, k_.c1f.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,   \
                k_.digit_arg(), xhat, xhat_stride, (uint32_t)(npolys * kc.L), gal)
 #define FHE_KS_F64(HR)                                                                                                 \
     do {                                                                                                               \
@@ -1520,28 +1530,6 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
             FHE_KS_F64_G(GMV, false, HR);                                                                              \
         }                                                                                                              \
     } while (0)
-#if defined(FHE_LAB)
-            if constexpr (LOGN == 13) {
-                // FHE_LAB_KS13_F64_T512 = 1: 512 threads x 16 coefficients, both accumulator sets in registers, tile-only LDS
-                // (two workgroups per CU), radix-8 passes while the twiddles are scalar and radix-4 after (124 VGPRs, no
-                // scratch; radix-8 throughout spills 52 B, radix-16 204 B).  Round 6 A/B (profiles/r06_ks13_f64_t512_ab_rejected.jsonl, one lab
-                // build, alternating processes, same digest): relinearise of 1,024 1.149 -> 1.176 ms, of 256 0.305 -> 0.314 -- slower,
-                // as the integer form of this cut was in round 3: two more passes and their LDS traffic cost what the second
-                // resident workgroup hides.  With the one-word twiddles radix-8 passes fit (126 VGPRs, no scratch): measured again
-                // in that form, profiles/r06_ks13_f64_t512_radix8_ab.jsonl.  Lab only
-                static const int t512 = FHE_LAB_INT("KS13_F64_T512", 0);
-                if (t512 && !gal && hr == 5) {
-                    const size_t lds2 = k::lds_words(1u << LOGN) * sizeof(u64);
-                    const unsigned grid2 = (unsigned)(npolys * kc.L);
-                    allow_big_lds((k::ks_fused_kernel<LOGN, false, k::KS_GMAX, 512, true, 0, false, 5>), lds2);
-                    FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, k::KS_GMAX, 512, true, 0, false, 5>),
-                               dim3(grid2), dim3(512), lds2, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride, k_.c0f.p,
-                               k_.c0f.p, k_.c1f.p, k_.c1f.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,
-                               k_.digit_arg(), xhat, xhat_stride, grid2, gal);
-                    return;
-                }
-            }
-#endif
             if (hr == 3) FHE_KS_F64(3);
             else if (hr == 4) FHE_KS_F64(4);
             else FHE_KS_F64(5);
@@ -1713,8 +1701,19 @@ inline bool ks_use_unfused(const Ksk &k_, int mode, size_t npolys) {
     // 0.382 / 0.443 vs 0.461 / 0.465 / 0.479, at C5 (320 / 384 parts) 0.834 / 0.967 vs 1.040 / 1.045; 576: 0.669 vs 0.727
     // (C3), 1.440 vs 1.562 (C5); with the last round more than half full the fused kernel is ahead again (448: 0.120 vs 0.128).
     if (kc.logn == 12) return 5 * fused_wg <= cus;
-    if (5 * fused_wg <= 3 * cus) return true;
     const size_t full = fused_wg / cus, rem = fused_wg % cus;
+    // Round 6, the F64 instances (profiles/r06_m_f64_ks_modes_grid.jsonl, r06_n_f64_ks_modes_grid_after.jsonl, stock sets, relinearise of 8 ... 512): their fused
+    // kernels are ahead of the integer ones by more than their stage A is, so the windows shrink.  N = 8192 (512 threads,
+    // two workgroups per CU -- but the second workgroup of a CU costs it ~0.7 of the first, so the steps stay one per CUs'
+    // worth): unfused up to 15/16 of a round (240 workgroups: 0.0694 vs 0.0698 ms, 200: 0.0649 vs 0.0688) and after one
+    // full round up to 4/9 of the next (320: 0.0926 vs 0.0989; 360: 0.0976 vs 0.1001; 400: 0.1104 vs 0.1018); N = 16384: up to 0.6 of a round
+    // as before (144: 0.160 vs 0.172; 180: 0.192 vs 0.173) and after one full round up to a quarter of the next (288: 0.306
+    // vs 0.336; 360: 0.377 vs 0.354); never after two (560 at N = 8192: 0.157 vs 0.145; 576 at N = 16384: 0.598 vs 0.536).
+    if (kc.logn <= 14 && k_.c0f.p && kc.f64_class(0, kc.L)) {
+        if (kc.logn == 13 ? 16 * fused_wg <= 15 * cus : 5 * fused_wg <= 3 * cus) return true;
+        return full == 1 && rem > 0 && (kc.logn == 13 ? 9 * rem <= 4 * cus : 4 * rem <= cus);
+    }
+    if (5 * fused_wg <= 3 * cus) return true;
     // (after two full rounds only up to 0.4 of a third: 640 workgroups at C2 0.192 vs 0.182 ms)
     return rem > 0 && ((full == 1 && 2 * rem <= cus) || (full == 2 && 5 * rem <= 2 * cus));
 }

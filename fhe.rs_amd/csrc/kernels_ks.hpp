@@ -42,7 +42,9 @@ constexpr int ks_min_waves(int logn, int tt) { return (logn == 14 && tt == 512) 
 // F64 twiddle table and k0 / k1 are the key words as doubles (Ksk::c0f, c1f; k0s / k1s are not read: the accumulate takes its
 // quotient from h / p, which halves the key bytes pulled through L2); a digit row of
 // another modulus of the basis IS a representative under this one -- there is no lift at all.  RNS digits, whole-row tiles
-// (G0 = 0), TT = 0.  The integer instances (F64 = 0) are the round-5 kernels bit for bit (tests/test_isa_guards.py).
+// (G0 = 0); TT = 512 at N = 8192 (radix-8 passes fit beside both accumulator sets once the per-lane twiddles are one word:
+// 126 VGPRs, no scratch -- the two-workgroups-per-CU cut that lost with two-word twiddles is 6 % ahead here, engine.hpp
+// launch_ks_fused), TT = 0 otherwise.  The integer instances (F64 = 0) are the round-5 kernels bit for bit (tests/test_isa_guards.py).
 template <int LOGN, bool NARROW = false, int GM = KS_GMAX, int TT = 0, bool RNS = false, int G0 = 0, bool GAL = false, int F64 = 0>
 __global__ void __launch_bounds__(ks_threads_tt(LOGN, TT), ks_min_waves(LOGN, TT))
     ks_fused_kernel(const u64 *__restrict__ pin, u64 src_poly_stride, u64 *__restrict__ out0, u64 *__restrict__ out1,

@@ -14,7 +14,7 @@
     defined(FHE_KS_EXPERIMENTS) || defined(FHE_PHASE_TIMING) || defined(FHE_LDS_PAD) || defined(FHE_NO_WAVE_SYNC) || \
     defined(FHE_DIAG_NO_SGPR_ASM) || defined(FHE_KS_HALF13) || defined(FHE_KS_SPLIT_XCD) || defined(FHE_STREAM_NT) || \
     defined(FHE_MUL_DIRFLAGS) || defined(FHE_MUL_MERGED_EXT) || defined(FHE_PIPE_NT) || \
-    defined(FHE_KS_HALF15) || defined(FHE_FWD_DIRECT_STORE)
+    defined(FHE_KS_HALF15) || defined(FHE_FWD_DIRECT_STORE) || defined(FHE_KS12_F64_T256)
 #error "kernel-variant macros are lab-only: add -DFHE_LAB (the release build pins every knob, see knobs.hpp)"
 #endif
 #endif
@@ -42,6 +42,13 @@
 // per lane pair; the saved LDS round trip does not pay for it.  Off.
 #ifndef FHE_FWD_DIRECT_STORE
 #define FHE_FWD_DIRECT_STORE 0
+#endif
+// F64 key switch at N = 4096 in the 16-coefficients-per-thread geometry of N = 8192's F64 instance (256 threads, accumulators in
+// registers, four workgroups per CU) instead of 512 threads x 8 with the c1 accumulators in LDS.  Measured and rejected
+// (profiles/r06_l_f64_geometry_ab.jsonl, release builds alternating, same digests): relinearise of 1,024 / 256 at the stock
+// n = 4096 set -2 %, of 64 (192 workgroups, less than one per CU: the slower single workgroup is what shows) +23 %.
+#ifndef FHE_KS12_F64_T256
+#define FHE_KS12_F64_T256 0
 #endif
 // LDS tile padding (kernels_common.hpp padi): 0 = one extra word every 16 (two-way conflicted in every pass pattern, 2 KiB
 // smaller per tile), 1 = three extra words every 32 (conflict-free in seven of the nine patterns, tools/lds_pad_search.py).

@@ -15,10 +15,10 @@ FHE_PROBE_F(14, true, GM_MIXED, false, 1)   // generic loaders, rows larger than
 FHE_PROBE_F(14, true, GM_MIXED, false, 2)
 // round 6: the F64 instances the reference's stock sets run on (radix-8 passes at every size, one-word per-lane twiddles)
 #define FHE_PROBE_D(LOGN, GALV, HR)                                                                                    \
-    template __global__ void ks_fused_kernel<LOGN, false, KS_GMAX, 0, true, 0, GALV, HR>(                              \
+    template __global__ void ks_fused_kernel<LOGN, false, KS_GMAX, (LOGN == 13 ? 512 : 0), true, 0, GALV, HR>(         \
         const u64 *, u64, u64 *, u64 *, u64, const u64 *, const u64 *, u64, const u64 *, const u64 *, const u64 *,     \
         const u64 *, const DevMod *, const u64x2 *, uint32_t, uint32_t, uint32_t, const u64 *, u64, uint32_t, uint32_t);
-FHE_PROBE_D(13, false, 5)   // stock n = 8192
+FHE_PROBE_D(13, false, 5)   // stock n = 8192 (512 threads x 16 coefficients, two workgroups per CU)
 FHE_PROBE_D(14, false, 4)   // stock n = 16384 relinearise
 FHE_PROBE_D(14, true, 4)    // stock n = 16384 rotations
 #define FHE_PROBE_S(G0, NW)                                                                                            \

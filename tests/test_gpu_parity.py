@@ -843,6 +843,17 @@ def test_key_switch_auto_picks_strategy_by_launch_size(fhe):
     for rounds8, want_unfused in ((9, True), (12, True), (14, False), (16, False)):
         ks = kernels_of(ctx, L, rounds8 * cus // (8 * L))
         assert ("ks_mac" in ks) == want_unfused and ("key_switch_fused" in ks) == (not want_unfused), (rounds8, ks)
+    # round 6 (profiles/r06_m_f64_ks_modes_grid.jsonl, r06_n_f64_ks_modes_grid_after.jsonl): the F64 instances (moduli below 2^50 -- the reference's stock sets) have
+    # narrower windows: N = 8192 unfused up to 15/16 of a round and up to 4/9 of the round after the first, N = 16384 up to
+    # 0.6 of a round and up to a quarter of the round after the first; never after two full rounds
+    import ref_params
+    for n, cases_ in ((8192, ((15, 16, True), (5, 4, True), (3, 2, False), (17, 8, False))),
+                      (16384, ((9, 16, True), (3, 4, False), (9, 8, True), (3, 2, False), (17, 8, False)))):
+        q = ref_params.DEFAULT_128[n]
+        ctx = fhe.Context(q, n)
+        for num, den, want_unfused in cases_:
+            ks = kernels_of(ctx, len(q), num * cus // (den * len(q)))
+            assert ("ks_digit_ntt_f64" in ks) == want_unfused and ("key_switch_fused_f64" in ks) == (not want_unfused), (n, num, den, ks)
     n, L = 32768, 2                                  # two digits: never unfused; sub-blocks while they fit at once
     ctx = fhe.Context(fhe.generate_moduli([60] * L, n), n)
     ks = kernels_of(ctx, L, cus // (4 * L))          # batch x L x 4 sub-blocks = CUs

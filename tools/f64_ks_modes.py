@@ -17,14 +17,19 @@ SETS = {4096: [0xffffee001, 0xffffc4001, 0x1ffffe0001],
         16384: [0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001, 0x1ffffffee8001,
                 0x1ffffffea0001, 0x1ffffffe88001, 0x1ffffffe48001]}
 timeit = bench.make_timeit(torch, 5)
+# optional: FHE_MODES_GRID="8192:32,64,96;16384:16,32" restricts the sets and batches; FHE_MODES_F64_ONLY=1 skips the integer kernels
+GRID = {int(a.split(":")[0]): [int(b) for b in a.split(":")[1].split(",")] for a in os.environ.get("FHE_MODES_GRID", "").split(";") if a}
+F64_ONLY = os.environ.get("FHE_MODES_F64_ONLY", "0") == "1"
 for n, q in SETS.items():
+    if GRID and n not in GRID:
+        continue
     ctx = fhe.Context(q, n)
     ksk = bench.key_for(fhe, ctx, 11)
     rk = fhe.RelinearizationKey(ksk)
-    for batch in (1, 4, 16, 64, 256, 1024 if n <= 8192 else 512):
+    for batch in GRID.get(n, (1, 4, 16, 64, 256, 1024 if n <= 8192 else 512)):
         ct3 = ctx.synth_uniform(11, 0, 0, 3, batch)
         cell = dict(n=n, batch=batch)
-        for f64 in (True, False):
+        for f64 in ((True,) if F64_ONLY else (True, False)):
             fhe.set_f64(f64)
             for mode, name in ((0, "auto"), (1, "fused"), (2, "unfused")):
                 ksk.set_mode(mode)

@@ -16,7 +16,11 @@ SETS = {"stock4096": (4096, [0xffffee001, 0xffffc4001, 0x1ffffe0001], 1024),
         "stock16384": (16384, [0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001, 0x1ffffffee8001,
                                0x1ffffffea0001, 0x1ffffffe88001, 0x1ffffffe48001], 256),
         "c3shape": (16384, None, 256), "n4096_4x60": (4096, "4x60", 2048)}
+ONLY = sys.argv[1].split(",") if len(sys.argv) > 1 else None      # e.g. "stock8192,stock4096"
+CHUNKS = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 16, 32, 64, 128, 256, 512, 1024, 2048]
 for name, (n, q, batch) in SETS.items():
+    if ONLY and name not in ONLY:
+        continue
     t = fhe.generate_prime(20, 2 * n, (1 << 20) - 1)
     if q is None:
         par = fhe.BfvParameters(n, t, moduli_sizes=[60] * 8)
@@ -41,7 +45,7 @@ for name, (n, q, batch) in SETS.items():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / steps
     for streams in (1, 2):
-        for chunk in (0, 16, 32, 64, 128, 256, 512, 1024, 2048):
+        for chunk in CHUNKS:
             if chunk > batch:
                 continue
             ms = min(run(chunk, streams), run(chunk, streams))

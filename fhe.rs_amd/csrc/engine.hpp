@@ -1512,28 +1512,46 @@ inline void launch_ks_fused(const Ksk &k_, const u64 *p, u64 p_stride, u64 *o0, 
             // radix-4: profiles/r03_ks13_t512_rns_ab.txt, r06_ks13_f64_t512_ab_rejected.jsonl); with one-word per-lane twiddles
             // radix-8 passes fit (126 VGPRs, no scratch) and it is ahead: relinearise of 1,024 at the stock n = 8192 set 1.114
             // -> 1.032 ms, of 64 0.114 -> 0.106 (profiles/r06_ks13_f64_t512_radix8_ab.jsonl, same digest).
+            // A launch with at most one workgroup per CU has no second workgroup to overlap with: there the tile's own 1024
+            // threads (N = 8192: 1024 x 8, c1 accumulators in LDS, resident item loop) finish a single workgroup sooner --
+            // 0.052-0.055 ms against 0.062-0.070 for up to 256 workgroups (profiles/r06_l_f64_ks_modes.jsonl,
+            // r06_m_f64_ks_modes_grid.jsonl) -- so the 512-thread instance is taken from the second workgroup per CU on.
             constexpr int F64_TT = (LOGN == 13 || (LOGN == 12 && FHE_KS12_F64_T256)) ? (1 << LOGN) / 16 : 0;
-            const size_t lds_f = F64_TT ? k::lds_words(1u << LOGN) * sizeof(u64) : lds;
-            const unsigned grid_f = F64_TT ? (unsigned)(npolys * kc.L) : ks_grid;
-#define FHE_KS_F64_G(GMV, GALV, HR)                                                                                    \
-    allow_big_lds((k::ks_fused_kernel<LOGN, false, GMV, F64_TT, true, 0, GALV, HR>), lds_f);                           \
-    FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, GMV, F64_TT, true, 0, GALV, HR>), dim3(grid_f), \
-               dim3(k::ks_threads_tt(LOGN, F64_TT)), lds_f, s, p, p_stride, o0, o1, out_stride, a0, a1, a_stride,      \
-               k_.c0f.p, k_.c0f.p, k_.c1f.p, k_.c1f.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits, (uint32_t)kc.L,   \
-               k_.digit_arg(), xhat, xhat_stride, (uint32_t)(npolys * kc.L), gal)
+            const bool two_per_cu = F64_TT != 0 && npolys * kc.L > (size_t)device_cus(kc.device);
+#define FHE_KS_F64_G(GMV, GALV, HR, TTV)                                                                               \
+    do {                                                                                                               \
+        const size_t lds_f = TTV ? k::lds_words(1u << LOGN) * sizeof(u64) : lds;                                       \
+        const unsigned grid_f = TTV ? (unsigned)(npolys * kc.L) : ks_grid;                                             \
+        allow_big_lds((k::ks_fused_kernel<LOGN, false, GMV, TTV, true, 0, GALV, HR>), lds_f);                          \
+        FHE_LAUNCH("key_switch_fused_f64", (k::ks_fused_kernel<LOGN, false, GMV, TTV, true, 0, GALV, HR>),             \
+                   dim3(grid_f), dim3(k::ks_threads_tt(LOGN, TTV)), lds_f, s, p, p_stride, o0, o1, out_stride, a0, a1, \
+                   a_stride, k_.c0f.p, k_.c0f.p, k_.c1f.p, k_.c1f.p, kc.dmods(), kc.dtw_f(), (uint32_t)k_.ndigits,     \
+                   (uint32_t)kc.L, k_.digit_arg(), xhat, xhat_stride, (uint32_t)(npolys * kc.L), gal);                 \
+    } while (0)
+#define FHE_KS_F64_T(GMV, GALV, HR)                                                                                    \
+    do {                                                                                                               \
+        if constexpr (F64_TT != 0) {                                                                                   \
+            if (two_per_cu) {                                                                                          \
+                FHE_KS_F64_G(GMV, GALV, HR, F64_TT);                                                                   \
+                break;                                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
+        FHE_KS_F64_G(GMV, GALV, HR, 0);                                                                                \
+    } while (0)
 #define FHE_KS_F64(HR)                                                                                                 \
     do {                                                                                                               \
         constexpr int GMV = k::KS_GMAX;   /* radix-8 passes at every size: one-word twiddles leave the N = 16384 tile room */ \
         if (gal) {                                                                                                     \
-            FHE_KS_F64_G(GMV, true, HR);                                                                               \
+            FHE_KS_F64_T(GMV, true, HR);                                                                               \
         } else {                                                                                                       \
-            FHE_KS_F64_G(GMV, false, HR);                                                                              \
+            FHE_KS_F64_T(GMV, false, HR);                                                                              \
         }                                                                                                              \
     } while (0)
             if (hr == 3) FHE_KS_F64(3);
             else if (hr == 4) FHE_KS_F64(4);
             else FHE_KS_F64(5);
 #undef FHE_KS_F64
+#undef FHE_KS_F64_T
 #undef FHE_KS_F64_G
             return;
         }
@@ -1702,15 +1720,17 @@ inline bool ks_use_unfused(const Ksk &k_, int mode, size_t npolys) {
     // (C3), 1.440 vs 1.562 (C5); with the last round more than half full the fused kernel is ahead again (448: 0.120 vs 0.128).
     if (kc.logn == 12) return 5 * fused_wg <= cus;
     const size_t full = fused_wg / cus, rem = fused_wg % cus;
-    // Round 6, the F64 instances (profiles/r06_m_f64_ks_modes_grid.jsonl, r06_n_f64_ks_modes_grid_after.jsonl, stock sets, relinearise of 8 ... 512): their fused
-    // kernels are ahead of the integer ones by more than their stage A is, so the windows shrink.  N = 8192 (512 threads,
-    // two workgroups per CU -- but the second workgroup of a CU costs it ~0.7 of the first, so the steps stay one per CUs'
-    // worth): unfused up to 15/16 of a round (240 workgroups: 0.0694 vs 0.0698 ms, 200: 0.0649 vs 0.0688) and after one
-    // full round up to 4/9 of the next (320: 0.0926 vs 0.0989; 360: 0.0976 vs 0.1001; 400: 0.1104 vs 0.1018); N = 16384: up to 0.6 of a round
-    // as before (144: 0.160 vs 0.172; 180: 0.192 vs 0.173) and after one full round up to a quarter of the next (288: 0.306
-    // vs 0.336; 360: 0.377 vs 0.354); never after two (560 at N = 8192: 0.157 vs 0.145; 576 at N = 16384: 0.598 vs 0.536).
+    // Round 6, the F64 instances (profiles/r06_m_f64_ks_modes_grid.jsonl, r06_n_f64_ks_modes_grid_after.jsonl,
+    // r06_p_f64_ks_modes_grid_two_geometries.jsonl; stock sets, relinearise of 8 ... 1,024): their fused kernels are ahead of
+    // the integer ones by more than their stage A is, so the windows after a full round shrink.  Below one round nothing
+    // changes (N = 8192, 1024-thread instance: 140 workgroups 0.0542 vs 0.0567 ms, 160: 0.0574 vs 0.0571, 255: 0.0754 vs
+    // 0.0639; N = 16384: 144: 0.160 vs 0.172, 180: 0.192 vs 0.173).  N = 8192 from the second workgroup per CU on (512-thread
+    // instance; a CU's second workgroup costs it ~0.7 of the first, so the steps stay one per CUs' worth): unfused up to 4/9 of
+    // the round after the first (320: 0.0926 vs 0.0989; 360: 0.0976 vs 0.1001; 400: 0.1104 vs 0.1018); N = 16384: up to a
+    // quarter (288: 0.306 vs 0.336; 360: 0.377 vs 0.354); never after two (560 at N = 8192: 0.157 vs 0.145; 576 at N = 16384:
+    // 0.598 vs 0.536).
     if (kc.logn <= 14 && k_.c0f.p && kc.f64_class(0, kc.L)) {
-        if (kc.logn == 13 ? 16 * fused_wg <= 15 * cus : 5 * fused_wg <= 3 * cus) return true;
+        if (5 * fused_wg <= 3 * cus) return true;
         return full == 1 && rem > 0 && (kc.logn == 13 ? 9 * rem <= 4 * cus : 4 * rem <= cus);
     }
     if (5 * fused_wg <= 3 * cus) return true;

@@ -14,13 +14,14 @@ FHE_PROBE_F(13, true, KS_GMAX, true, 0)     // C2
 FHE_PROBE_F(14, true, GM_MIXED, false, 1)   // generic loaders, rows larger than LDS
 FHE_PROBE_F(14, true, GM_MIXED, false, 2)
 // round 6: the F64 instances the reference's stock sets run on (radix-8 passes at every size, one-word per-lane twiddles)
-#define FHE_PROBE_D(LOGN, GALV, HR)                                                                                    \
-    template __global__ void ks_fused_kernel<LOGN, false, KS_GMAX, (LOGN == 13 ? 512 : 0), true, 0, GALV, HR>(         \
+#define FHE_PROBE_D(LOGN, GALV, HR, TTV)                                                                               \
+    template __global__ void ks_fused_kernel<LOGN, false, KS_GMAX, TTV, true, 0, GALV, HR>(                            \
         const u64 *, u64, u64 *, u64 *, u64, const u64 *, const u64 *, u64, const u64 *, const u64 *, const u64 *,     \
         const u64 *, const DevMod *, const u64x2 *, uint32_t, uint32_t, uint32_t, const u64 *, u64, uint32_t, uint32_t);
-FHE_PROBE_D(13, false, 5)   // stock n = 8192 (512 threads x 16 coefficients, two workgroups per CU)
-FHE_PROBE_D(14, false, 4)   // stock n = 16384 relinearise
-FHE_PROBE_D(14, true, 4)    // stock n = 16384 rotations
+FHE_PROBE_D(13, false, 5, 512)   // stock n = 8192, launches of more than one workgroup per CU (512 threads x 16 coefficients)
+FHE_PROBE_D(13, false, 5, 0)     // stock n = 8192, smaller launches (1024 threads x 8, resident item loop)
+FHE_PROBE_D(14, false, 4, 0)     // stock n = 16384 relinearise
+FHE_PROBE_D(14, true, 4, 0)      // stock n = 16384 rotations
 #define FHE_PROBE_S(G0, NW)                                                                                            \
     template __global__ void ks_fused_split_kernel<G0, 13, NW, false>(                                                 \
         const u64 *, u64, u64 *, u64 *, u64, const u64 *, const u64 *, u64, const u64 *, const u64 *, const u64 *,     \

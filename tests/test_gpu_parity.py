@@ -844,10 +844,11 @@ def test_key_switch_auto_picks_strategy_by_launch_size(fhe):
         ks = kernels_of(ctx, L, rounds8 * cus // (8 * L))
         assert ("ks_mac" in ks) == want_unfused and ("key_switch_fused" in ks) == (not want_unfused), (rounds8, ks)
     # round 6 (profiles/r06_m_f64_ks_modes_grid.jsonl, r06_n_f64_ks_modes_grid_after.jsonl): the F64 instances (moduli below 2^50 -- the reference's stock sets) have
-    # narrower windows: N = 8192 unfused up to 15/16 of a round and up to 4/9 of the round after the first, N = 16384 up to
-    # 0.6 of a round and up to a quarter of the round after the first; never after two full rounds
+    # narrower windows after a full round: up to 0.6 of a round as the integer kernels (N = 8192 fused launches of at most one
+    # workgroup per CU run the 1024-thread instance), then up to 4/9 (N = 8192, the 512-thread instance) / a quarter (N = 16384)
+    # of the round after the first; never after two full rounds (r06_p_f64_ks_modes_grid_two_geometries.jsonl)
     import ref_params
-    for n, cases_ in ((8192, ((15, 16, True), (5, 4, True), (3, 2, False), (17, 8, False))),
+    for n, cases_ in ((8192, ((9, 16, True), (3, 4, False), (5, 4, True), (3, 2, False), (17, 8, False))),
                       (16384, ((9, 16, True), (3, 4, False), (9, 8, True), (3, 2, False), (17, 8, False)))):
         q = ref_params.DEFAULT_128[n]
         ctx = fhe.Context(q, n)
@@ -1021,6 +1022,17 @@ def test_f64_key_switch(fhe, n, sizes, mode):
     reference's stock widths (parameters.rs:222-251), a 50-bit basis, and every width of VERDICT r05 #3's list in one
     basis; key_switch, relinearise, two rotations, against the C oracle, then with the option off."""
     cases.case_f64_key_switch(fhe, True, n, sizes, batch=3, exps=(3, 2 * n - 1), mode=mode)
+
+
+@pytest.mark.parametrize("sizes", [(43, 43, 44, 44, 44), (50, 49, 48, 27)])
+def test_f64_key_switch_two_workgroups_per_cu(fhe, sizes):
+    """N = 8192: launches of more than one workgroup per CU run the 512-thread x 16-coefficient instance (two workgroups per
+    CU; engine.hpp launch_ks_fused), smaller ones the tile's own 1024 threads -- the batch-3 cases above.  key_switch,
+    relinearise, two rotations (the gathering loaders of the GAL instance) of enough ciphertexts for the former, against the C
+    oracle, every ciphertext; then with the option off (the integer kernel on the same launch)."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    cases.case_f64_key_switch(fhe, True, 8192, sizes, batch=cus // len(sizes) + 2, exps=(3, 2 * 8192 - 1), mode=1)
 
 
 def test_f64_key_switch_accumulator_fold(fhe):

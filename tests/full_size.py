@@ -242,6 +242,12 @@ def random_shape(idx, big=False):
         L = rng.randrange(1, 13 if n == 4096 else 8)
         sizes = [rng.choice([27, 30, 36, 40, 43, 44, 47, 48, 49, 50]) for _ in range(L)]
         return n, sizes, rng.randrange(1, 5)
+    if big == "f64wide":
+        # round 6: N = 8192 launches of MORE than one workgroup per CU (256 CUs) -- the 512-thread x 16-coefficient F64
+        # key-switch instance (engine.hpp launch_ks_fused), which batches of 1 ... 4 never reach
+        L = rng.randrange(2, 8)
+        sizes = [rng.choice([27, 30, 36, 40, 43, 44, 47, 48, 49, 50]) for _ in range(L)]
+        return 8192, sizes, 256 // L + rng.randrange(1, 9)
     if big:
         n = 1 << rng.randrange(15, 17)
         L = rng.randrange(1, 6)
@@ -260,6 +266,12 @@ def check_random_shape(fhe, idx, big=False):
     n, sizes, batch = random_shape(idx, big)
     cfg = 100 + idx
     L = len(sizes)
+    if big == "f64wide":   # (sampled ciphertexts: first, two inside, last)
+        smp = sorted({0, batch // 3, 2 * batch // 3, batch - 1})
+        check_relin_rotate(fhe, n, sizes, batch, cfg, sample=smp)
+        if idx % 4 == 0:
+            check_mul(fhe, n, sizes, batch, relin=True, cfg=cfg, sample=smp)
+        return
     check_mul(fhe, n, sizes, batch, relin=L >= 2, cfg=cfg, mod_switch=L >= 2 and idx % 2 == 0)
     if L >= 2:
         check_relin_rotate(fhe, n, sizes, batch, cfg)

@@ -15,7 +15,7 @@ cp $SRC/smoke.log $P/${TAG}_smoke.log
 cp $SRC/f64_ab_v3.jsonl $P/${TAG}_f64_ab_v3.jsonl
 cp $SRC/f64_rates.json $P/${TAG}_f64_rates.json
 cp $SRC/soak_f64.json $P/${TAG}_soak_f64_vs_integer.json
-cat $SRC/sweep_f64_auto.json $SRC/sweep_f64_fused.json $SRC/sweep_f64_unfused.json $SRC/sweep_auto.json > $P/${TAG}_random_sweeps.jsonl
+cat $SRC/sweep_*.json > $P/${TAG}_random_sweeps.jsonl
 cp $SRC/latency_breakdown.json $P/${TAG}_latency_breakdown.json
 cp $SRC/stock_sets_profile.json $P/${TAG}_stock_sets_profile.json
 ls -la $P/${TAG}_*

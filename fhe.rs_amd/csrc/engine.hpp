@@ -1110,11 +1110,15 @@ struct Scaler {
 
 // NF of the scale_kernel<NF> instance for `nfrom` source moduli (the column's residues live in registers)
 inline size_t scale_kernel_nf(size_t nfrom) {
-    // 4 / 9 / 17 / 33: the operand and product bases of BASELINE's configs (L = 4, 8, 16; K = 9, 17, 33).  Round 5 adds
+    // 4 / 9 / 17 / 33: the operand and product bases of BASELINE's configs (L = 4, 8, 16; K = 9, 17, 33).  Round 5 added
     // 6 / 12 / 20 for the reference's stock sets (default_parameters_128: L = 3, 5, 9 and K = 6, 10, 18), which ran on
     // the next instance up -- K = 10 on NF = 17, K = 18 on NF = 33: up to 1.8 x the term loops, all of it zero padding.
-    return nfrom <= 4 ? 4 : nfrom <= 6 ? 6 : nfrom <= 9 ? 9 : nfrom <= 12 ? 12 : nfrom <= 17 ? 17 : nfrom <= 20 ? 20
-         : nfrom <= 33 ? 33 : 64;
+    // Round 6: the exact fits that were still padded -- 3 / 5 / 10 / 18 (stock sets: L = 3 on NF = 4, L = 5 on 6, K = 10 on
+    // 12, K = 18 on 20: 10-25 % of the terms were zeros) and 8 / 16 (C3's and C5's operand bases, on 9 and 17).
+    static constexpr size_t fits[] = {3, 4, 5, 6, 8, 9, 10, 12, 16, 17, 18, 20, 33};
+    for (size_t nf : fits)
+        if (nfrom <= nf) return nf;
+    return 64;
 }
 
 inline void scaler_upload(Scaler &s) {
@@ -1305,11 +1309,17 @@ inline void launch_scale(const Scaler &sc, const u64 *in, u64 in_stride, u64 *ou
         FHE_LAUNCH(label, (k::scale_kernel<NF, false>), grid, block, 0, s, in, out, in_stride, out_stride,   \
                    sc.dev, t.dmods(), (uint32_t)f.logn, total, asc)
     switch (scale_kernel_nf(f.L)) {   // (the same NF scaler_upload padded the tables to)
+        case 3: FHE_SCALE_CASE(3); break;
         case 4: FHE_SCALE_CASE(4); break;
+        case 5: FHE_SCALE_CASE(5); break;
         case 6: FHE_SCALE_CASE(6); break;
+        case 8: FHE_SCALE_CASE(8); break;
         case 9: FHE_SCALE_CASE(9); break;
+        case 10: FHE_SCALE_CASE(10); break;
         case 12: FHE_SCALE_CASE(12); break;
+        case 16: FHE_SCALE_CASE(16); break;
         case 17: FHE_SCALE_CASE(17); break;
+        case 18: FHE_SCALE_CASE(18); break;
         case 20: FHE_SCALE_CASE(20); break;
         case 33: FHE_SCALE_CASE(33); break;
         default:

@@ -1114,8 +1114,9 @@ inline size_t scale_kernel_nf(size_t nfrom) {
     // 6 / 12 / 20 for the reference's stock sets (default_parameters_128: L = 3, 5, 9 and K = 6, 10, 18), which ran on
     // the next instance up -- K = 10 on NF = 17, K = 18 on NF = 33: up to 1.8 x the term loops, all of it zero padding.
     // Round 6: the exact fits that were still padded -- 3 / 5 / 10 / 18 (stock sets: L = 3 on NF = 4, L = 5 on 6, K = 10 on
-    // 12, K = 18 on 20: 10-25 % of the terms were zeros) and 8 / 16 (C3's and C5's operand bases, on 9 and 17).
-    static constexpr size_t fits[] = {3, 4, 5, 6, 8, 9, 10, 12, 16, 17, 18, 20, 33};
+    // 12, K = 18 on 20: 10-25 % of the terms were zeros) and 8 / 16 (C3's and C5's operand bases, on 9 and 17); 14 / 23 /
+    // 27 / 31 for the levels of C5's chain (L = 15 ... 10: K = 31, 29, 27, 25, 23, 21 all ran on NF = 33, up to 57 % padding).
+    static constexpr size_t fits[] = {3, 4, 5, 6, 8, 9, 10, 12, 14, 16, 17, 18, 20, 23, 27, 31, 33};
     for (size_t nf : fits)
         if (nfrom <= nf) return nf;
     return 64;
@@ -1317,10 +1318,14 @@ inline void launch_scale(const Scaler &sc, const u64 *in, u64 in_stride, u64 *ou
         case 9: FHE_SCALE_CASE(9); break;
         case 10: FHE_SCALE_CASE(10); break;
         case 12: FHE_SCALE_CASE(12); break;
+        case 14: FHE_SCALE_CASE(14); break;
         case 16: FHE_SCALE_CASE(16); break;
         case 17: FHE_SCALE_CASE(17); break;
         case 18: FHE_SCALE_CASE(18); break;
         case 20: FHE_SCALE_CASE(20); break;
+        case 23: FHE_SCALE_CASE(23); break;
+        case 27: FHE_SCALE_CASE(27); break;
+        case 31: FHE_SCALE_CASE(31); break;
         case 33: FHE_SCALE_CASE(33); break;
         default:
             require(f.L <= 64, E_ARG, "RNS scaler supports at most 64 source moduli");

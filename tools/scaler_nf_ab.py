@@ -32,4 +32,8 @@ for name, (n, q, batch) in SETS.items():
     del a, b, mul, par, ctx
     fhe.workspace_trim()
     torch.cuda.empty_cache()
+if os.environ.get("FHE_AB_CHAIN", "1") == "1":
+    ch = bench.c5_chain(fhe, torch)
+    out["c5_chain_ms"] = ch["total_ms"]
+    out["c5_chain_per_level_ms"] = ch["per_level_ms"]
 print(json.dumps(out))

@@ -388,6 +388,16 @@ def test_scaler_many_wide_moduli(fhe):
     cases.case_scaler_many_wide_moduli(fhe, False)
 
 
+EVERY_SCALER_INSTANCE = (2, 3, 5, 7, 8, 10, 11, 13, 14, 15, 16, 18, 19, 22, 23, 26, 27, 30, 31, 32)
+
+
+def test_scaler_every_instance(fhe):
+    """Round 6: scale_kernel<NF> has an instance per source-basis size of BASELINE's configs, the reference's stock sets
+    and the levels of C5's chain (engine.hpp scale_kernel_nf); every instance on its exact fit and on a padded one, factor
+    one (the PLAIN instances) and a non-unit factor, against the oracle's RnsScaler::scale (rns/scaler.rs:249-352)."""
+    cases.case_scaler_many_wide_moduli(fhe, False, counts=EVERY_SCALER_INSTANCE, factors=((1, 1), (3, 7)))
+
+
 @pytest.mark.parametrize("n,bits", [(16384, 60), (32768, 60), (32768, 62), (65536, 60), (65536, 62)])
 def test_key_switch_decomposition_rows(fhe, n, bits):
     """Single-modulus key levels (base-2^k digits of one residue row) on whole rows and on the 16384-point parts of rows

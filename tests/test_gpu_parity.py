@@ -775,6 +775,13 @@ def test_scaler_many_wide_moduli(fhe, dev):
     cases.case_scaler_many_wide_moduli(fhe, dev)
 
 
+def test_scaler_every_instance(fhe):
+    """Round 6: every scale_kernel<NF> instance (engine.hpp scale_kernel_nf: BASELINE's bases, the stock sets, the levels of
+    C5's chain) on its exact fit and on a padded one, factor one (PLAIN) and a non-unit factor, vs the oracle."""
+    cases.case_scaler_many_wide_moduli(fhe, True, counts=(2, 3, 5, 7, 8, 10, 11, 13, 14, 15, 16, 18, 19, 22, 23, 26, 27, 30, 31, 32),
+                                       factors=((1, 1), (3, 7)))
+
+
 @pytest.mark.parametrize("n", [32768, 65536])
 def test_ntt_split_rows_narrow_moduli(fhe, n):
     """Rows larger than LDS over moduli below 2^60 only: the LDS halves of both transforms take the narrow passes

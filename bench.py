@@ -425,11 +425,12 @@ def compact_record(result):
         if result.get("per_rank"):
             rec["multi_gpu"]["rank_max_over_min"] = result["per_rank"].get("max_over_min")
     if result.get("binding_ceilings"):
-        # {config: [frac of 8 TB/s (stage model), frac of the integer-issue ceiling]} for the BASELINE configs and the
-        # reference's stock n = 8192 / 16384 sets; ops/s, the binding ceiling and every other ID: the detail file
+        # {config: [frac of 8 TB/s (stage model), frac of the integer-issue ceiling, ops/s]} for the BASELINE configs and the
+        # reference's stock n = 8192 / 16384 sets; the binding ceiling and every other ID: the detail file
         keep = ("C3_relinearize", "C3_rotate_columns", "C5_level0", "C5_chain", "stock8192_mul_and_relin",
                 "stock8192_relinearize", "stock16384_mul_and_relin", "stock16384_relinearize")
-        rec["configs"] = {k: [v.get("frac_hbm"), v.get("frac_int_issue")] for k, v in result["binding_ceilings"].items()
+        rate = lambda v: None if v.get("ops_per_s") is None else int(round(v["ops_per_s"]))
+        rec["configs"] = {k: [v.get("frac_hbm"), v.get("frac_int_issue"), rate(v)] for k, v in result["binding_ceilings"].items()
                           if k in keep and isinstance(v, dict)}
     if result.get("errors"):
         rec["errors"] = len(result["errors"])

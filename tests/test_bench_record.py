@@ -76,7 +76,7 @@ def test_compact_record_fits_the_driver_tail_and_has_the_keys():
     assert rec["multi_gpu"]["efficiency_vs_1gpu_same_batch"] == 0.9876 and "ranks" not in rec["multi_gpu"]
     rec = json.loads(bench.compact_record(_worst_case(_full(), n1=True)))
     assert rec["roofline"]["dominant_symbol"]["kernel"].startswith("ks_fused_kernel<13")
-    assert len(rec["configs"]) == 8 and len(rec["configs"]["C3_relinearize"]) == 2 and rec["errors"] == 1
+    assert len(rec["configs"]) == 8 and len(rec["configs"]["C3_relinearize"]) == 3 and rec["errors"] == 1
 
 
 def test_compact_record_never_drops_the_contract_when_it_must_shed():

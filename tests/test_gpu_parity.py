@@ -353,7 +353,7 @@ def test_bench_record_is_compact():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"] and cb["unit"] == "ops/s"
     assert rec["ntt"]["row_ntt_per_s"] == 4 * rec["ntt"]["poly_ntt_per_s"] or abs(rec["ntt"]["row_ntt_per_s"] / rec["ntt"]["poly_ntt_per_s"] - 4) < 1e-3
     assert rec["parity"].startswith("bit-identical")
-    # binding ceilings of the other BASELINE configs and the stock sets: [frac_hbm, frac_int_issue]
+    # binding ceilings of the other BASELINE configs and the stock sets: [frac_hbm, frac_int_issue, ops/s]
     for k in ("C3_relinearize", "C3_rotate_columns", "C5_level0", "C5_chain", "stock8192_mul_and_relin", "stock16384_relinearize"):
         assert k in rec["configs"] and 0 < rec["configs"][k][0] < 1 and 0 < rec["configs"][k][1] < 1.05, (k, rec["configs"].get(k))
     assert not det.get("errors"), det.get("errors")

@@ -950,7 +950,9 @@ def reference_default_128(fhe, torch, cpu_ms=None, sets=(4096, 8192, 16384)):
                      ("mul_then_relinearize", lambda: rk.relinearizes(plain.multiply(a, bb))),
                      ("mul_and_relin", lambda: mul.multiply(a, bb)), ("mul_and_relin_2", lambda: mul2.multiply(a, bb))]
             for name, fn in todo:
-                ms = timeit(fn)
+                # (batch entries: the median of three timings -- one timing of three calls moved by up to 8 % between the legs
+                # of one process, r06_final5: 167.9 k here against 182.8 k in tools/f64_ab.py's three repetitions)
+                ms = timeit(fn) if b == 1 else sorted(timeit(fn) for _ in range(3))[1]
                 d = ids.setdefault(name, {})
                 if b == 1:
                     d["single_ms"] = round(ms, 4)

@@ -2305,12 +2305,26 @@ public:
     // synchronised and destroyed, its scratch blocks freed) -- which is also what eventually collects the entries of
     // user streams that no longer exist (a host's own streams: the engine is never told, and cannot ask, see Workspace).
     hipStream_t stream_for(int device, hipStream_t user, bool tag_key = false) {
-        std::vector<hipStream_t> victims;
+        std::vector<std::pair<int, hipStream_t>> victims;
         hipStream_t out;
         {
             std::lock_guard<std::mutex> lk(mu);
             const std::pair<int, hipStream_t> key{device, user};
             Entry &a = reg[key];
+            if (!a.aux) {
+                // A parked stream of this device first (retire): the runtime multiplexes a process's streams onto a few
+                // hardware queues (four by default), assigned round-robin at CREATION -- after a dozen streams have come and
+                // gone a new one can land on the caller's own queue, and the two lanes of a multiply then run one after the
+                // other (bench.py's legs trim the workspace between configs: after its microbenchmarks' sixteen short-lived
+                // streams the stock n = 8192 mul_and_relin fell from 182 k to 165 k ops/s,
+                // profiles/r06_x_aux_priority_ab_rejected.jsonl, rows of the `before` build).  A stream that is kept keeps its queue.
+                for (auto it = parked.begin(); it != parked.end(); ++it)
+                    if (it->first == device) {
+                        a.aux = it->second;
+                        parked.erase(it);
+                        break;
+                    }
+            }
             if (!a.aux) {
                 hipStream_t made = nullptr;
                 const hipError_t err = hipStreamCreateWithFlags(&made, hipStreamNonBlocking);
@@ -2330,7 +2344,7 @@ public:
                     if (!it->second.tag_key && it->second.users == 0 && (lru == reg.end() || it->second.last_use < lru->second.last_use))
                         lru = it;
                 if (lru == reg.end()) break;
-                victims.push_back(lru->second.aux);
+                victims.emplace_back(lru->first.first, lru->second.aux);
                 reg.erase(lru);
             }
         }
@@ -2363,12 +2377,12 @@ public:
     // pooled events as well) is synchronised and destroyed, and the scratch blocks keyed to it are freed (ADVICE r03:
     // they used to stay in the pool under a handle that no longer existed)
     void drop(int device, hipStream_t user, bool all) {
-        std::vector<hipStream_t> victims;
+        std::vector<std::pair<int, hipStream_t>> victims;
         {
             std::lock_guard<std::mutex> lk(mu);
             for (auto it = reg.begin(); it != reg.end();) {
                 if (all || ((device < 0 || it->first.first == device) && it->first.second == user)) {
-                    if (it->second.aux) victims.push_back(it->second.aux);
+                    if (it->second.aux) victims.emplace_back(it->first.first, it->second.aux);
                     it = reg.erase(it);
                 } else {
                     ++it;
@@ -2394,14 +2408,27 @@ private:
         unsigned users = 0;
         uint64_t last_use = 0;
     };
-    static void retire(const std::vector<hipStream_t> &victims) {
-        for (hipStream_t aux : victims) {
+    // An internal stream that is no longer wanted: synchronised, its scratch blocks freed -- and the handle PARKED for the
+    // next stream_for on its device (at most PARK of them; the rest are destroyed).  A stream holds no device memory.
+    void retire(const std::vector<std::pair<int, hipStream_t>> &victims) {
+        for (const auto &v : victims) {
+            hipStream_t aux = v.second;
             if (!aux) continue;
             (void)hipStreamSynchronize(aux);
             Workspace::get().drop_internal_stream(aux);   // (its work is over: plain frees)
-            (void)hipStreamDestroy(aux);
+            bool keep = false;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (parked.size() < PARK) {
+                    parked.emplace_back(v.first, aux);
+                    keep = true;
+                }
+            }
+            if (!keep) (void)hipStreamDestroy(aux);
         }
     }
+    static constexpr size_t PARK = 8;
+    std::vector<std::pair<int, hipStream_t>> parked;
     std::mutex mu;
     std::map<std::pair<int, hipStream_t>, Entry> reg;
     std::vector<hipEvent_t> pool;

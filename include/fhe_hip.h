@@ -464,7 +464,9 @@ fhe_status fhe_synth_uniform_dev(const fhe_ctx *ctx, uint64_t seed, uint64_t ct0
                                  uint64_t *out, size_t batch, void *stream);
 /* The engine keeps its scratch buffers (grow-only, reused in stream order per device), its internal second
  * streams and a few pooled events between calls; this frees every idle one (call it while no engine call is
- * running) and returns the number of scratch bytes released. */
+ * running) and returns the number of scratch bytes released.  (Up to eight idle internal stream HANDLES stay parked
+ * for reuse -- a stream holds no device memory, and the runtime assigns a stream's hardware queue once, at creation:
+ * a re-created stream can land on the caller's queue and serialise the two lanes of a multiply.) */
 size_t fhe_workspace_trim(void);
 /* Bounds on what the engine RETAINS between calls: `per_stream_bytes` for the scratch blocks keyed to one
  * (device, stream), `total_bytes` over all of them; 0 = no bound.  Defaults: no per-stream bound, total = a quarter of

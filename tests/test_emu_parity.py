@@ -104,6 +104,30 @@ def test_multiply_two_streams(fhe):
     cases.case_multiply(fhe, False, nmod=2, level=0, chunk=1, streams=2, batch=5)
 
 
+def test_internal_streams_are_parked_and_reused(fhe):
+    """An internal second stream that the engine gives up (fhe_workspace_trim here) is parked and taken again by the next
+    call that needs one -- a re-created stream can land on the caller's own hardware queue and serialise the two lanes of
+    a multiply (profiles/r06_y_parked_streams_*_ab.jsonl).  White box on the emulator's stream table, which
+    hands out consecutive one-byte slots: between two probes exactly ONE slot (the first probe's) has been taken if
+    the second multiply created no stream."""
+    def probe():
+        s = fhe.Stream(0)
+        v = s.handle.value
+        s.destroy()
+        return v
+    a = fhe.Stream(0)
+    with a:
+        cases.case_multiply(fhe, "abi", nmod=2, n=16, batch=5, chunk=2, streams=2)
+    assert fhe.workspace_stats()["internal_streams"] >= 1
+    first = probe()
+    fhe.workspace_trim()
+    assert fhe.workspace_stats()["internal_streams"] == 0
+    with a:
+        cases.case_multiply(fhe, "abi", nmod=2, n=16, batch=5, chunk=2, streams=2)
+    assert probe() - first == 1
+    a.destroy()
+
+
 @pytest.mark.parametrize("n", [128, 512])
 def test_multiply_vector_tile_paths(fhe, n):
     """Sizes whose tiles take the 16-byte-chunk (CH > 0) load/MAC/store paths of the kernels."""
